@@ -1,0 +1,26 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import numpy as np
+    path = os.path.join(ROOT, "tests", "golden", "repellency_golden.npz")
+    z = np.load(path)
+    cases = {}
+    for key in z.files:
+        if key == "__cases__":
+            continue
+        name, field = key.split("/", 1)
+        cases.setdefault(name, {})[field] = z[key]
+    return cases
