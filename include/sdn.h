@@ -146,6 +146,122 @@ int sdn_flow_endpoints(const float* x, const float* v, int64_t n, float sigma, f
 int sdn_flow_renoise(const float* x0r, const float* x1, const float* z, int64_t n, float sigma_next,
                      float* out, void* stream);
 
+/* ===================================================================================== *
+ *  Denoiser-network operators (rows U1-U6) -- bf16 storage, fp32 accumulation.
+ *  Activations are NHWC bf16: a [B,H,W,C] feature map is the [B*H*W, C] token matrix.
+ *  The reference runs these through diffusers 0.29.0 (third-party; wiring spec vendored at
+ *  models/unet.py:683-932, models/unet_2d_blocks.py, models/transformer_2d.py:239-359).
+ * ===================================================================================== */
+
+#define SDN_A_PLAIN    0   /* A is [M, K] row-major (optionally split in two sources at K1)   */
+#define SDN_A_CONV3X3  1   /* A is the implicit im2col of an NHWC map: 3x3, pad 1             */
+#define SDN_ACT_NONE   0
+#define SDN_ACT_SILU   1
+#define SDN_ACT_GEGLU  2   /* W rows interleaved value/gate in blocks of 16; out = v*gelu(g)  */
+#define SDN_OUT_BF16      0   /* [M, ldc] bf16                                                */
+#define SDN_OUT_F32       1   /* [M, ldc] f32                                                 */
+#define SDN_OUT_F32_NCHW  2   /* [B, n_valid, rows_per_batch] f32 (conv_out -> latent layout) */
+
+typedef struct sdn_gemm_desc {
+  int32_t M, N, K;          /* C[M,N] = A[M,K] . W[N,K]^T ; K % 64 == 0 ; N % 32 == 0           */
+  int32_t a_mode;           /* SDN_A_*                                                         */
+  int32_t K1;               /* PLAIN: columns [0,K1) come from `a` (ld K1), [K1,K) from `a2`
+                               (ld K-K1): the skip-concat of the up blocks, never materialised;
+                               0 or K = single source                                         */
+  int32_t Hs, Ws, Cin;      /* CONV3X3: stored input map [B,Hs,Ws,Cin], K = 9*Cin             */
+  int32_t Ho, Wo, stride;   /*          output map, stride 1|2 (Downsample2D)                  */
+  int32_t upsample;         /*          1 = nearest-2x of the stored map first (Upsample2D)    */
+  int32_t act;              /* SDN_ACT_*                                                       */
+  int32_t out_kind;         /* SDN_OUT_*                                                       */
+  int32_t rows_per_batch;   /* rows of one sample (H*W): row -> sample for rowbias / NCHW      */
+  int32_t ld_rowbias;       /* leading dimension of rowbias [B, ld_rowbias]                    */
+  int32_t n_valid;          /* columns actually stored (0 = N); W is zero-padded to N rows     */
+  int32_t ldc;              /* leading dimension of out/residual (0 = natural)                 */
+} sdn_gemm_desc;
+
+/* out = act(A.W^T + bias[n] + rowbias[b(m), n] + residual[m, n]).
+ * Replaces F.linear / conv2d(3x3 | 1x1) + the adds around them: ResnetBlock2D conv1 (+ time_emb_proj
+ * broadcast), conv2 (+ shortcut), Downsample2D, Upsample2D, Transformer2DModel proj_in/proj_out
+ * (models/transformer_2d.py:810-858), Attention to_q/k/v/out, FeedForward GEGLU (models/transformer_2d.py:335-355). */
+int sdn_gemm_bf16(const sdn_gemm_desc* d_host, const void* a, const void* a2, const void* w,
+                  const float* bias, const float* rowbias, const void* residual, void* out, void* stream);
+
+/* GroupNorm (+ optional SiLU) over an NHWC bf16 map, optionally over the channel-concat of two maps
+ * (x [B,HW,C1] ++ x2 [B,HW,C2]) written as ONE normalised map [B,HW,C1+C2].
+ * stats_ws: B*16*groups*2 floats of scratch (deterministic two-level reduction).  Replaces GroupNorm+SiLU of ResnetBlock2D (eps 1e-5) and the
+ * GroupNorm of Transformer2DModel (eps 1e-6, no SiLU; models/transformer_2d.py:506-512). */
+int sdn_groupnorm_bf16(const void* x, const void* x2, int32_t batch, int32_t hw, int32_t c1, int32_t c2,
+                       int32_t groups, float eps, int32_t silu, const float* gamma, const float* beta,
+                       void* out, float* stats_ws, void* stream);
+
+/* LayerNorm over the last axis of [rows, C] bf16 (eps 1e-5, affine) -- BasicTransformerBlock norm1/2/3
+ * (models/transformer_2d.py:265,305,335). */
+int sdn_layernorm_bf16(const void* x, int64_t rows, int32_t c, float eps, const float* gamma,
+                       const float* beta, void* out, void* stream);
+
+/* softmax(Q K^T * scale) V per (batch, head); flash-style, never materialises the score matrix.
+ *   q [B, Nq, ldq] (head h at columns h*d .. h*d+d), k/v [B, Nk, ldk/ldv] likewise, out [B, Nq, ldo].
+ * d in {40, 80, 160} (SD-v1.4: 8 heads at C = 320/640/1280) or 64 (MMDiT).  Nq % 32 == 0.
+ * Replaces F.scaled_dot_product_attention in diffusers' AttnProcessor2_0 (imported at
+ * models/unet_2d_blocks.py:24; called from BasicTransformerBlock, models/transformer_2d.py:284-328). */
+int sdn_attention_bf16(const void* q, const void* k, const void* v, void* out, int32_t batch, int32_t heads,
+                       int32_t nq, int32_t nk, int32_t head_dim, int32_t ldq, int32_t ldk, int32_t ldv,
+                       int32_t ldo, float scale, void* stream);
+
+/* conv_in: 3x3 conv of the fp32 NCHW latent [B,Cin<=16,H,W] into an NHWC bf16 map [B,H,W,Cout]
+ * (models/unet.py:840).  w is [Cout][3][3][Cin] bf16, bias f32. */
+int sdn_conv_in_bf16(const float* latents_nchw, const void* w, const float* bias, int32_t batch, int32_t cin,
+                     int32_t h, int32_t wd, int32_t cout, void* out_nhwc, void* stream);
+
+/* Sinusoidal timestep features, flip_sin_to_cos, shift 0: out[b] = [cos(t f_k) | sin(t f_k)], f_k =
+ * exp(-ln(1e4) k / half) -> bf16 [B, dim]  (Timesteps(320), models/unet.py:764-786). */
+int sdn_timestep_embed_bf16(float timestep, int32_t batch, int32_t dim, void* out, void* stream);
+
+/* ---- whole-network entry: SD-v1.4-family UNet2DConditionModel forward -------------------------- */
+typedef struct sdn_unet_config {
+  int32_t in_channels, out_channels, sample_size;      /* 4, 4, 64                                  */
+  int32_t n_levels;                                    /* 4                                         */
+  int32_t block_out_channels[4];                       /* 320, 640, 1280, 1280                      */
+  int32_t level_has_attn[4];                           /* 1,1,1,0 (CrossAttnDown x3, DownBlock2D)   */
+  int32_t layers_per_block;                            /* 2                                         */
+  int32_t n_heads;                                     /* 8 (config key attention_head_dim, legacy) */
+  int32_t cross_dim, text_len;                         /* 768, 77                                   */
+  int32_t norm_groups;                                 /* 32                                        */
+} sdn_unet_config;
+
+typedef struct sdn_unet sdn_unet;   /* opaque: op plan + parameter manifest (host memory only) */
+
+/* parameter kinds = how a diffusers state_dict tensor is laid out in the packed weight buffer */
+#define SDN_P_VEC_F32     0   /* 1-D -> f32                                                    */
+#define SDN_P_MAT         1   /* [out,in] or [out,in,1,1] -> bf16 [out][in]                    */
+#define SDN_P_CONV3X3     2   /* [out,in,3,3] -> bf16 [out][ky][kx][in], rows zero-padded      */
+#define SDN_P_GEGLU_MAT   3   /* [2F,in] -> bf16, rows interleaved value/gate in blocks of 16  */
+#define SDN_P_GEGLU_VEC   4   /* [2F] -> f32, interleaved the same way                         */
+
+typedef struct sdn_param_info {
+  char     name[128];       /* diffusers state_dict key                                          */
+  int32_t  kind;            /* SDN_P_*                                                            */
+  int32_t  rows, cols;      /* source logical matrix (rows = out features; cols = in*kh*kw)      */
+  int32_t  rows_padded;     /* rows reserved in the packed buffer (zero filled beyond `rows`)    */
+  int64_t  offset;          /* byte offset in the packed weight buffer                           */
+} sdn_param_info;
+
+int    sdn_unet_create(const sdn_unet_config* cfg_host, sdn_unet** out_host);
+void   sdn_unet_destroy(sdn_unet* u);
+int    sdn_unet_param_count(const sdn_unet* u);
+int    sdn_unet_param_info(const sdn_unet* u, int32_t index, sdn_param_info* info_host);
+size_t sdn_unet_weight_bytes(const sdn_unet* u);
+size_t sdn_unet_workspace_bytes(sdn_unet* u, int32_t batch);
+/* Total algorithmic FLOPs of one forward at this batch (2*M*N*K of every GEMM + attention cores), and the
+ * attention-core share -- the numerators of the MFMA roofline. */
+double sdn_unet_flops(sdn_unet* u, int32_t batch, double* attention_core_flops_host);
+
+/* eps = UNet(latents, t, text):  latents [B, in_ch, S, S] fp32 NCHW, text [B, text_len, cross_dim] bf16,
+ * out [B, out_ch, S, S] fp32 NCHW.  One timestep for the whole batch (the reference passes a scalar t,
+ * ...threshold_time.py:538).  Replaces self.unet(latent_model_input, t, encoder_hidden_states=E).sample. */
+int sdn_unet_forward(sdn_unet* u, const void* weights, const float* latents, float timestep, const void* text,
+                     float* out, int32_t batch, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,11 +32,22 @@ class RepelParams(C.Structure):
                 ("scale", C.c_float), ("epsilon", C.c_float), ("gate", C.c_float)]
 
 
+class GemmDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("M", "N", "K", "a_mode", "K1", "Hs", "Ws", "Cin", "Ho", "Wo", "stride",
+                                         "upsample", "act", "out_kind", "rows_per_batch", "ld_rowbias", "n_valid",
+                                         "ldc")]
+
+
 class UnetConfig(C.Structure):
     _fields_ = [("in_channels", C.c_int32), ("out_channels", C.c_int32), ("sample_size", C.c_int32),
                 ("n_levels", C.c_int32), ("block_out_channels", C.c_int32 * 4), ("level_has_attn", C.c_int32 * 4),
                 ("layers_per_block", C.c_int32), ("n_heads", C.c_int32), ("cross_dim", C.c_int32),
-                ("text_len", C.c_int32), ("norm_groups", C.c_int32), ("dtype", C.c_int32)]
+                ("text_len", C.c_int32), ("norm_groups", C.c_int32)]
+
+
+class ParamInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 128), ("kind", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32),
+                ("rows_padded", C.c_int32), ("offset", C.c_int64)]
 
 
 _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
@@ -56,6 +67,21 @@ SIGNATURES = {
     "sdn_flow_euler_step": (C.c_int, [_vp, _vp, _i64, _f32, _f32, _vp, _vp]),
     "sdn_flow_endpoints": (C.c_int, [_vp, _vp, _i64, _f32, _vp, _vp, _vp]),
     "sdn_flow_renoise": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp, _vp]),
+    "sdn_gemm_bf16": (C.c_int, [C.POINTER(GemmDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sdn_groupnorm_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "sdn_layernorm_bf16": (C.c_int, [_vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp]),
+    "sdn_attention_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32,
+                                     _vp]),
+    "sdn_conv_in_bf16": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "sdn_timestep_embed_bf16": (C.c_int, [_f32, _i32, _i32, _vp, _vp]),
+    "sdn_unet_create": (C.c_int, [C.POINTER(UnetConfig), C.POINTER(_vp)]),
+    "sdn_unet_destroy": (None, [_vp]),
+    "sdn_unet_param_count": (C.c_int, [_vp]),
+    "sdn_unet_param_info": (C.c_int, [_vp, _i32, C.POINTER(ParamInfo)]),
+    "sdn_unet_weight_bytes": (_sz, [_vp]),
+    "sdn_unet_workspace_bytes": (_sz, [_vp, _i32]),
+    "sdn_unet_flops": (C.c_double, [_vp, _i32, C.POINTER(C.c_double)]),
+    "sdn_unet_forward": (C.c_int, [_vp, _vp, _vp, _f32, _vp, _vp, _i32, _vp, _sz, _vp]),
 }
 
 

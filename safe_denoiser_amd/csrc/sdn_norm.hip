@@ -1,0 +1,291 @@
+// GroupNorm(+SiLU), LayerNorm, conv_in and the timestep embedding: the HBM-bound operators of the UNet
+// (rows U1, U3-U5).  All read bf16 NHWC in 16-byte chunks, accumulate in fp32 and write bf16 once.
+#include "sdn_common.h"
+#include "sdn_ops.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+constexpr int THREADS = 256;
+constexpr int GN_MAX_TILES = 16;
+
+__device__ __forceinline__ float bf2f(unsigned v16) { return __uint_as_float(v16 << 16); }
+__device__ __forceinline__ void unpack8(const u32x4 v, float* f) {
+  f[0] = bf2f(v.x & 0xffff); f[1] = bf2f(v.x >> 16); f[2] = bf2f(v.y & 0xffff); f[3] = bf2f(v.y >> 16);
+  f[4] = bf2f(v.z & 0xffff); f[5] = bf2f(v.z >> 16); f[6] = bf2f(v.w & 0xffff); f[7] = bf2f(v.w >> 16);
+}
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  bf16x2 p = {(__bf16)lo, (__bf16)hi};
+  return *reinterpret_cast<unsigned*>(&p);
+}
+__device__ __forceinline__ u32x4 pack8(const float* f) {
+  return (u32x4){pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7])};
+}
+__device__ __forceinline__ float silu_f(float v) { return v / (1.f + __expf(-v)); }
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm pass 1: per (sample, row tile) partial sums per group, deterministic.
+// Thread (cl, rl): cl owns NCH fixed 8-channel chunks, rl strides over the tile's rows.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(THREADS)
+k_gn_stats(const unsigned short* __restrict__ x, const unsigned short* __restrict__ x2, int hw, int c1, int c2,
+           int groups, int rows_per_tile, int ct, int nch, float* __restrict__ partials) {
+  extern __shared__ float lds[];                 // [rt][C][2]
+  const int C = c1 + c2, cpg = C / groups;
+  const int b = blockIdx.x, tile = blockIdx.y, ntiles = gridDim.y;
+  const int rt = THREADS / ct;
+  const int cl = threadIdx.x % ct, rl = threadIdx.x / ct;
+  const int r_lo = tile * rows_per_tile, r_hi = min(hw, r_lo + rows_per_tile);
+  if (rl < rt) {
+    for (int q = 0; q < nch; ++q) {
+      const int ch0 = (cl + q * ct) * 8;
+      const unsigned short* src; int ld, cc;
+      if (ch0 < c1) { src = x; ld = c1; cc = ch0; } else { src = x2; ld = c2; cc = ch0 - c1; }
+      float s[8], ss[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
+      for (int r = r_lo + rl; r < r_hi; r += rt) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(src + ((long)b * hw + r) * ld + cc);
+        float f[8];
+        unpack8(v, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[e] += f[e]; ss[e] = fmaf(f[e], f[e], ss[e]); }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        lds[((long)rl * C + ch0 + e) * 2 + 0] = s[e];
+        lds[((long)rl * C + ch0 + e) * 2 + 1] = ss[e];
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < groups) {
+    const int gidx = threadIdx.x;
+    float s = 0.f, ss = 0.f;
+    for (int r = 0; r < rt; ++r)
+      for (int c = gidx * cpg; c < (gidx + 1) * cpg; ++c) {
+        s += lds[((long)r * C + c) * 2 + 0];
+        ss += lds[((long)r * C + c) * 2 + 1];
+      }
+    float* o = partials + (((long)b * ntiles + tile) * groups + gidx) * 2;
+    o[0] = s; o[1] = ss;
+  }
+}
+
+// GroupNorm pass 2: normalise + affine (+SiLU), write the (concatenated) map.
+__global__ void __launch_bounds__(THREADS)
+k_gn_apply(const unsigned short* __restrict__ x, const unsigned short* __restrict__ x2, int hw, int c1, int c2,
+           int groups, int ntiles, int rows_per_block, float eps, int silu, const float* __restrict__ gamma,
+           const float* __restrict__ beta, const float* __restrict__ partials, unsigned short* __restrict__ out) {
+  __shared__ float s_mean[64], s_rstd[64];
+  const int C = c1 + c2, cpg = C / groups, cchunks = C / 8;
+  const int b = blockIdx.x;
+  if (threadIdx.x < groups) {
+    float s = 0.f, ss = 0.f;
+    for (int t = 0; t < ntiles; ++t) {
+      const float* p = partials + (((long)b * ntiles + t) * groups + threadIdx.x) * 2;
+      s += p[0]; ss += p[1];
+    }
+    const float n = (float)hw * (float)cpg;
+    const float mean = s / n;
+    const float var = fmaxf(ss / n - mean * mean, 0.f);
+    s_mean[threadIdx.x] = mean;
+    s_rstd[threadIdx.x] = rsqrtf(var + eps);
+  }
+  __syncthreads();
+  const int r_lo = blockIdx.y * rows_per_block, r_hi = min(hw, r_lo + rows_per_block);
+  const long total = (long)(r_hi - r_lo) * cchunks;
+  for (long e = threadIdx.x; e < total; e += THREADS) {
+    const int r = r_lo + (int)(e / cchunks), ch0 = (int)(e % cchunks) * 8;
+    const unsigned short* src; int ld, cc;
+    if (ch0 < c1) { src = x; ld = c1; cc = ch0; } else { src = x2; ld = c2; cc = ch0 - c1; }
+    const u32x4 v = *reinterpret_cast<const u32x4*>(src + ((long)b * hw + r) * ld + cc);
+    float f[8];
+    unpack8(v, f);
+    const float4 g0 = *reinterpret_cast<const float4*>(gamma + ch0), g1 = *reinterpret_cast<const float4*>(gamma + ch0 + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(beta + ch0), b1 = *reinterpret_cast<const float4*>(beta + ch0 + 4);
+    const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+    const float bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int gi = (ch0 + k) / cpg;
+      float y = (f[k] - s_mean[gi]) * s_rstd[gi] * gm[k] + bt[k];
+      f[k] = silu ? silu_f(y) : y;
+    }
+    *reinterpret_cast<u32x4*>(out + ((long)b * hw + r) * C + ch0) = pack8(f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, up to 4 chunks (C <= 2048) held in registers; two-pass variance.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(THREADS)
+k_layernorm(const unsigned short* __restrict__ x, long rows, int C, float eps, const float* __restrict__ gamma,
+            const float* __restrict__ beta, unsigned short* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int cchunks = C / 8;
+  float f[4][8];
+  float s = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int cc = lane + q * 64;
+    if (cc < cchunks) {
+      unpack8(*reinterpret_cast<const u32x4*>(x + row * C + cc * 8), f[q]);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += f[q][k];
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float ss = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int cc = lane + q * 64;
+    if (cc < cchunks) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const float d = f[q][k] - mean; ss = fmaf(d, d, ss); }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)C + eps);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int cc = lane + q * 64;
+    if (cc < cchunks) {
+      const float4 g0 = *reinterpret_cast<const float4*>(gamma + cc * 8), g1 = *reinterpret_cast<const float4*>(gamma + cc * 8 + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(beta + cc * 8), b1 = *reinterpret_cast<const float4*>(beta + cc * 8 + 4);
+      const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+      const float bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      float y[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) y[k] = (f[q][k] - mean) * rstd * gm[k] + bt[k];
+      *reinterpret_cast<u32x4*>(out + row * C + cc * 8) = pack8(y);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv_in: direct 3x3 conv, fp32 NCHW latent -> NHWC bf16.  One thread = one pixel x 8 output channels.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(THREADS)
+k_conv_in(const float* __restrict__ lat, const unsigned short* __restrict__ w, const float* __restrict__ bias,
+          int B, int cin, int H, int W, int cout, unsigned short* __restrict__ out) {
+  extern __shared__ float wl[];                   // [cout][9*cin] as f32
+  const int kk = 9 * cin;
+  for (int i = threadIdx.x; i < cout * kk; i += THREADS) wl[i] = bf2f(w[i]);
+  __syncthreads();
+  const int cchunks = cout / 8;
+  const long total = (long)B * H * W * cchunks;
+  for (long e = (long)blockIdx.x * THREADS + threadIdx.x; e < total; e += (long)gridDim.x * THREADS) {
+    const int cc = (int)(e % cchunks);
+    const long pix = e / cchunks;
+    const int xw = (int)(pix % W), yh = (int)((pix / W) % H), b = (int)(pix / ((long)W * H));
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = bias[cc * 8 + k];
+    for (int tap = 0; tap < 9; ++tap) {
+      const int iy = yh + tap / 3 - 1, ix = xw + tap % 3 - 1;
+      if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+      for (int c = 0; c < cin; ++c) {
+        const float v = lat[(((long)b * cin + c) * H + iy) * W + ix];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = fmaf(v, wl[(cc * 8 + k) * kk + tap * cin + c], acc[k]);
+      }
+    }
+    *reinterpret_cast<u32x4*>(out + pix * cout + cc * 8) = pack8(acc);
+  }
+}
+
+__global__ void k_temb(float t, int B, int dim, unsigned short* __restrict__ out) {
+  const int half = dim / 2;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * dim; i += gridDim.x * blockDim.x) {
+    const int k = i % dim;
+    const int kk = k < half ? k : k - half;
+    const float f = expf(-9.210340371976184f * (float)kk / (float)half);   // ln(10000)
+    const float a = t * f;
+    const float v = k < half ? cosf(a) : sinf(a);
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    bf16x2 p = {(__bf16)v, (__bf16)0.f};
+    out[i] = (unsigned short)(*reinterpret_cast<unsigned*>(&p) & 0xffff);
+  }
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int sdn_groupnorm_bf16(const void* x, const void* x2, int32_t batch, int32_t hw, int32_t c1, int32_t c2,
+                       int32_t groups, float eps, int32_t silu, const float* gamma, const float* beta, void* out,
+                       float* stats_ws, void* stream) {
+  if (!x || !gamma || !beta || !out || !stats_ws || batch < 0 || hw <= 0 || c1 <= 0 || c2 < 0 || groups <= 0 ||
+      groups > 64)
+    return SDN_E_INVALID;
+  if (c2 > 0 && !x2) return SDN_E_INVALID;
+  const int C = c1 + c2;
+  if ((c1 & 7) || (c2 & 7) || C % groups != 0 || C > 4096) return SDN_E_INVALID;
+  if (!al16(x) || (x2 && !al16(x2)) || !al16(out) || !al16(gamma) || !al16(beta)) return SDN_E_INVALID;
+  if (batch == 0) return SDN_OK;
+  const int cch = C / 8;
+  int nch = (cch + THREADS - 1) / THREADS;
+  while (cch % nch != 0) ++nch;
+  const int ct = cch / nch;
+  if (ct > THREADS) return SDN_E_INVALID;
+  const int rt = THREADS / ct;
+  int ntiles = hw / 256;                      // >= 256 rows per stats tile
+  if (ntiles < 1) ntiles = 1;
+  if (ntiles > GN_MAX_TILES) ntiles = GN_MAX_TILES;
+  const int rows_per_tile = (hw + ntiles - 1) / ntiles;
+  ntiles = (hw + rows_per_tile - 1) / rows_per_tile;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = (size_t)rt * C * 2 * sizeof(float);
+  if (lds > 64 * 1024) return SDN_E_INVALID;
+  hipLaunchKernelGGL(k_gn_stats, dim3(batch, ntiles), dim3(THREADS), lds, st, (const unsigned short*)x,
+                     (const unsigned short*)x2, hw, c1, c2, groups, rows_per_tile, ct, nch, stats_ws);
+  int rows_per_block = (256 * 8 * 4) / C;     // ~4 chunks per thread
+  if (rows_per_block < 1) rows_per_block = 1;
+  const int nblk = (hw + rows_per_block - 1) / rows_per_block;
+  hipLaunchKernelGGL(k_gn_apply, dim3(batch, nblk), dim3(THREADS), 0, st, (const unsigned short*)x,
+                     (const unsigned short*)x2, hw, c1, c2, groups, ntiles, rows_per_block, eps, silu, gamma, beta,
+                     stats_ws, (unsigned short*)out);
+  return sdn_launch_status();
+}
+
+int sdn_layernorm_bf16(const void* x, int64_t rows, int32_t c, float eps, const float* gamma, const float* beta,
+                       void* out, void* stream) {
+  if (!x || !gamma || !beta || !out || rows < 0 || c <= 0 || (c & 7) || c > 2048) return SDN_E_INVALID;
+  if (!al16(x) || !al16(out) || !al16(gamma) || !al16(beta)) return SDN_E_INVALID;
+  if (rows == 0) return SDN_OK;
+  hipLaunchKernelGGL(k_layernorm, dim3((unsigned)((rows + 3) / 4)), dim3(THREADS), 0, (hipStream_t)stream,
+                     (const unsigned short*)x, (long)rows, c, eps, gamma, beta, (unsigned short*)out);
+  return sdn_launch_status();
+}
+
+int sdn_conv_in_bf16(const float* lat, const void* w, const float* bias, int32_t batch, int32_t cin, int32_t h,
+                     int32_t wd, int32_t cout, void* out, void* stream) {
+  if (!lat || !w || !bias || !out || batch < 0 || cin <= 0 || cin > 16 || h <= 0 || wd <= 0 || cout <= 0 ||
+      (cout & 7) || !al16(out))
+    return SDN_E_INVALID;
+  if (batch == 0) return SDN_OK;
+  const size_t lds = (size_t)cout * 9 * cin * sizeof(float);
+  if (lds > 64 * 1024) return SDN_E_INVALID;
+  const long total = (long)batch * h * wd * (cout / 8);
+  long grid = (total + THREADS - 1) / THREADS;
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(k_conv_in, dim3((unsigned)grid), dim3(THREADS), lds, (hipStream_t)stream, lat,
+                     (const unsigned short*)w, bias, batch, cin, h, wd, cout, (unsigned short*)out);
+  return sdn_launch_status();
+}
+
+int sdn_timestep_embed_bf16(float timestep, int32_t batch, int32_t dim, void* out, void* stream) {
+  if (!out || batch < 0 || dim <= 0 || (dim & 1)) return SDN_E_INVALID;
+  if (batch == 0) return SDN_OK;
+  const int n = batch * dim;
+  hipLaunchKernelGGL(k_temb, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, timestep, batch, dim,
+                     (unsigned short*)out);
+  return sdn_launch_status();
+}
+
+}  // extern "C"

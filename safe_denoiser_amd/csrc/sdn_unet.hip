@@ -1,0 +1,563 @@
+// UNet2DConditionModel forward (row U1/U2) as a static launch plan over libsdn's operators.
+//
+// Host-only logic: from the config it derives (a) the parameter manifest -- every diffusers state_dict key the
+// network needs, with the layout it takes inside ONE packed weight buffer -- and (b) per batch size, a linear
+// list of kernel launches with all activation addresses resolved at plan time inside ONE workspace (liveness-
+// based reuse so the hot working set stays L2 / Infinity-Cache resident).  sdn_unet_forward() then only walks
+// the list and launches; it never allocates or synchronises (hipGraph-capturable).
+//
+// Wiring follows the reference's vendored spec: models/unet.py:683-932 (forward), models/unet_2d_blocks.py
+// :769-924 (mid), :1174-1426 (down), :2416-2704 (up), models/transformer_2d.py:239-359,505-540,810-858, and the
+// diffusers-0.29.0 leaf definitions restated in SURVEY.md appendix A.
+//
+// Fusions relative to the reference graph (results identical up to rounding):
+//   * to_q/to_k/to_v of self-attention = one GEMM over the stacked [3C, C] weight; to_k/to_v of cross-attention
+//     = one GEMM over [2C, 768];
+//   * all 22 ResnetBlock2D time_emb_proj linears = ONE GEMM per forward ([B,1280] x [sum Cout, 1280]); its f32
+//     rows are added inside conv1's epilogue together with the conv bias;
+//   * SiLU(temb) folded into time_embedding.linear_2's epilogue (temb is only ever consumed through SiLU);
+//   * residual adds, shortcut adds, GEGLU, bias: GEMM epilogues; torch.cat([h, skip]) is never materialised for
+//     the 1x1 shortcut (two-source A operand) and is written once, already normalised, by GroupNorm for conv1;
+//   * nearest-2x upsample and the stride-2 downsample are index arithmetic inside the conv's im2col loader;
+//   * conv_out writes the fp32 NCHW latent layout directly.
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "sdn_common.h"
+#include "sdn_ops.h"
+
+namespace {
+
+enum Space { SP_NONE = 0, SP_W = 1, SP_WS = 2, SP_LATENTS = 3, SP_TEXT = 4, SP_OUT = 5 };
+struct Ref { int space = SP_NONE; int64_t off = 0; };
+
+enum OpKind { OP_TEMB, OP_CONV_IN, OP_GEMM, OP_GN, OP_LN, OP_ATTN };
+
+struct Op {
+  int kind;
+  sdn_gemm_desc gd;
+  Ref a, a2, w, bias, rowbias, residual, out, aux;
+  // GN / LN / conv_in / attention scalars
+  int batch = 0, hw = 0, c1 = 0, c2 = 0, groups = 0, silu = 0;
+  float eps = 0.f;
+  int64_t rows = 0;
+  int heads = 0, nq = 0, nk = 0, hd = 0, ldq = 0, ldk = 0, ldv = 0, ldo = 0;
+  float scale = 0.f;
+  Ref k, v;
+};
+
+struct Arena {                      // plan-time first-fit allocator with coalescing; offsets are 256-B aligned
+  std::map<int64_t, int64_t> free_;  // off -> size
+  int64_t top = 0, peak = 0;
+  static int64_t up(int64_t v) { return (v + 255) & ~(int64_t)255; }
+  int64_t alloc(int64_t bytes) {
+    bytes = up(bytes);
+    for (auto it = free_.begin(); it != free_.end(); ++it) {
+      if (it->second >= bytes) {
+        const int64_t off = it->first, rest = it->second - bytes;
+        free_.erase(it);
+        if (rest > 0) free_[off + bytes] = rest;
+        return off;
+      }
+    }
+    // extend the top (merge with a free block that touches the top)
+    if (!free_.empty()) {
+      auto last = std::prev(free_.end());
+      if (last->first + last->second == top) {
+        const int64_t off = last->first;
+        free_.erase(last);
+        top = off + bytes;
+        if (top > peak) peak = top;
+        return off;
+      }
+    }
+    const int64_t off = top;
+    top += bytes;
+    if (top > peak) peak = top;
+    return off;
+  }
+  void release(int64_t off, int64_t bytes) {
+    bytes = up(bytes);
+    auto it = free_.emplace(off, bytes).first;
+    auto nx = std::next(it);
+    if (nx != free_.end() && it->first + it->second == nx->first) { it->second += nx->second; free_.erase(nx); }
+    if (it != free_.begin()) {
+      auto pv = std::prev(it);
+      if (pv->first + pv->second == it->first) { pv->second += it->second; free_.erase(it); }
+    }
+  }
+};
+
+struct Act {                         // a bf16 [rows, C] activation living in the workspace
+  int64_t off = -1, bytes = 0; int C = 0, hw = 0, side = 0;
+};
+
+struct Plan {
+  int batch = 0;
+  std::vector<Op> ops;
+  int64_t ws_bytes = 0;
+  double flops = 0.0, attn_flops = 0.0;
+};
+
+}  // namespace
+
+struct sdn_unet {
+  sdn_unet_config cfg;
+  std::vector<sdn_param_info> params;
+  std::map<std::string, int> param_index;
+  int64_t weight_bytes = 0;
+  std::map<int, Plan> plans;
+  int tproj_total = 0;
+};
+
+namespace {
+
+struct Builder {
+  sdn_unet* u;
+  Plan* plan;
+  Arena arena;
+  int B;
+  Ref tproj;                 // f32 [B, tproj_total]
+  int tproj_cursor = 0;      // column offset of the next resnet's slice
+  Ref gn_stats;
+
+  // ---- parameters -------------------------------------------------------------------------------
+  Ref param(const std::string& name, int kind, int rows, int cols, int rows_padded = 0) {
+    auto it = u->param_index.find(name);
+    if (it != u->param_index.end()) return Ref{SP_W, u->params[it->second].offset};
+    sdn_param_info pi;
+    memset(&pi, 0, sizeof(pi));
+    snprintf(pi.name, sizeof(pi.name), "%s", name.c_str());
+    pi.kind = kind; pi.rows = rows; pi.cols = cols; pi.rows_padded = rows_padded > rows ? rows_padded : rows;
+    const int64_t esz = (kind == SDN_P_VEC_F32 || kind == SDN_P_GEGLU_VEC) ? 4 : 2;
+    const int64_t bytes = (int64_t)pi.rows_padded * (cols > 0 ? cols : 1) * esz;
+    pi.offset = u->weight_bytes;
+    u->weight_bytes += (bytes + 255) & ~(int64_t)255;
+    u->param_index[name] = (int)u->params.size();
+    u->params.push_back(pi);
+    return Ref{SP_W, pi.offset};
+  }
+  // members of a stacked matrix must be byte-contiguous: their sizes are multiples of 256 B for every SD width
+  Ref stacked(const std::vector<std::string>& names, int rows_each, int cols) {
+    Ref first;
+    int64_t expect = -1;
+    for (size_t i = 0; i < names.size(); ++i) {
+      Ref r = param(names[i], SDN_P_MAT, rows_each, cols);
+      if (i == 0) first = r;
+      else if (r.off != expect) { fprintf(stderr, "libsdn: stacked weight %s is not contiguous\n", names[i].c_str()); abort(); }
+      expect = r.off + (int64_t)rows_each * cols * 2;
+    }
+    return first;
+  }
+
+  // ---- activations ------------------------------------------------------------------------------
+  Act act(int64_t rows, int C, int hw = 0, int side = 0, int esz = 2) {
+    Act t; t.bytes = rows * C * esz; t.off = arena.alloc(t.bytes); t.C = C; t.hw = hw; t.side = side; return t;
+  }
+  void drop(Act& t) { if (t.off >= 0) arena.release(t.off, t.bytes); t.off = -1; }
+  static Ref R(const Act& t) { return Ref{SP_WS, t.off}; }
+
+  // ---- op emitters ------------------------------------------------------------------------------
+  void gemm(int64_t M, int N, int K, Ref a, Ref w, Ref bias, Ref out, int act_ = SDN_ACT_NONE, Ref residual = Ref(),
+            int out_kind = SDN_OUT_BF16, int n_valid = 0, Ref a2 = Ref(), int K1 = 0, Ref rowbias = Ref(),
+            int rows_per_batch = 0, int ld_rowbias = 0) {
+    Op o; o.kind = OP_GEMM; memset(&o.gd, 0, sizeof(o.gd));
+    o.gd.M = (int)M; o.gd.N = N; o.gd.K = K; o.gd.a_mode = SDN_A_PLAIN; o.gd.K1 = K1; o.gd.act = act_;
+    o.gd.out_kind = out_kind; o.gd.n_valid = n_valid; o.gd.rows_per_batch = rows_per_batch; o.gd.ld_rowbias = ld_rowbias;
+    o.a = a; o.a2 = a2; o.w = w; o.bias = bias; o.rowbias = rowbias; o.residual = residual; o.out = out;
+    plan->ops.push_back(o);
+    plan->flops += 2.0 * (double)M * (double)(n_valid > 0 ? n_valid : N) * (double)K;
+  }
+  void conv3x3(const Act& in, int cout, int n_pad, Ref w, Ref bias, Ref out, int stride, int upsample, Ref residual,
+               Ref rowbias, int ld_rowbias, int out_kind = SDN_OUT_BF16, int n_valid = 0) {
+    const int Hi = upsample ? in.side * 2 : in.side;
+    const int Ho = (Hi + 2 - 3) / stride + 1;
+    Op o; o.kind = OP_GEMM; memset(&o.gd, 0, sizeof(o.gd));
+    o.gd.M = B * Ho * Ho; o.gd.N = n_pad; o.gd.K = 9 * in.C; o.gd.a_mode = SDN_A_CONV3X3;
+    o.gd.Hs = in.side; o.gd.Ws = in.side; o.gd.Cin = in.C; o.gd.Ho = Ho; o.gd.Wo = Ho; o.gd.stride = stride;
+    o.gd.upsample = upsample; o.gd.out_kind = out_kind; o.gd.n_valid = n_valid; o.gd.rows_per_batch = Ho * Ho;
+    o.gd.ld_rowbias = ld_rowbias;
+    o.a = R(in); o.w = w; o.bias = bias; o.rowbias = rowbias; o.residual = residual; o.out = out;
+    plan->ops.push_back(o);
+    plan->flops += 2.0 * (double)o.gd.M * (double)cout * (double)o.gd.K;
+  }
+  void groupnorm(const Act& x, const Act* x2, float eps, int silu, Ref gamma, Ref beta, const Act& out) {
+    Op o; o.kind = OP_GN; o.a = R(x); if (x2) o.a2 = R(*x2);
+    o.batch = B; o.hw = x.hw; o.c1 = x.C; o.c2 = x2 ? x2->C : 0; o.groups = u->cfg.norm_groups; o.eps = eps;
+    o.silu = silu; o.w = gamma; o.bias = beta; o.out = R(out); o.aux = gn_stats;
+    plan->ops.push_back(o);
+  }
+  void layernorm(const Act& x, Ref gamma, Ref beta, const Act& out) {
+    Op o; o.kind = OP_LN; o.a = R(x); o.rows = (int64_t)B * x.hw; o.c1 = x.C; o.eps = 1e-5f; o.w = gamma; o.bias = beta;
+    o.out = R(out);
+    plan->ops.push_back(o);
+  }
+  void attention(Ref q, Ref k, Ref v, Ref out, int nq, int nk, int C, int ldq, int ldk, int ldv) {
+    Op o; o.kind = OP_ATTN; o.a = q; o.k = k; o.v = v; o.out = out; o.batch = B; o.heads = u->cfg.n_heads;
+    o.nq = nq; o.nk = nk; o.hd = C / u->cfg.n_heads; o.ldq = ldq; o.ldk = ldk; o.ldv = ldv; o.ldo = C;
+    o.scale = 1.0f / sqrtf((float)o.hd);
+    plan->ops.push_back(o);
+    const double f = 4.0 * (double)B * o.heads * (double)nq * (double)nk * (double)o.hd;
+    plan->flops += f; plan->attn_flops += f;
+  }
+
+  // ---- blocks --------------------------------------------------------------------------------------
+  // ResnetBlock2D: GN-SiLU-conv3x3(+temb) - GN-SiLU-conv3x3 + shortcut.  Input = x (++ skip).
+  Act resnet(const std::string& pfx, Act& x, Act* skip, int cout) {
+    const int cin = x.C + (skip ? skip->C : 0);
+    Ref n1g = param(pfx + ".norm1.weight", SDN_P_VEC_F32, cin, 0), n1b = param(pfx + ".norm1.bias", SDN_P_VEC_F32, cin, 0);
+    Ref c1w = param(pfx + ".conv1.weight", SDN_P_CONV3X3, cout, 9 * cin), c1b = param(pfx + ".conv1.bias", SDN_P_VEC_F32, cout, 0);
+    const int tcol = tproj_cursor; tproj_cursor += cout;       // time_emb_proj registered up-front (stacked)
+    Ref n2g = param(pfx + ".norm2.weight", SDN_P_VEC_F32, cout, 0), n2b = param(pfx + ".norm2.bias", SDN_P_VEC_F32, cout, 0);
+    Ref c2w = param(pfx + ".conv2.weight", SDN_P_CONV3X3, cout, 9 * cout), c2b = param(pfx + ".conv2.bias", SDN_P_VEC_F32, cout, 0);
+    const int64_t rows = (int64_t)B * x.hw;
+    Act g1 = act(rows, cin, x.hw, x.side);
+    groupnorm(x, skip, 1e-5f, 1, n1g, n1b, g1);
+    Act h = act(rows, cout, x.hw, x.side);
+    conv3x3(g1, cout, cout, c1w, c1b, R(h), 1, 0, Ref(), Ref{SP_WS, tproj.off + (int64_t)tcol * 4}, u->tproj_total);
+    drop(g1);
+    Act g2 = act(rows, cout, x.hw, x.side);
+    groupnorm(h, nullptr, 1e-5f, 1, n2g, n2b, g2);
+    drop(h);
+    Act out = act(rows, cout, x.hw, x.side);
+    if (cin != cout) {
+      Ref scw = param(pfx + ".conv_shortcut.weight", SDN_P_MAT, cout, cin), scb = param(pfx + ".conv_shortcut.bias", SDN_P_VEC_F32, cout, 0);
+      Act sc = act(rows, cout, x.hw, x.side);
+      gemm(rows, cout, cin, R(x), scw, scb, R(sc), SDN_ACT_NONE, Ref(), SDN_OUT_BF16, 0, skip ? R(*skip) : Ref(),
+           skip ? x.C : 0);
+      conv3x3(g2, cout, cout, c2w, c2b, R(out), 1, 0, R(sc), Ref(), 0);
+      drop(sc);
+    } else {
+      conv3x3(g2, cout, cout, c2w, c2b, R(out), 1, 0, R(x), Ref(), 0);
+    }
+    drop(g2);
+    return out;
+  }
+
+  // Transformer2DModel (continuous) with one BasicTransformerBlock.
+  Act transformer(const std::string& pfx, Act& x) {
+    const int C = x.C, hw = x.hw, T = u->cfg.text_len, X = u->cfg.cross_dim;
+    const int64_t rows = (int64_t)B * hw;
+    const std::string tb = pfx + ".transformer_blocks.0";
+    Ref ng = param(pfx + ".norm.weight", SDN_P_VEC_F32, C, 0), nb = param(pfx + ".norm.bias", SDN_P_VEC_F32, C, 0);
+    Ref piw = param(pfx + ".proj_in.weight", SDN_P_MAT, C, C), pib = param(pfx + ".proj_in.bias", SDN_P_VEC_F32, C, 0);
+    Ref l1g = param(tb + ".norm1.weight", SDN_P_VEC_F32, C, 0), l1b = param(tb + ".norm1.bias", SDN_P_VEC_F32, C, 0);
+    Ref qkv = stacked({tb + ".attn1.to_q.weight", tb + ".attn1.to_k.weight", tb + ".attn1.to_v.weight"}, C, C);
+    Ref o1w = param(tb + ".attn1.to_out.0.weight", SDN_P_MAT, C, C), o1b = param(tb + ".attn1.to_out.0.bias", SDN_P_VEC_F32, C, 0);
+    Ref l2g = param(tb + ".norm2.weight", SDN_P_VEC_F32, C, 0), l2b = param(tb + ".norm2.bias", SDN_P_VEC_F32, C, 0);
+    Ref q2w = param(tb + ".attn2.to_q.weight", SDN_P_MAT, C, C);
+    Ref kv2 = stacked({tb + ".attn2.to_k.weight", tb + ".attn2.to_v.weight"}, C, X);
+    Ref o2w = param(tb + ".attn2.to_out.0.weight", SDN_P_MAT, C, C), o2b = param(tb + ".attn2.to_out.0.bias", SDN_P_VEC_F32, C, 0);
+    Ref l3g = param(tb + ".norm3.weight", SDN_P_VEC_F32, C, 0), l3b = param(tb + ".norm3.bias", SDN_P_VEC_F32, C, 0);
+    Ref f1w = param(tb + ".ff.net.0.proj.weight", SDN_P_GEGLU_MAT, 8 * C, C), f1b = param(tb + ".ff.net.0.proj.bias", SDN_P_GEGLU_VEC, 8 * C, 0);
+    Ref f2w = param(tb + ".ff.net.2.weight", SDN_P_MAT, C, 4 * C), f2b = param(tb + ".ff.net.2.bias", SDN_P_VEC_F32, C, 0);
+    Ref pow_ = param(pfx + ".proj_out.weight", SDN_P_MAT, C, C), pob = param(pfx + ".proj_out.bias", SDN_P_VEC_F32, C, 0);
+
+    Act gn = act(rows, C, hw, x.side);
+    groupnorm(x, nullptr, 1e-6f, 0, ng, nb, gn);
+    Act h = act(rows, C, hw, x.side);
+    gemm(rows, C, C, R(gn), piw, pib, R(h));
+    drop(gn);
+    // self-attention
+    Act ln = act(rows, C, hw, x.side);
+    layernorm(h, l1g, l1b, ln);
+    Act qkvb = act(rows, 3 * C, hw, x.side);
+    gemm(rows, 3 * C, C, R(ln), qkv, Ref(), R(qkvb));
+    Act at = act(rows, C, hw, x.side);
+    attention(R(qkvb), Ref{SP_WS, qkvb.off + (int64_t)C * 2}, Ref{SP_WS, qkvb.off + (int64_t)2 * C * 2}, R(at), hw, hw, C,
+              3 * C, 3 * C, 3 * C);
+    drop(qkvb);
+    Act h2 = act(rows, C, hw, x.side);
+    gemm(rows, C, C, R(at), o1w, o1b, R(h2), SDN_ACT_NONE, R(h));
+    drop(h);
+    // cross-attention
+    layernorm(h2, l2g, l2b, ln);
+    Act qb = act(rows, C, hw, x.side);
+    gemm(rows, C, C, R(ln), q2w, Ref(), R(qb));
+    Act kvb = act((int64_t)B * T, 2 * C);
+    gemm((int64_t)B * T, 2 * C, X, Ref{SP_TEXT, 0}, kv2, Ref(), R(kvb));
+    attention(R(qb), R(kvb), Ref{SP_WS, kvb.off + (int64_t)C * 2}, R(at), hw, T, C, C, 2 * C, 2 * C);
+    drop(qb); drop(kvb);
+    Act h3 = act(rows, C, hw, x.side);
+    gemm(rows, C, C, R(at), o2w, o2b, R(h3), SDN_ACT_NONE, R(h2));
+    drop(h2); drop(at);
+    // GEGLU feed-forward
+    layernorm(h3, l3g, l3b, ln);
+    Act ff = act(rows, 4 * C, hw, x.side);
+    gemm(rows, 8 * C, C, R(ln), f1w, f1b, R(ff), SDN_ACT_GEGLU);
+    drop(ln);
+    Act h4 = act(rows, C, hw, x.side);
+    gemm(rows, C, 4 * C, R(ff), f2w, f2b, R(h4), SDN_ACT_NONE, R(h3));
+    drop(ff); drop(h3);
+    Act out = act(rows, C, hw, x.side);
+    gemm(rows, C, C, R(h4), pow_, pob, R(out), SDN_ACT_NONE, R(x));
+    drop(h4);
+    return out;
+  }
+
+  struct Res { std::string pfx; int cout; };
+  // Walk the architecture once to list every resnet (execution order) -> stacked time_emb_proj.
+  std::vector<Res> enumerate_resnets() const {
+    const sdn_unet_config& c = u->cfg;
+    std::vector<Res> v;
+    char buf[96];
+    for (int i = 0; i < c.n_levels; ++i)
+      for (int j = 0; j < c.layers_per_block; ++j) {
+        snprintf(buf, sizeof(buf), "down_blocks.%d.resnets.%d", i, j);
+        v.push_back({buf, c.block_out_channels[i]});
+      }
+    const int top = c.block_out_channels[c.n_levels - 1];
+    v.push_back({"mid_block.resnets.0", top});
+    v.push_back({"mid_block.resnets.1", top});
+    for (int i = 0; i < c.n_levels; ++i)
+      for (int j = 0; j <= c.layers_per_block; ++j) {
+        snprintf(buf, sizeof(buf), "up_blocks.%d.resnets.%d", i, j);
+        v.push_back({buf, c.block_out_channels[c.n_levels - 1 - i]});
+      }
+    return v;
+  }
+
+  void build() {
+    const sdn_unet_config& c = u->cfg;
+    const int S = c.sample_size, ch0 = c.block_out_channels[0], tdim = 4 * ch0;
+    char buf[96];
+
+    // ---- time embedding + stacked time_emb_proj ----
+    Ref l1w = param("time_embedding.linear_1.weight", SDN_P_MAT, tdim, ch0), l1b = param("time_embedding.linear_1.bias", SDN_P_VEC_F32, tdim, 0);
+    Ref l2w = param("time_embedding.linear_2.weight", SDN_P_MAT, tdim, tdim), l2b = param("time_embedding.linear_2.bias", SDN_P_VEC_F32, tdim, 0);
+    const std::vector<Res> rs = enumerate_resnets();
+    int total = 0;
+    Ref tpw, tpb;
+    {
+      int64_t expect = -1;
+      for (size_t i = 0; i < rs.size(); ++i) {
+        Ref r = param(rs[i].pfx + ".time_emb_proj.weight", SDN_P_MAT, rs[i].cout, tdim);
+        if (i == 0) tpw = r; else if (r.off != expect) { fprintf(stderr, "libsdn: time_emb_proj not contiguous\n"); abort(); }
+        expect = r.off + (int64_t)rs[i].cout * tdim * 2;
+        total += rs[i].cout;
+      }
+      expect = -1;
+      for (size_t i = 0; i < rs.size(); ++i) {
+        Ref r = param(rs[i].pfx + ".time_emb_proj.bias", SDN_P_VEC_F32, rs[i].cout, 0);
+        if (i == 0) tpb = r; else if (r.off != expect) { fprintf(stderr, "libsdn: time_emb_proj bias not contiguous\n"); abort(); }
+        expect = r.off + (int64_t)rs[i].cout * 4;
+      }
+    }
+    u->tproj_total = total;
+    gn_stats = Ref{SP_WS, arena.alloc((int64_t)B * 16 * 64 * 2 * 4)};
+    Act tsin = act(B, ch0);
+    { Op o; o.kind = OP_TEMB; o.batch = B; o.c1 = ch0; o.out = R(tsin); plan->ops.push_back(o); }
+    Act t1 = act(B, tdim);
+    gemm(B, tdim, ch0, R(tsin), l1w, l1b, R(t1), SDN_ACT_SILU);
+    drop(tsin);
+    Act semb = act(B, tdim);
+    gemm(B, tdim, tdim, R(t1), l2w, l2b, R(semb), SDN_ACT_SILU);
+    drop(t1);
+    Act tp = act(B, total, 0, 0, 4);
+    tproj = R(tp);
+    gemm(B, total, tdim, R(semb), tpw, tpb, R(tp), SDN_ACT_NONE, Ref(), SDN_OUT_F32);
+    drop(semb);
+
+    // ---- conv_in ----
+    Ref ciw = param("conv_in.weight", SDN_P_CONV3X3, ch0, 9 * c.in_channels), cib = param("conv_in.bias", SDN_P_VEC_F32, ch0, 0);
+    Act h = act((int64_t)B * S * S, ch0, S * S, S);
+    { Op o; o.kind = OP_CONV_IN; o.batch = B; o.c1 = c.in_channels; o.c2 = ch0; o.hw = S; o.a = Ref{SP_LATENTS, 0}; o.w = ciw; o.bias = cib; o.out = R(h); plan->ops.push_back(o);
+      plan->flops += 2.0 * B * S * S * (double)ch0 * 9 * c.in_channels; }
+
+    std::vector<Act> skips;
+    skips.push_back(h);                       // h stays alive as a skip; keep using it as the running tensor
+    Act cur = h;
+    bool cur_is_skip = true;
+
+    // ---- down path ----
+    for (int i = 0; i < c.n_levels; ++i) {
+      const int cout = c.block_out_channels[i];
+      for (int j = 0; j < c.layers_per_block; ++j) {
+        snprintf(buf, sizeof(buf), "down_blocks.%d.resnets.%d", i, j);
+        Act r = resnet(buf, cur, nullptr, cout);
+        if (!cur_is_skip) drop(cur);
+        cur = r; cur_is_skip = false;
+        if (c.level_has_attn[i]) {
+          snprintf(buf, sizeof(buf), "down_blocks.%d.attentions.%d", i, j);
+          Act t = transformer(buf, cur);
+          drop(cur);
+          cur = t;
+        }
+        skips.push_back(cur); cur_is_skip = true;
+      }
+      if (i + 1 < c.n_levels) {
+        snprintf(buf, sizeof(buf), "down_blocks.%d.downsamplers.0.conv", i);
+        Ref w = param(std::string(buf) + ".weight", SDN_P_CONV3X3, cout, 9 * cout), bb = param(std::string(buf) + ".bias", SDN_P_VEC_F32, cout, 0);
+        const int s2 = cur.side / 2;
+        Act d = act((int64_t)B * s2 * s2, cout, s2 * s2, s2);
+        conv3x3(cur, cout, cout, w, bb, R(d), 2, 0, Ref(), Ref(), 0);
+        cur = d; skips.push_back(cur); cur_is_skip = true;
+      }
+    }
+    // ---- mid ----
+    {
+      Act r = resnet("mid_block.resnets.0", cur, nullptr, cur.C);
+      cur = r; cur_is_skip = false;
+      Act t = transformer("mid_block.attentions.0", cur);
+      drop(cur); cur = t;
+      Act r2 = resnet("mid_block.resnets.1", cur, nullptr, cur.C);
+      drop(cur); cur = r2;
+    }
+    // ---- up path ----
+    for (int i = 0; i < c.n_levels; ++i) {
+      const int lvl = c.n_levels - 1 - i, cout = c.block_out_channels[lvl];
+      for (int j = 0; j <= c.layers_per_block; ++j) {
+        Act skip = skips.back(); skips.pop_back();
+        snprintf(buf, sizeof(buf), "up_blocks.%d.resnets.%d", i, j);
+        Act r = resnet(buf, cur, &skip, cout);
+        drop(cur); drop(skip);
+        cur = r;
+        if (c.level_has_attn[lvl]) {
+          snprintf(buf, sizeof(buf), "up_blocks.%d.attentions.%d", i, j);
+          Act t = transformer(buf, cur);
+          drop(cur); cur = t;
+        }
+      }
+      if (i + 1 < c.n_levels) {
+        snprintf(buf, sizeof(buf), "up_blocks.%d.upsamplers.0.conv", i);
+        Ref w = param(std::string(buf) + ".weight", SDN_P_CONV3X3, cout, 9 * cout), bb = param(std::string(buf) + ".bias", SDN_P_VEC_F32, cout, 0);
+        const int s2 = cur.side * 2;
+        Act up = act((int64_t)B * s2 * s2, cout, s2 * s2, s2);
+        conv3x3(cur, cout, cout, w, bb, R(up), 1, 1, Ref(), Ref(), 0);
+        drop(cur); cur = up;
+      }
+    }
+    // ---- tail: GN + SiLU + conv_out -> fp32 NCHW ----
+    Ref og = param("conv_norm_out.weight", SDN_P_VEC_F32, ch0, 0), ob = param("conv_norm_out.bias", SDN_P_VEC_F32, ch0, 0);
+    const int npad = 32;
+    Ref cow = param("conv_out.weight", SDN_P_CONV3X3, c.out_channels, 9 * ch0, npad);
+    Ref cob = param("conv_out.bias", SDN_P_VEC_F32, c.out_channels, 0, npad);
+    Act g = act((int64_t)B * S * S, ch0, S * S, S);
+    groupnorm(cur, nullptr, 1e-5f, 1, og, ob, g);
+    drop(cur);
+    conv3x3(g, c.out_channels, npad, cow, cob, Ref{SP_OUT, 0}, 1, 0, Ref(), Ref(), 0, SDN_OUT_F32_NCHW, c.out_channels);
+    drop(g);
+    plan->ws_bytes = arena.peak;
+  }
+};
+
+Plan* get_plan(sdn_unet* u, int batch) {
+  auto it = u->plans.find(batch);
+  if (it != u->plans.end()) return &it->second;
+  Plan& p = u->plans[batch];
+  p.batch = batch;
+  Builder b{u, &p};
+  b.B = batch;
+  b.build();
+  return &p;
+}
+
+inline const char* resolve(const Ref& r, const char* w, const char* ws, const char* lat, const char* text, const char* out) {
+  switch (r.space) {
+    case SP_W: return w + r.off;
+    case SP_WS: return ws + r.off;
+    case SP_LATENTS: return lat + r.off;
+    case SP_TEXT: return text + r.off;
+    case SP_OUT: return out + r.off;
+    default: return nullptr;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int sdn_unet_create(const sdn_unet_config* cfg, sdn_unet** out) {
+  if (!cfg || !out) return SDN_E_INVALID;
+  if (cfg->n_levels < 1 || cfg->n_levels > 4 || cfg->layers_per_block < 1 || cfg->n_heads <= 0 ||
+      cfg->in_channels <= 0 || cfg->in_channels > 16 || cfg->out_channels <= 0 || cfg->out_channels > 32 ||
+      cfg->sample_size <= 0 || (cfg->sample_size % (1 << (cfg->n_levels - 1))) != 0 || cfg->cross_dim % 64 != 0 ||
+      cfg->text_len <= 0 || cfg->norm_groups <= 0 || cfg->norm_groups > 64)
+    return SDN_E_INVALID;
+  for (int i = 0; i < cfg->n_levels; ++i) {
+    const int c = cfg->block_out_channels[i];
+    if (c <= 0 || c % 64 != 0 || c % cfg->norm_groups != 0 || c % cfg->n_heads != 0) return SDN_E_INVALID;
+    const int hd = c / cfg->n_heads;
+    if (cfg->level_has_attn[i] && hd != 40 && hd != 64 && hd != 80 && hd != 160) return SDN_E_INVALID;
+    if (sdn_gemm_pick_nrep(c, SDN_ACT_NONE) == 0 || sdn_gemm_pick_nrep(8 * c, SDN_ACT_GEGLU) == 0) return SDN_E_INVALID;
+  }
+  {
+    const int hd_mid = cfg->block_out_channels[cfg->n_levels - 1] / cfg->n_heads;       // mid block always attends
+    if (hd_mid != 40 && hd_mid != 64 && hd_mid != 80 && hd_mid != 160) return SDN_E_INVALID;
+  }
+  sdn_unet* u = new sdn_unet();
+  u->cfg = *cfg;
+  get_plan(u, 1);                 // registers the parameter manifest (batch-independent)
+  *out = u;
+  return SDN_OK;
+}
+
+void sdn_unet_destroy(sdn_unet* u) { delete u; }
+
+int sdn_unet_param_count(const sdn_unet* u) { return u ? (int)u->params.size() : 0; }
+
+int sdn_unet_param_info(const sdn_unet* u, int32_t index, sdn_param_info* info) {
+  if (!u || !info || index < 0 || index >= (int)u->params.size()) return SDN_E_INVALID;
+  *info = u->params[index];
+  return SDN_OK;
+}
+
+size_t sdn_unet_weight_bytes(const sdn_unet* u) { return u ? (size_t)u->weight_bytes : 0; }
+
+size_t sdn_unet_workspace_bytes(sdn_unet* u, int32_t batch) {
+  if (!u || batch <= 0) return 0;
+  return (size_t)get_plan(u, batch)->ws_bytes;
+}
+
+double sdn_unet_flops(sdn_unet* u, int32_t batch, double* attn) {
+  if (!u || batch <= 0) return 0.0;
+  Plan* p = get_plan(u, batch);
+  if (attn) *attn = p->attn_flops;
+  return p->flops;
+}
+
+int sdn_unet_forward(sdn_unet* u, const void* weights, const float* latents, float timestep, const void* text,
+                     float* out, int32_t batch, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!u || !weights || !latents || !text || !out || !workspace || batch <= 0) return SDN_E_INVALID;
+  Plan* p = get_plan(u, batch);
+  if (workspace_bytes < (size_t)p->ws_bytes) return SDN_E_WORKSPACE;
+  const char* W = (const char*)weights; const char* WS = (const char*)workspace;
+  const char* L = (const char*)latents; const char* T = (const char*)text; const char* O = (const char*)out;
+  auto P = [&](const Ref& r) { return resolve(r, W, WS, L, T, O); };
+  for (const Op& o : p->ops) {
+    int rc = SDN_OK;
+    switch (o.kind) {
+      case OP_TEMB:
+        rc = sdn_timestep_embed_bf16(timestep, o.batch, o.c1, (void*)P(o.out), stream);
+        break;
+      case OP_CONV_IN:
+        rc = sdn_conv_in_bf16((const float*)P(o.a), P(o.w), (const float*)P(o.bias), o.batch, o.c1, o.hw, o.hw, o.c2,
+                              (void*)P(o.out), stream);
+        break;
+      case OP_GEMM:
+        rc = sdn_gemm_bf16(&o.gd, P(o.a), P(o.a2), P(o.w), (const float*)P(o.bias), (const float*)P(o.rowbias),
+                           P(o.residual), (void*)P(o.out), stream);
+        break;
+      case OP_GN:
+        rc = sdn_groupnorm_bf16(P(o.a), P(o.a2), o.batch, o.hw, o.c1, o.c2, o.groups, o.eps, o.silu,
+                                (const float*)P(o.w), (const float*)P(o.bias), (void*)P(o.out), (float*)P(o.aux), stream);
+        break;
+      case OP_LN:
+        rc = sdn_layernorm_bf16(P(o.a), o.rows, o.c1, o.eps, (const float*)P(o.w), (const float*)P(o.bias),
+                                (void*)P(o.out), stream);
+        break;
+      case OP_ATTN:
+        rc = sdn_attention_bf16(P(o.a), P(o.k), P(o.v), (void*)P(o.out), o.batch, o.heads, o.nq, o.nk, o.hd, o.ldq,
+                                o.ldk, o.ldv, o.ldo, o.scale, stream);
+        break;
+    }
+    if (rc != SDN_OK) return rc;
+  }
+  return SDN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,188 @@
+"""UNet2DConditionModel front-end: the call surface the reference's pipelines use
+(`self.unet(latent_model_input, t, encoder_hidden_states=E).sample`, ...threshold_time.py:538,540;
+`self.unet.config.sample_size`, `self.unet.in_channels`), executed by libsdn's static launch plan.
+
+Weights: a diffusers-keyed state_dict (the names of `UNet2DConditionModel.state_dict()` for SD-v1.4) is packed
+ONCE into a single device buffer in the engine's layouts, driven by the manifest the C side publishes
+(sdn_unet_param_info): conv kernels [O,I,3,3] -> [O][ky][kx][I] bf16, linears / 1x1 convs -> [O][I] bf16,
+GEGLU projection rows interleaved value/gate in blocks of 16, norms and biases f32.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from types import SimpleNamespace
+
+import torch
+
+from . import _lib
+
+SD14_CONFIG = dict(in_channels=4, out_channels=4, sample_size=64, block_out_channels=(320, 640, 1280, 1280),
+                   down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D",
+                                     "DownBlock2D"),
+                   layers_per_block=2, attention_head_dim=8, cross_attention_dim=768, norm_num_groups=32)
+
+P_VEC_F32, P_MAT, P_CONV3X3, P_GEGLU_MAT, P_GEGLU_VEC = 0, 1, 2, 3, 4
+
+
+class UNetOutput:
+    __slots__ = ("sample",)
+
+    def __init__(self, sample):
+        self.sample = sample
+
+
+def _interleave16(t: torch.Tensor) -> torch.Tensor:
+    """[2F, ...] (value rows then gate rows) -> blocks of 16 value rows followed by their 16 gate rows."""
+    f = t.shape[0] // 2
+    v, g = t[:f], t[f:]
+    rest = t.shape[1:]
+    return torch.stack([v.reshape(f // 16, 16, *rest), g.reshape(f // 16, 16, *rest)], dim=1).reshape(2 * f, *rest)
+
+
+class UNet2DConditionModel:
+    def __init__(self, text_len: int = 77, **config):
+        cfg = dict(SD14_CONFIG)
+        cfg.update(config)
+        self.config = SimpleNamespace(**cfg)
+        self.in_channels = cfg["in_channels"]
+        self.text_len = text_len
+        boc = list(cfg["block_out_channels"])
+        n = len(boc)
+        c = _lib.UnetConfig(in_channels=cfg["in_channels"], out_channels=cfg["out_channels"],
+                            sample_size=cfg["sample_size"], n_levels=n,
+                            block_out_channels=(C.c_int32 * 4)(*(boc + [0] * (4 - n))),
+                            level_has_attn=(C.c_int32 * 4)(*([1 if "CrossAttn" in t else 0
+                                                              for t in cfg["down_block_types"]] + [0] * (4 - n))),
+                            layers_per_block=cfg["layers_per_block"], n_heads=cfg["attention_head_dim"],
+                            cross_dim=cfg["cross_attention_dim"], text_len=text_len,
+                            norm_groups=cfg["norm_num_groups"])
+        h = C.c_void_p()
+        _lib.check(_lib.lib().sdn_unet_create(C.byref(c), C.byref(h)), "sdn_unet_create")
+        self._h = h
+        self._weights = None
+        self._ws = {}
+        self.manifest = []
+        info = _lib.ParamInfo()
+        for i in range(_lib.lib().sdn_unet_param_count(h)):
+            _lib.check(_lib.lib().sdn_unet_param_info(h, i, C.byref(info)), "sdn_unet_param_info")
+            self.manifest.append(dict(name=info.name.decode(), kind=info.kind, rows=info.rows, cols=info.cols,
+                                      rows_padded=info.rows_padded, offset=info.offset))
+        self.weight_bytes = _lib.lib().sdn_unet_weight_bytes(h)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _lib.lib().sdn_unet_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- parameters ---------------------------------------------------------------------------------
+    def state_dict_shapes(self) -> dict:
+        """diffusers key -> source tensor shape."""
+        out = {}
+        cin = self.config.in_channels
+        for p in self.manifest:
+            k, r, c = p["kind"], p["rows"], p["cols"]
+            if k in (P_VEC_F32, P_GEGLU_VEC):
+                out[p["name"]] = (r,)
+            elif k == P_CONV3X3:
+                out[p["name"]] = (r, c // 9, 3, 3)
+            elif p["name"].endswith(("proj_in.weight", "proj_out.weight", "conv_shortcut.weight")):
+                out[p["name"]] = (r, c, 1, 1)
+            else:
+                out[p["name"]] = (r, c)
+        del cin
+        return out
+
+    def synthetic_state_dict(self, seed: int = 1234) -> dict:
+        """Random weights of this architecture (there are no checkpoints on the box): variance-preserving
+        uniform U(-sqrt(3/fan_in), sqrt(3/fan_in)) for matrices, small uniform biases, norm gains near 1."""
+        g = torch.Generator().manual_seed(seed)
+        sd = {}
+        for name, shape in self.state_dict_shapes().items():
+            if len(shape) == 1:
+                if ".norm" in name or name.startswith("conv_norm_out"):
+                    base = 1.0 if name.endswith("weight") else 0.0
+                    sd[name] = base + 0.1 * (torch.rand(shape, generator=g) - 0.5)
+                else:
+                    sd[name] = 0.2 * (torch.rand(shape, generator=g) - 0.5)
+            else:
+                fan_in = 1
+                for d in shape[1:]:
+                    fan_in *= d
+                bound = (3.0 / fan_in) ** 0.5
+                sd[name] = (torch.rand(shape, generator=g) * 2 - 1) * bound
+        return sd
+
+    def pack_state_dict(self, sd: dict) -> torch.Tensor:
+        """CPU uint8 buffer in the engine layout."""
+        buf = torch.zeros(self.weight_bytes, dtype=torch.uint8)
+        for p in self.manifest:
+            t = sd[p["name"]].detach().float().cpu()
+            k = p["kind"]
+            if k == P_CONV3X3:
+                t = t.permute(0, 2, 3, 1).reshape(p["rows"], p["cols"])
+            elif k in (P_MAT, P_GEGLU_MAT):
+                t = t.reshape(p["rows"], p["cols"])
+            if k in (P_GEGLU_MAT, P_GEGLU_VEC):
+                t = _interleave16(t)
+            if k in (P_VEC_F32, P_GEGLU_VEC):
+                raw = t.contiguous().view(torch.uint8)
+            else:
+                raw = t.to(torch.bfloat16).contiguous().view(torch.uint8).reshape(-1)
+            buf[p["offset"]:p["offset"] + raw.numel()] = raw.reshape(-1)
+        return buf
+
+    def load_state_dict(self, sd: dict, device="cuda"):
+        missing = [p["name"] for p in self.manifest if p["name"] not in sd]
+        if missing:
+            raise KeyError(f"state_dict lacks {len(missing)} keys, e.g. {missing[:3]}")
+        _lib.require_gpu()
+        self._weights = self.pack_state_dict(sd).to(device)
+        return self
+
+    # ---- forward --------------------------------------------------------------------------------------
+    def flops(self, batch: int):
+        a = C.c_double()
+        total = _lib.lib().sdn_unet_flops(self._h, batch, C.byref(a))
+        return total, a.value
+
+    def _workspace(self, batch: int, device):
+        ws = self._ws.get(batch)
+        if ws is None:
+            n = _lib.lib().sdn_unet_workspace_bytes(self._h, batch)
+            ws = torch.empty(n, dtype=torch.uint8, device=device)
+            self._ws[batch] = ws
+        return ws
+
+    def prepare_text(self, encoder_hidden_states: torch.Tensor) -> torch.Tensor:
+        e = encoder_hidden_states
+        if e.shape[1] != self.text_len or e.shape[2] != self.config.cross_attention_dim:
+            raise _lib.SdnError(f"encoder_hidden_states must be [B,{self.text_len},{self.config.cross_attention_dim}]")
+        return e.to(torch.bfloat16).contiguous()
+
+    def forward_into(self, sample, timestep, text_bf16, out):
+        """No-allocation form used by the engine loop (text already bf16, `out` preallocated fp32)."""
+        b = sample.shape[0]
+        ws = self._workspace(b, sample.device)
+        _lib.check(_lib.lib().sdn_unet_forward(self._h, _lib.dptr(self._weights), _lib.dptr(sample, torch.float32),
+                                               float(timestep), _lib.dptr(text_bf16, torch.bfloat16),
+                                               _lib.dptr(out, torch.float32), b, _lib.dptr(ws), ws.numel(),
+                                               _lib.stream_ptr()), "sdn_unet_forward")
+        return out
+
+    def __call__(self, sample, timestep, encoder_hidden_states=None, return_dict=True, **unused):
+        _lib.require_gpu()
+        if self._weights is None:
+            raise _lib.SdnError("no weights loaded: call load_state_dict() first")
+        x = sample.float().contiguous()
+        s = self.config.sample_size
+        if tuple(x.shape[1:]) != (self.config.in_channels, s, s):
+            raise _lib.SdnError(f"sample must be [B,{self.config.in_channels},{s},{s}], got {tuple(x.shape)}")
+        e = self.prepare_text(encoder_hidden_states)
+        if e.shape[0] != x.shape[0]:
+            raise _lib.SdnError("batch mismatch between sample and encoder_hidden_states")
+        out = torch.empty((x.shape[0], self.config.out_channels, s, s), dtype=torch.float32, device=x.device)
+        self.forward_into(x, float(timestep), e, out)
+        return UNetOutput(out) if return_dict else (out,)

@@ -1,0 +1,206 @@
+"""Operator-level parity: each HIP kernel (through the C ABI) vs a plain PyTorch fp32 reference of the same op on the
+SAME bf16-rounded inputs.  Expected error = one bf16 rounding of the output (2^-9 relative) + fp32 accumulation-order
+noise; tolerances are written per test."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import safe_denoiser_amd as sda
+from safe_denoiser_amd import _lib
+from tests_support import ops
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF)
+
+
+def rel_l2(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-20))
+
+
+def check_bf16(out, ref, tol=4e-3):
+    """bf16 output vs fp32 reference: relative L2 <= tol and max elementwise error <= 2^-7 of the reference scale."""
+    assert out.shape == ref.shape, (out.shape, ref.shape)
+    assert rel_l2(out, ref) <= tol, rel_l2(out, ref)
+    err = (out.float().cpu() - ref.float().cpu()).abs().max()
+    assert float(err) <= 2 ** -7 * float(ref.abs().max()) + 1e-3, float(err)
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 320, 320), (256, 160, 64), (4096, 640, 1280), (77 * 3, 1280, 768),
+                                   (2, 1280, 320), (192, 128, 128), (4096 * 2, 960, 320), (64, 64, 64), (100, 32, 64)])
+def test_gemm_plain_bias(M, N, K):
+    a, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(3))
+    ref = a.float() @ w.float().T + bias
+    out = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda())
+    check_bf16(out, ref)
+
+
+def test_gemm_identity_asymmetric():
+    """A = I with an asymmetric W catches a transposed C write (guide: 'A=I-check with ASYMMETRIC B')."""
+    K = 128
+    a = torch.eye(K).to(BF)
+    w = (torch.arange(160 * K).reshape(160, K) % 251 - 125).float().to(BF)
+    out = ops.gemm(a.cuda(), w.cuda())
+    assert torch.equal(out.float().cpu(), w.float().T.contiguous())
+
+
+def test_gemm_f32_out_residual_silu_and_dual_source():
+    M, N, K1, K2 = 384, 320, 640, 320
+    a1, a2 = rnd(M, K1, seed=4), rnd(M, K2, seed=5)
+    w = rnd(N, K1 + K2, seed=6, scale=(K1 + K2) ** -0.5)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(7))
+    res = rnd(M, N, seed=8)
+    ref = torch.cat([a1, a2], 1).float() @ w.float().T + bias
+    out = ops.gemm(a1.cuda(), w.cuda(), bias=bias.cuda(), a2=a2.cuda())                 # skip-concat, never materialised
+    check_bf16(out, ref)
+    out = ops.gemm(a1.cuda(), w.cuda(), bias=bias.cuda(), a2=a2.cuda(), residual=res.cuda())
+    check_bf16(out, ref + res.float())
+    out = ops.gemm(a1.cuda(), w.cuda(), bias=bias.cuda(), a2=a2.cuda(), act=1)
+    check_bf16(out, F.silu(ref))
+    out = ops.gemm(a1.cuda(), w.cuda(), bias=bias.cuda(), a2=a2.cuda(), out_kind=1)
+    torch.testing.assert_close(out.cpu(), ref, rtol=2e-4, atol=2e-4)                    # f32 out: accumulation order only
+
+
+def test_gemm_rowbias_per_sample():
+    B, hw, N, K = 3, 64, 320, 320
+    a, w = rnd(B * hw, K, seed=9), rnd(N, K, seed=10, scale=K ** -0.5)
+    rb = torch.randn(B, 2 * N, generator=torch.Generator().manual_seed(11))
+    ref = (a.float() @ w.float().T).reshape(B, hw, N) + rb[:, None, N:]
+    rbg = rb.cuda()
+    out = ops.gemm(a.cuda(), w.cuda(), rowbias=rbg[:, N:], rows_per_batch=hw)            # a column slice of the stacked time proj
+    check_bf16(out.reshape(B, hw, N), ref)
+
+
+@pytest.mark.parametrize("C", [320, 640])
+def test_gemm_geglu(C):
+    from safe_denoiser_amd.unet import _interleave16
+    M = 256
+    x = rnd(M, C, seed=12)
+    w = rnd(8 * C, C, seed=13, scale=C ** -0.5)
+    b = torch.randn(8 * C, generator=torch.Generator().manual_seed(14))
+    proj = x.float() @ w.float().T + b
+    val, gate = proj.chunk(2, -1)
+    ref = val * F.gelu(gate)
+    out = ops.gemm(x.cuda(), _interleave16(w).contiguous().cuda(), bias=_interleave16(b).contiguous().cuda(), act=2)
+    check_bf16(out, ref)
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,stride,ups", [(2, 16, 320, 320, 1, 0), (1, 16, 640, 320, 2, 0),
+                                                     (2, 8, 320, 640, 1, 1), (3, 8, 64, 160, 1, 0),
+                                                     (1, 64, 320, 320, 1, 0)])
+def test_conv3x3_implicit_gemm(B, H, Cin, Cout, stride, ups):
+    x = rnd(B, Cin, H, H, seed=15)
+    w = rnd(Cout, Cin, 3, 3, seed=16, scale=(9 * Cin) ** -0.5)
+    bias = torch.randn(Cout, generator=torch.Generator().manual_seed(17))
+    xin = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if ups else x.float()
+    ref = F.conv2d(xin, w.float(), bias, stride=stride, padding=1)
+    Ho = ref.shape[-1]
+    xn = x.permute(0, 2, 3, 1).contiguous().cuda()                                       # NHWC
+    wn = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().cuda()                # [O][ky][kx][I]
+    out = ops.gemm(xn, wn, bias=bias.cuda(), conv=dict(Hs=H, Ws=H, Cin=Cin, Ho=Ho, Wo=Ho, stride=stride, upsample=ups))
+    check_bf16(out.reshape(B, Ho, Ho, Cout).permute(0, 3, 1, 2), ref)
+
+
+def test_conv_out_padded_n_to_f32_nchw():
+    B, H, Cin, Cout = 2, 16, 320, 4
+    x = rnd(B, Cin, H, H, seed=18)
+    w = rnd(Cout, Cin, 3, 3, seed=19, scale=(9 * Cin) ** -0.5)
+    bias = torch.randn(Cout, generator=torch.Generator().manual_seed(20))
+    ref = F.conv2d(x.float(), w.float(), bias, padding=1)
+    wp = torch.zeros(32, 9 * Cin, dtype=BF); wp[:Cout] = w.permute(0, 2, 3, 1).reshape(Cout, -1)
+    bp = torch.zeros(32); bp[:Cout] = bias
+    out = ops.gemm(x.permute(0, 2, 3, 1).contiguous().cuda(), wp.cuda(), bias=bp.cuda(),
+                   conv=dict(Hs=H, Ws=H, Cin=Cin, Ho=H, Wo=H), out_kind=2, n_valid=Cout)
+    torch.testing.assert_close(out.reshape(B, Cout, H, H).cpu(), ref, rtol=2e-4, atol=2e-4)
+
+
+def test_gemm_rejects_bad_shapes():
+    a, w = rnd(64, 96).cuda(), rnd(32, 96).cuda()
+    with pytest.raises(sda.SdnError):
+        ops.gemm(a, w)                                                                   # K % 64 != 0
+    a, w = rnd(64, 64).cuda(), rnd(48, 64).cuda()
+    with pytest.raises(sda.SdnError):
+        ops.gemm(a, w)                                                                   # N % 32 != 0
+
+
+# ------------------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize("B,hw,c1,c2,silu,eps", [(2, 4096, 320, 0, 1, 1e-5), (3, 256, 1280, 640, 1, 1e-5),
+                                                 (1, 1024, 640, 320, 1, 1e-5), (2, 64, 1280, 1280, 1, 1e-5),
+                                                 (2, 1024, 640, 0, 0, 1e-6), (1, 64, 64, 0, 1, 1e-5)])
+def test_groupnorm_silu_concat(B, hw, c1, c2, silu, eps):
+    x = rnd(B, hw, c1, seed=21) * 2 + 0.5
+    x2 = (rnd(B, hw, c2, seed=22) * 0.5 - 1) if c2 else None
+    C_ = c1 + c2
+    g = 1 + 0.1 * torch.randn(C_, generator=torch.Generator().manual_seed(23))
+    b = 0.1 * torch.randn(C_, generator=torch.Generator().manual_seed(24))
+    full = torch.cat([x, x2], 2) if c2 else x
+    ref = F.group_norm(full.float().permute(0, 2, 1), 32, g, b, eps=eps)
+    ref = (F.silu(ref) if silu else ref).permute(0, 2, 1)
+    out = ops.groupnorm(x.cuda(), None if x2 is None else x2.cuda(), 32, eps, silu, g.cuda(), b.cuda())
+    check_bf16(out, ref)
+
+
+@pytest.mark.parametrize("rows,C", [(4096, 320), (1000, 640), (7, 1280), (64, 1536)])
+def test_layernorm(rows, C):
+    x = rnd(rows, C, seed=25) * 3 + 1
+    g = 1 + 0.1 * torch.randn(C, generator=torch.Generator().manual_seed(26))
+    b = 0.1 * torch.randn(C, generator=torch.Generator().manual_seed(27))
+    ref = F.layer_norm(x.float(), (C,), g, b, eps=1e-5)
+    check_bf16(ops.layernorm(x.cuda(), g.cuda(), b.cuda()), ref)
+
+
+# ------------------------------------------------------------------------------------------ attention
+@pytest.mark.parametrize("B,H,Nq,Nk,d", [(2, 8, 256, 256, 40), (1, 8, 1024, 1024, 80), (2, 8, 64, 64, 160),
+                                         (2, 8, 256, 77, 40), (1, 8, 64, 77, 160), (1, 4, 128, 200, 64),
+                                         (1, 8, 4096, 4096, 40)])
+def test_attention_vs_sdpa(B, H, Nq, Nk, d):
+    q, k, v = rnd(B, Nq, H * d, seed=28), rnd(B, Nk, H * d, seed=29), rnd(B, Nk, H * d, seed=30)
+    sp = lambda t, n: t.float().reshape(B, n, H, d).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(sp(q, Nq), sp(k, Nk), sp(v, Nk)).transpose(1, 2).reshape(B, Nq, H * d)
+    out = ops.attention(q.cuda(), k.cuda(), v.cuda(), H)
+    # P is rounded to bf16 before the PV product (as every bf16 flash kernel does): 6e-3 relative L2
+    assert rel_l2(out, ref) <= 6e-3, rel_l2(out, ref)
+
+
+def test_attention_fused_qkv_views_and_sharp_softmax():
+    """Strided q/k/v views of one [B,N,3C] projection; one key dominating (forces the running-max rescale path)."""
+    B, H, N, d = 1, 8, 256, 40
+    C_ = H * d
+    qkv = rnd(B, N, 3 * C_, seed=31)
+    qkv[0, 200, C_:2 * C_] = qkv[0, 5, :C_] * 6                      # key 200 matches query 5 strongly (late tile)
+    q, k, v = qkv[..., :C_], qkv[..., C_:2 * C_], qkv[..., 2 * C_:]
+    sp = lambda t: t.float().reshape(B, N, H, d).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(sp(q), sp(k), sp(v)).transpose(1, 2).reshape(B, N, C_)
+    g = qkv.cuda()
+    out = ops.attention(g[..., :C_], g[..., C_:2 * C_], g[..., 2 * C_:], H)
+    assert rel_l2(out, ref) <= 6e-3
+
+
+# ------------------------------------------------------------------------------------------ conv_in / temb
+def test_conv_in_and_timestep_embedding():
+    B, H = 2, 64
+    lat = torch.randn(B, 4, H, H, generator=torch.Generator().manual_seed(32))
+    w = rnd(320, 4, 3, 3, seed=33, scale=1 / 6)
+    bias = torch.randn(320, generator=torch.Generator().manual_seed(34))
+    ref = F.conv2d(lat, w.float(), bias, padding=1).permute(0, 2, 3, 1)
+    out = torch.empty(B, H, H, 320, dtype=BF, device="cuda")
+    wn = w.permute(0, 2, 3, 1).contiguous().cuda()
+    _lib.check(sda.lib().sdn_conv_in_bf16(lat.cuda().data_ptr(), wn.data_ptr(), bias.cuda().data_ptr(), B, 4, H, H, 320,
+                                          out.data_ptr(), _lib.stream_ptr()), "conv_in")
+    torch.cuda.synchronize()
+    check_bf16(out, ref)
+    from oracle.unet import OracleUNet
+    for t in (981.0, 1.0, 500.0):
+        te = torch.empty(3, 320, dtype=BF, device="cuda")
+        _lib.check(sda.lib().sdn_timestep_embed_bf16(t, 3, 320, te.data_ptr(), _lib.stream_ptr()), "temb")
+        exp = OracleUNet({}, None).timestep_features(t, 3, 320)
+        assert float((te.float().cpu() - exp).abs().max()) <= 2 ** -8 + 2e-4     # bf16 rounding + fp32 sin/cos argument

@@ -1,0 +1,62 @@
+"""Whole-network parity: libsdn's UNet launch plan vs the CPU oracle on the same synthetic weights and inputs.
+
+Two comparisons, tolerances stated here:
+  * vs the oracle run with bf16 storage emulation (same rounding points as the engine): relative L2 <= 1.5e-2.
+    The residue is accumulation order + the flash kernel's bf16 P (not emulable), amplified through ~60 layers.
+  * vs the pure-fp32 oracle: relative L2 <= 5e-2 (what bf16 storage itself costs; reported, loose bound).
+"""
+import pytest
+import torch
+
+from oracle.unet import OracleUNet
+from safe_denoiser_amd.unet import UNet2DConditionModel
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / b.norm())
+
+
+SMALL = dict(block_out_channels=(320, 640), down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"),
+             layers_per_block=1, attention_head_dim=8, cross_attention_dim=768, sample_size=16)
+SMALL_O = dict(block_out_channels=(320, 640), level_has_attn=(True, False), layers_per_block=1, n_heads=8,
+               cross_dim=768, sample_size=16)
+
+
+@pytest.mark.parametrize("batch", [1, 3])
+def test_small_unet_matches_oracle(batch):
+    u = UNet2DConditionModel(text_len=77, **SMALL)
+    sd = u.synthetic_state_dict(7)
+    u.load_state_dict(sd)
+    g = torch.Generator().manual_seed(batch)
+    x = torch.randn(batch, 4, 16, 16, generator=g)
+    e = torch.randn(batch, 77, 768, generator=g)
+    y = u(x.cuda(), 781.0, encoder_hidden_states=e.cuda()).sample
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all()
+    ref_bf = OracleUNet(sd, SMALL_O, act_dtype=torch.bfloat16)(x, 781.0, e)
+    ref_32 = OracleUNet(sd, SMALL_O, act_dtype=None)(x, 781.0, e)
+    r1, r2 = rel_l2(y, ref_bf), rel_l2(y, ref_32)
+    print(f"small unet B={batch}: rel L2 vs bf16-emulating oracle {r1:.3e}, vs fp32 oracle {r2:.3e}")
+    assert r1 <= 1.5e-2 and r2 <= 5e-2
+    # batch rows are independent: sample 0 alone gives the same answer
+    y0 = u(x[:1].cuda(), 781.0, encoder_hidden_states=e[:1].cuda()).sample
+    torch.testing.assert_close(y0, y[:1], rtol=0, atol=0)
+
+
+def test_full_sd14_unet_matches_oracle():
+    u = UNet2DConditionModel()
+    sd = u.synthetic_state_dict(1234)
+    u.load_state_dict(sd)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 4, 64, 64, generator=g)
+    e = torch.randn(2, 77, 768, generator=g)
+    y = u(x.cuda(), 981.0, encoder_hidden_states=e.cuda()).sample
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all()
+    ref_bf = OracleUNet(sd, None, act_dtype=torch.bfloat16)(x, 981.0, e)
+    r1 = rel_l2(y, ref_bf)
+    print(f"full SD-v1.4 unet: rel L2 vs bf16-emulating oracle {r1:.3e}; |y| rms {float(y.pow(2).mean().sqrt()):.3f}")
+    assert r1 <= 1.5e-2

@@ -1,0 +1,73 @@
+"""Thin ctypes callers of libsdn's operator-level entry points, shared by the GPU tests and the benchmark."""
+import ctypes as C
+
+import torch
+
+import safe_denoiser_amd as sda
+from safe_denoiser_amd import _lib
+
+BF = torch.bfloat16
+
+
+def gemm(a, w, *, bias=None, rowbias=None, residual=None, a2=None, conv=None, act=0, out_kind=0, n_valid=0,
+         rows_per_batch=0):
+    """a [M,K] bf16 (or NHWC map for conv=dict(Hs,Ws,Cin,Ho,Wo,stride,upsample)), w [N,K] bf16."""
+    N, K = w.shape
+    d = _lib.GemmDesc()
+    if conv:
+        B = a.shape[0]
+        d.a_mode = 1
+        d.Hs, d.Ws, d.Cin, d.Ho, d.Wo = conv["Hs"], conv["Ws"], conv["Cin"], conv["Ho"], conv["Wo"]
+        d.stride, d.upsample = conv.get("stride", 1), conv.get("upsample", 0)
+        M = B * d.Ho * d.Wo
+        rows_per_batch = d.Ho * d.Wo
+    else:
+        M = a.shape[0]
+        d.K1 = a.shape[1] if a2 is not None else 0
+    d.M, d.N, d.K, d.act, d.out_kind, d.n_valid = M, N, K, act, out_kind, n_valid
+    d.rows_per_batch = rows_per_batch
+    if rowbias is not None:
+        d.ld_rowbias = rowbias.shape[1]
+    nv = n_valid or N
+    if out_kind == 0:
+        out = torch.empty((M, N // 2 if act == 2 else nv), dtype=BF, device=a.device)
+    elif out_kind == 1:
+        out = torch.empty((M, nv), dtype=torch.float32, device=a.device)
+    else:
+        out = torch.empty((M // rows_per_batch, nv, rows_per_batch), dtype=torch.float32, device=a.device)
+    p = lambda t: None if t is None else t.data_ptr()
+    _lib.check(sda.lib().sdn_gemm_bf16(C.byref(d), p(a), p(a2), p(w), p(bias), p(rowbias), p(residual), p(out),
+                                       _lib.stream_ptr()), "sdn_gemm_bf16")
+    return out
+
+
+def groupnorm(x, x2, groups, eps, silu, gamma, beta):
+    B, hw, c1 = x.shape
+    c2 = 0 if x2 is None else x2.shape[2]
+    out = torch.empty((B, hw, c1 + c2), dtype=BF, device=x.device)
+    ws = torch.empty(B * 16 * groups * 2, dtype=torch.float32, device=x.device)
+    _lib.check(sda.lib().sdn_groupnorm_bf16(x.data_ptr(), None if x2 is None else x2.data_ptr(), B, hw, c1, c2, groups,
+                                            eps, silu, gamma.data_ptr(), beta.data_ptr(), out.data_ptr(),
+                                            ws.data_ptr(), _lib.stream_ptr()), "sdn_groupnorm_bf16")
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    rows, c = x.shape
+    out = torch.empty_like(x)
+    _lib.check(sda.lib().sdn_layernorm_bf16(x.data_ptr(), rows, c, eps, gamma.data_ptr(), beta.data_ptr(),
+                                            out.data_ptr(), _lib.stream_ptr()), "sdn_layernorm_bf16")
+    return out
+
+
+def attention(q, k, v, heads, scale=None):
+    """q [B,Nq,H*d], k/v [B,Nk,H*d] bf16 (may be strided views of a fused projection)."""
+    B, nq, c = q.shape
+    nk = k.shape[1]
+    d = c // heads
+    out = torch.empty((B, nq, c), dtype=BF, device=q.device)
+    scale = scale if scale is not None else d ** -0.5
+    _lib.check(sda.lib().sdn_attention_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, heads, nq, nk,
+                                            d, q.stride(1), k.stride(1), v.stride(1), c, scale, _lib.stream_ptr()),
+               "sdn_attention_bf16")
+    return out
