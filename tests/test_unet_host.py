@@ -41,8 +41,8 @@ def test_offsets_are_disjoint_and_aligned():
 
 
 def test_pack_layouts_small_config():
-    u = UNet2DConditionModel(block_out_channels=(64, 128), down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"),
-                             layers_per_block=1, attention_head_dim=2, cross_attention_dim=64, sample_size=8,
+    u = UNet2DConditionModel(block_out_channels=(64, 64), down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"),
+                             layers_per_block=1, attention_head_dim=1, cross_attention_dim=64, sample_size=8,
                              norm_num_groups=32, text_len=5)
     sd = u.synthetic_state_dict(0)
     buf = u.pack_state_dict(sd)
@@ -66,7 +66,7 @@ def test_pack_layouts_small_config():
     k = by["down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_k.weight"]
     assert k["offset"] == q["offset"] + q["rows"] * q["cols"] * 2
     # the oracle accepts exactly this state dict
-    o = OracleUNet(sd, dict(block_out_channels=(64, 128), level_has_attn=(True, False), layers_per_block=1, n_heads=2,
+    o = OracleUNet(sd, dict(block_out_channels=(64, 64), level_has_attn=(True, False), layers_per_block=1, n_heads=1,
                             cross_dim=64, sample_size=8))
     y = o(torch.randn(1, 4, 8, 8), 500.0, torch.randn(1, 5, 64))
     assert y.shape == (1, 4, 8, 8) and torch.isfinite(y).all()
