@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec (512x512, 50 steps, SD-v1.4 + repellency) on N MI355X of one node.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one batch of P prompts taken through the whole hot path: 50 denoising iterations, each = UNet forward on
+[2P,4,64,64] (CFG) + guidance combine + (t in 780..1000: x0 probe + repellency projection against proj_ref[515] +
+device-side re-noise select) + scheduler step.  Inputs are synthetic (no weights/datasets on the box) and resident in
+HBM before the timed region: SD-v1.4-architecture UNet with random weights (seed 1234), text states randn (seed 7),
+proj_ref = channel-normalised randn([515,4,64,64], seed 0), repellency knobs of configs/nudity/safe_denoiser.yaml,
+beta_threshold calibrated by the engine's own row-R5 path.  Prompts shard across ranks (no collective in the loop);
+rank 0 broadcasts proj_ref + threshold once over RCCL.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_HBM_GBS = 8000.0          # HBM3E peak, same table
+
+
+def build_engine(args, rank, world, dev):
+    from safe_denoiser_amd import dist as sdist
+    from safe_denoiser_amd.pipeline import SafeDenoiserPipeline, make_scheduler
+    from safe_denoiser_amd.repellency import repellency_methods_threshold as thr
+    from safe_denoiser_amd.unet import UNet2DConditionModel
+
+    unet = UNet2DConditionModel()
+    unet.load_state_dict(unet.synthetic_state_dict(1234), device=dev)
+    sched = make_scheduler(args.scheduler)
+
+    refs = None
+    if rank == 0:
+        g = torch.Generator().manual_seed(0)
+        refs = torch.randn(args.refs, 4, 64, 64, generator=g)
+        refs = refs / torch.norm(refs, dim=1, keepdim=True)
+    refs = sdist.broadcast_proj_ref(refs, dev)                         # RCCL broadcast, 33.75 MB
+    tmp = tempfile.mkdtemp(prefix=f"sdn_bench_r{rank}_")
+    path = os.path.join(tmp, "repellency_proj_ref.pt")
+    torch.save(refs.cpu(), path)
+    knobs = dict(scale=0.33, sigma=3.15, beta_threshold_margin=1.6, proj_ref_path=path, cache_proj_ref=True)
+    if rank == 0:                                                       # row R5: calibrate once, share the scalar
+        cal = thr.get_repellency_method("kernel_fast", torch.zeros(1, device=dev), None, None, 50, 1000, 0.00085,
+                                        0.012, n_embed=16, scheduler=make_scheduler("ddpm"),
+                                        proj_noisy_ref_path_for_beta=None, **knobs)
+        beta = float(cal.beta_threshold)
+        del cal
+    else:
+        beta = 0.0
+    beta = sdist.broadcast_scalar(beta, dev)
+    proc = thr.get_repellency_method("kernel_fast", torch.zeros(1, device=dev), None, None, 50, 1000, 0.00085, 0.012,
+                                     n_embed=16, beta_threshold=beta, **knobs)
+    pipe = SafeDenoiserPipeline(unet, sched, variant="threshold_time")
+    return unet, pipe, proc, beta
+
+
+def cpu_baseline(args):
+    """The CPU oracle (a port of the reference loop, fp32 torch ops) on the host cores: ONE of the 50 denoising
+    iterations of ONE prompt at the full SD-v1.4 size, inside the repellency window, extrapolated x50."""
+    from oracle import repellency as orp
+    from oracle import schedulers as osch
+    from oracle.unet import OracleUNet
+    from safe_denoiser_amd.unet import UNet2DConditionModel
+    cores = torch.get_num_threads()
+    sd = UNet2DConditionModel().synthetic_state_dict(1234)
+    unet = OracleUNet(sd, None, act_dtype=None)
+    g = torch.Generator().manual_seed(0)
+    refs = orp.channel_normalise(torch.randn(args.refs, 4, 64, 64, generator=g))
+    lat = torch.randn(1, 4, 64, 64, generator=g)
+    text = torch.randn(2, 77, 768, generator=g)
+    s = osch.DDPM(); s.set_timesteps(50)
+    t0 = time.perf_counter()
+    out = unet(torch.cat([lat] * 2), 981.0, text)
+    eps = out[0:1] + 7.5 * (out[1:2] - out[0:1])
+    x0 = s.step(eps, 981, lat, generator=g).pred_original_sample
+    orp.kernel_fast_conditioning(x0, refs, flavour="threshold", scale=0.33, sigma=3.15, beta_threshold=1.0,
+                                 beta_threshold_margin=1.6, use_beta_threshold=True)
+    s.step(eps, 981, lat, generator=g)
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / (50.0 * dt), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"1 prompt x 1 of 50 iterations (UNet b=2 fp32 + CFG + x0 probe + repellency M={args.refs} + "
+                      f"DDPM step) = {dt:.2f} s of CPU work, extrapolated x50"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--prompts-per-batch", type=int, default=16)
+    ap.add_argument("--inference-steps", type=int, default=50)
+    ap.add_argument("--scheduler", default="ddpm", choices=["ddpm", "ddim"])
+    ap.add_argument("--refs", type=int, default=515)
+    ap.add_argument("--total-prompts", type=int, default=515)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from safe_denoiser_amd import dist as sdist
+    rank, world, local = sdist.init_from_env()
+    if world != args.gpus and rank == 0:
+        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    unet, pipe, proc, beta = build_engine(args, rank, world, dev)
+    P = args.prompts_per_batch
+    mine = sdist.shard_indices(args.total_prompts, rank, world)        # this rank's prompts of the 515-prompt job
+    g = torch.Generator().manual_seed(7)
+    text_all = torch.randn(args.total_prompts, 77, 768, generator=g)
+    uncond = torch.randn(1, 77, 768, generator=torch.Generator().manual_seed(8))
+
+    def batch(k):
+        idx = [mine[(k * P + j) % len(mine)] for j in range(P)]
+        E = torch.cat([uncond.expand(P, -1, -1), text_all[idx]]).to(dev)
+        gens = [torch.Generator(device=dev).manual_seed(1000 + i) for i in idx]
+        return E, gens
+
+    def run(k, profile=False):
+        E, gens = batch(k)
+        if profile:
+            unet.profile_next()
+        return pipe(prompt_embeddings=E, num_inference_steps=args.inference_steps, guidance_scale=7.5, generator=gens,
+                    repellency_processor=proc, return_latents=True)
+
+    for k in range(args.warmup):
+        run(k)
+    sdist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    renoise = 0
+    for k in range(args.steps):
+        out = run(args.warmup + k)
+        renoise += pipe.last_stats["renoise_draws"]
+    torch.cuda.synchronize(); sdist.barrier()
+    dt = sdist.max_over_ranks(time.perf_counter() - t0, dev)
+    assert torch.isfinite(out).all()
+
+    # ---- live kernel timing (HIP events on the launch stream) of one UNet forward at the benchmark shape ----
+    x = torch.randn(2 * P, 4, 64, 64, device=dev)
+    tb = unet.prepare_text(torch.randn(2 * P, 77, 768, device=dev))
+    y = torch.empty_like(x)
+    unet.forward_into(x, 981.0, tb, y)
+    rows_acc = {}
+    for _ in range(3):
+        unet.profile_next()
+        unet.forward_into(x, 981.0, tb, y)
+        for r in unet.profile_read():
+            a = rows_acc.setdefault(r["kernel"], dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            for f in ("launches", "ms", "flops", "bytes"):
+                a[f] += r[f]
+    dom = max(rows_acc, key=lambda k_: rows_acc[k_]["ms"])
+    d = rows_acc[dom]
+    achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+    attn = {k_: v for k_, v in rows_acc.items() if k_.startswith("k_attn")}
+    attn_tf = sum(v["flops"] for v in attn.values()) / (sum(v["ms"] for v in attn.values()) * 1e-3) / 1e12
+    unet_ms = sum(v["ms"] for v in rows_acc.values()) / 3
+    total_f, attn_f = unet.flops(2 * P)
+
+    # repellency projection (HBM-bound): algorithmic bytes = one read of proj_ref + x in/out
+    xq = torch.randn(P, 4, 64, 64, device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    proc.conditioning_device(xq)
+    e0.record()
+    for _ in range(20):
+        proc.conditioning_device(xq)
+    e1.record(); torch.cuda.synchronize()
+    rep_ms = e0.elapsed_time(e1) / 20
+    rep_bytes = args.refs * 16384 * 4 + 2 * P * 16384 * 4
+
+    n_img = world * P * args.steps
+    value = n_img / dt
+    line = {
+        "metric": "images/sec (512x512, 50 steps, SD-v1.4 + repellency)", "value": value, "unit": "images/sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"SD-v1.4 UNet (random weights) + safe_denoiser.yaml repellency (kernel_fast, M={args.refs}, "
+                               f"sigma 3.15, scale .33, margin 1.6, window 780<=t<=1000), {args.total_prompts}-prompt job "
+                               f"sharded r::{world}, CFG 7.5 (2 branches), {args.scheduler.upper()} {args.inference_steps} "
+                               f"steps, 64x64x4 latents",
+                   "prompts_per_batch": P, "images_timed": n_img, "beta_threshold": beta,
+                   "renoise_draws_rank0": renoise, "parallelism": f"prompt-shard x{world}"},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None, "kernel": dom,
+                     "launches_per_forward": d["launches"] // 3, "avg_launch_us": d["ms"] / d["launches"] * 1e3,
+                     "share_of_unet_time": d["ms"] / 3 / unet_ms},
+        "attention_roofline": {"achieved": attn_tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                               "frac": attn_tf / PEAK_BF16_TFLOPS,
+                               "kernels": {k_: {"avg_launch_us": v["ms"] / v["launches"] * 1e3,
+                                                "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12} for k_, v in attn.items()}},
+        "unet": {"ms_per_forward": unet_ms, "batch": 2 * P, "tflops": total_f / (unet_ms * 1e-3) / 1e12,
+                 "attention_core_share_of_flops": attn_f / total_f,
+                 "by_kernel_ms": {k_: v["ms"] / 3 for k_, v in sorted(rows_acc.items(), key=lambda kv: -kv[1]["ms"])}},
+        "repellency_roofline": {"bound": "hbm", "achieved": rep_bytes / (rep_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
+                                "unit": "GB/s", "frac": rep_bytes / (rep_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                "us_per_call": rep_ms * 1e3, "queries": P},
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

@@ -262,6 +262,19 @@ double sdn_unet_flops(sdn_unet* u, int32_t batch, double* attention_core_flops_h
 int sdn_unet_forward(sdn_unet* u, const void* weights, const float* latents, float timestep, const void* text,
                      float* out, int32_t batch, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- opt-in measurement: HIP events around every launch of ONE forward, on the forward's own stream ---- */
+typedef struct sdn_profile_row {
+  char    kernel[24];     /* kernel symbol, e.g. "k_gemm<5>", "k_attn<40>"                              */
+  int32_t launches;       /* launches of it in the profiled forward                                     */
+  double  ms;             /* summed event-to-event time of those launches                               */
+  double  flops;          /* summed algorithmic FLOPs (2MNK; 4 B H Nq Nk d)                             */
+  double  bytes;          /* summed algorithmic HBM bytes (operands once + result once)                 */
+} sdn_profile_row;
+/* Arms profiling for the NEXT sdn_unet_forward on this handle (that forward records 2 events per launch). */
+void sdn_unet_profile_next(sdn_unet* u);
+/* Waits for the profiled forward's events and aggregates them by kernel.  Returns the number of rows (<0 = error). */
+int  sdn_unet_profile_read(sdn_unet* u, sdn_profile_row* rows_host, int32_t max_rows);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,6 +45,11 @@ class UnetConfig(C.Structure):
                 ("text_len", C.c_int32), ("norm_groups", C.c_int32)]
 
 
+class ProfileRow(C.Structure):
+    _fields_ = [("kernel", C.c_char * 24), ("launches", C.c_int32), ("ms", C.c_double), ("flops", C.c_double),
+                ("bytes", C.c_double)]
+
+
 class ParamInfo(C.Structure):
     _fields_ = [("name", C.c_char * 128), ("kind", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32),
                 ("rows_padded", C.c_int32), ("offset", C.c_int64)]
@@ -82,6 +87,8 @@ SIGNATURES = {
     "sdn_unet_workspace_bytes": (_sz, [_vp, _i32]),
     "sdn_unet_flops": (C.c_double, [_vp, _i32, C.POINTER(C.c_double)]),
     "sdn_unet_forward": (C.c_int, [_vp, _vp, _vp, _f32, _vp, _vp, _i32, _vp, _sz, _vp]),
+    "sdn_unet_profile_next": (None, [_vp]),
+    "sdn_unet_profile_read": (C.c_int, [_vp, C.POINTER(ProfileRow), _i32]),
 }
 
 

@@ -48,6 +48,9 @@ struct Op {
   int heads = 0, nq = 0, nk = 0, hd = 0, ldq = 0, ldk = 0, ldv = 0, ldo = 0;
   float scale = 0.f;
   Ref k, v;
+  char label[24] = {0};      // kernel symbol this op launches (profiling rows are aggregated by it)
+  double flops = 0.0;        // algorithmic FLOPs of this launch
+  double bytes = 0.0;        // algorithmic HBM bytes of this launch (operands read once + result written once)
 };
 
 struct Arena {                      // plan-time first-fit allocator with coalescing; offsets are 256-B aligned
@@ -112,6 +115,9 @@ struct sdn_unet {
   int64_t weight_bytes = 0;
   std::map<int, Plan> plans;
   int tproj_total = 0;
+  bool profile_next = false;
+  std::vector<hipEvent_t> ev;          // 2 per op of the profiled forward
+  int profiled_batch = 0;
 };
 
 namespace {
@@ -169,8 +175,11 @@ struct Builder {
     o.gd.M = (int)M; o.gd.N = N; o.gd.K = K; o.gd.a_mode = SDN_A_PLAIN; o.gd.K1 = K1; o.gd.act = act_;
     o.gd.out_kind = out_kind; o.gd.n_valid = n_valid; o.gd.rows_per_batch = rows_per_batch; o.gd.ld_rowbias = ld_rowbias;
     o.a = a; o.a2 = a2; o.w = w; o.bias = bias; o.rowbias = rowbias; o.residual = residual; o.out = out;
+    o.flops = 2.0 * (double)M * (double)(n_valid > 0 ? n_valid : N) * (double)K;
+    o.bytes = 2.0 * ((double)M * K + (double)N * K + (double)M * (act_ == SDN_ACT_GEGLU ? N / 2 : N));
+    snprintf(o.label, sizeof(o.label), "k_gemm<%d>", sdn_gemm_pick_nrep(N, act_));
     plan->ops.push_back(o);
-    plan->flops += 2.0 * (double)M * (double)(n_valid > 0 ? n_valid : N) * (double)K;
+    plan->flops += o.flops;
   }
   void conv3x3(const Act& in, int cout, int n_pad, Ref w, Ref bias, Ref out, int stride, int upsample, Ref residual,
                Ref rowbias, int ld_rowbias, int out_kind = SDN_OUT_BF16, int n_valid = 0) {
@@ -182,26 +191,36 @@ struct Builder {
     o.gd.upsample = upsample; o.gd.out_kind = out_kind; o.gd.n_valid = n_valid; o.gd.rows_per_batch = Ho * Ho;
     o.gd.ld_rowbias = ld_rowbias;
     o.a = R(in); o.w = w; o.bias = bias; o.rowbias = rowbias; o.residual = residual; o.out = out;
+    o.flops = 2.0 * (double)o.gd.M * (double)cout * (double)o.gd.K;
+    o.bytes = 2.0 * ((double)B * in.side * in.side * in.C + (double)n_pad * o.gd.K + (double)o.gd.M * cout);
+    snprintf(o.label, sizeof(o.label), "k_gemm<%d>", sdn_gemm_pick_nrep(n_pad, SDN_ACT_NONE));
     plan->ops.push_back(o);
-    plan->flops += 2.0 * (double)o.gd.M * (double)cout * (double)o.gd.K;
+    plan->flops += o.flops;
   }
   void groupnorm(const Act& x, const Act* x2, float eps, int silu, Ref gamma, Ref beta, const Act& out) {
     Op o; o.kind = OP_GN; o.a = R(x); if (x2) o.a2 = R(*x2);
     o.batch = B; o.hw = x.hw; o.c1 = x.C; o.c2 = x2 ? x2->C : 0; o.groups = u->cfg.norm_groups; o.eps = eps;
     o.silu = silu; o.w = gamma; o.bias = beta; o.out = R(out); o.aux = gn_stats;
+    o.bytes = 2.0 * 3.0 * (double)B * x.hw * (o.c1 + o.c2);       // two reads (stats, apply) + one write
+    snprintf(o.label, sizeof(o.label), "k_gn_stats+apply");
     plan->ops.push_back(o);
   }
   void layernorm(const Act& x, Ref gamma, Ref beta, const Act& out) {
     Op o; o.kind = OP_LN; o.a = R(x); o.rows = (int64_t)B * x.hw; o.c1 = x.C; o.eps = 1e-5f; o.w = gamma; o.bias = beta;
     o.out = R(out);
+    o.bytes = 2.0 * 2.0 * (double)o.rows * x.C;
+    snprintf(o.label, sizeof(o.label), "k_layernorm");
     plan->ops.push_back(o);
   }
   void attention(Ref q, Ref k, Ref v, Ref out, int nq, int nk, int C, int ldq, int ldk, int ldv) {
     Op o; o.kind = OP_ATTN; o.a = q; o.k = k; o.v = v; o.out = out; o.batch = B; o.heads = u->cfg.n_heads;
     o.nq = nq; o.nk = nk; o.hd = C / u->cfg.n_heads; o.ldq = ldq; o.ldk = ldk; o.ldv = ldv; o.ldo = C;
     o.scale = 1.0f / sqrtf((float)o.hd);
-    plan->ops.push_back(o);
     const double f = 4.0 * (double)B * o.heads * (double)nq * (double)nk * (double)o.hd;
+    o.flops = f;
+    o.bytes = 2.0 * (double)B * C * (2.0 * nq + 2.0 * nk);
+    snprintf(o.label, sizeof(o.label), "k_attn<%d>", o.hd);
+    plan->ops.push_back(o);
     plan->flops += f; plan->attn_flops += f;
   }
 
@@ -350,7 +369,7 @@ struct Builder {
     u->tproj_total = total;
     gn_stats = Ref{SP_WS, arena.alloc((int64_t)B * 16 * 64 * 2 * 4)};
     Act tsin = act(B, ch0);
-    { Op o; o.kind = OP_TEMB; o.batch = B; o.c1 = ch0; o.out = R(tsin); plan->ops.push_back(o); }
+    { Op o; o.kind = OP_TEMB; o.batch = B; o.c1 = ch0; o.out = R(tsin); snprintf(o.label, sizeof(o.label), "k_temb"); plan->ops.push_back(o); }
     Act t1 = act(B, tdim);
     gemm(B, tdim, ch0, R(tsin), l1w, l1b, R(t1), SDN_ACT_SILU);
     drop(tsin);
@@ -365,8 +384,10 @@ struct Builder {
     // ---- conv_in ----
     Ref ciw = param("conv_in.weight", SDN_P_CONV3X3, ch0, 9 * c.in_channels), cib = param("conv_in.bias", SDN_P_VEC_F32, ch0, 0);
     Act h = act((int64_t)B * S * S, ch0, S * S, S);
-    { Op o; o.kind = OP_CONV_IN; o.batch = B; o.c1 = c.in_channels; o.c2 = ch0; o.hw = S; o.a = Ref{SP_LATENTS, 0}; o.w = ciw; o.bias = cib; o.out = R(h); plan->ops.push_back(o);
-      plan->flops += 2.0 * B * S * S * (double)ch0 * 9 * c.in_channels; }
+    { Op o; o.kind = OP_CONV_IN; o.batch = B; o.c1 = c.in_channels; o.c2 = ch0; o.hw = S; o.a = Ref{SP_LATENTS, 0}; o.w = ciw; o.bias = cib; o.out = R(h);
+      o.flops = 2.0 * B * S * S * (double)ch0 * 9 * c.in_channels; o.bytes = (double)B * S * S * (4.0 * c.in_channels + 2.0 * ch0);
+      snprintf(o.label, sizeof(o.label), "k_conv_in"); plan->ops.push_back(o);
+      plan->flops += o.flops; }
 
     std::vector<Act> skips;
     skips.push_back(h);                       // h stays alive as a skip; keep using it as the running tensor
@@ -528,8 +549,16 @@ int sdn_unet_forward(sdn_unet* u, const void* weights, const float* latents, flo
   const char* W = (const char*)weights; const char* WS = (const char*)workspace;
   const char* L = (const char*)latents; const char* T = (const char*)text; const char* O = (const char*)out;
   auto P = [&](const Ref& r) { return resolve(r, W, WS, L, T, O); };
+  const bool prof = u->profile_next;
+  if (prof) {                                    // opt-in diagnostics: HIP events around every launch of this forward
+    u->profile_next = false;
+    while (u->ev.size() < 2 * p->ops.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return SDN_E_LAUNCH; u->ev.push_back(e); }
+    u->profiled_batch = batch;
+  }
+  size_t opi = 0;
   for (const Op& o : p->ops) {
     int rc = SDN_OK;
+    if (prof) (void)hipEventRecord(u->ev[2 * opi], (hipStream_t)stream);
     switch (o.kind) {
       case OP_TEMB:
         rc = sdn_timestep_embed_bf16(timestep, o.batch, o.c1, (void*)P(o.out), stream);
@@ -555,9 +584,36 @@ int sdn_unet_forward(sdn_unet* u, const void* weights, const float* latents, flo
                                 o.ldk, o.ldv, o.ldo, o.scale, stream);
         break;
     }
+    if (prof) (void)hipEventRecord(u->ev[2 * opi + 1], (hipStream_t)stream);
+    ++opi;
     if (rc != SDN_OK) return rc;
   }
   return SDN_OK;
+}
+
+void sdn_unet_profile_next(sdn_unet* u) { if (u) u->profile_next = true; }
+
+int sdn_unet_profile_read(sdn_unet* u, sdn_profile_row* rows, int32_t max_rows) {
+  if (!u || !rows || max_rows <= 0 || u->profiled_batch <= 0) return SDN_E_INVALID;
+  Plan* p = get_plan(u, u->profiled_batch);
+  if (u->ev.size() < 2 * p->ops.size()) return SDN_E_INVALID;
+  int n = 0;
+  for (size_t i = 0; i < p->ops.size(); ++i) {
+    if (hipEventSynchronize(u->ev[2 * i + 1]) != hipSuccess) return SDN_E_LAUNCH;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, u->ev[2 * i], u->ev[2 * i + 1]) != hipSuccess) return SDN_E_LAUNCH;
+    const Op& o = p->ops[i];
+    int r = 0;
+    for (; r < n; ++r) if (strcmp(rows[r].kernel, o.label) == 0) break;
+    if (r == n) {
+      if (n == max_rows) return SDN_E_INVALID;
+      memset(&rows[r], 0, sizeof(rows[r]));
+      snprintf(rows[r].kernel, sizeof(rows[r].kernel), "%s", o.label);
+      ++n;
+    }
+    rows[r].launches += 1; rows[r].ms += ms; rows[r].flops += o.flops; rows[r].bytes += o.bytes;
+  }
+  return n;
 }
 
 }  // extern "C"

@@ -1,0 +1,103 @@
+"""Multi-GPU: one process per GPU, prompts sharded across ranks, proj_ref broadcast once.
+
+The reference has no distributed code; its only sharding hook is the manual prompt slice
+`--valid_case_numbers start,end` (run_nudity.py:373-375,584).  Prompts are independent units (per-prompt seed,
+run_nudity.py:448), so the step loop needs NO collective: rank r takes its shard, rank 0 broadcasts `proj_ref`
+(33.75 MB for M=515) and the calibrated `beta_threshold` over RCCL/xGMI at start, counters are gathered at the end.
+backend "nccl" is RCCL on ROCm; "gloo" is used for the CPU tests.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None):
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun contract).  Returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    return rank, world, local
+
+
+def shard_indices(n_items: int, rank: int, world: int, mode: str = "strided"):
+    """Prompt indices of this rank.  "strided": r, r+W, ... (balanced tail); "contiguous": the reference's
+    valid_case_numbers-style slice [start, end)."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    if mode == "strided":
+        return list(range(rank, n_items, world))
+    if mode == "contiguous":
+        per = (n_items + world - 1) // world
+        return list(range(min(rank * per, n_items), min((rank + 1) * per, n_items)))
+    raise ValueError(mode)
+
+
+def valid_case_numbers(n_items: int, rank: int, world: int):
+    """(start, end) as the reference's --valid_case_numbers would be given to rank r of W."""
+    idx = shard_indices(n_items, rank, world, "contiguous")
+    return (idx[0], idx[-1] + 1) if idx else (n_items, n_items)
+
+
+def broadcast_proj_ref(refs: Optional[torch.Tensor], device, src: int = 0) -> torch.Tensor:
+    """Rank `src` holds refs [M,C,H,W] fp32; everyone returns the same tensor on `device`.  Verifies the payload
+    with an fp64 checksum all-reduced MIN/MAX (cheap, once per run)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return refs.to(device)
+    rank = dist.get_rank()
+    meta = torch.zeros(4, dtype=torch.int64, device=device)
+    if rank == src:
+        meta = torch.tensor(list(refs.shape), dtype=torch.int64, device=device)
+    dist.broadcast(meta, src=src)
+    buf = refs.to(device=device, dtype=torch.float32).contiguous() if rank == src else \
+        torch.empty(tuple(meta.tolist()), dtype=torch.float32, device=device)
+    dist.broadcast(buf, src=src)
+    chk = buf.double().sum().reshape(1)
+    lo, hi = chk.clone(), chk.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    if float(lo) != float(hi):
+        raise RuntimeError("proj_ref broadcast checksum mismatch across ranks")
+    return buf
+
+
+def broadcast_scalar(value: float, device, src: int = 0) -> float:
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.broadcast(t, src=src)
+    return float(t.item())
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def max_over_ranks(value: float, device) -> float:
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value: float, device) -> float:
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())

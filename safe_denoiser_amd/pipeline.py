@@ -1,0 +1,205 @@
+"""The denoising loop with per-step repellency projection -- batched over prompts.
+
+Call surface: the reference's `ModifiedSafreeDiffusionPipeline_Rep.__call__`
+(models/textuals_visual/modified_safree_diffusion_pipeline_threshold_time.py:352-375,598) restricted to the hot path:
+the tensor-level inputs the loop consumes (`prompt_embeddings`, `generator`, `latents`, `repellency_processor`,
+`safree_dict`, `negation_warmup_start/end`, `return_latents`).  The text encoder, SAFREE text projection and the VAE
+decoder sit either side of the loop and are not part of this engine: pass CLIP hidden states
+as `prompt_embeddings` ([2P,77,768] = chunk(2) -> [P uncond | P text], or [3P,...] with `lra`), get latents back.
+
+What differs from the reference by design (results per sample are the same):
+  * P prompts are denoised together (the reference is hard-wired to batch 1); every prompt keeps its OWN
+    torch.Generator so its random stream -- latents, the discarded variance draw of the x0 probe, the conditional
+    re-noise draw, the step's variance draw, in that order (row S2) -- is exactly the reference's;
+  * all per-element math is in libsdn kernels; the only host<->device traffic in the loop is ONE readback of the
+    P is_negation flags per repellency-window step (the reference syncs three times per step per prompt), needed
+    only because the number of randn draws depends on the flag.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Sequence
+
+import torch
+
+from . import _lib
+from .schedulers import DDIMScheduler, DDPMScheduler
+
+# gating variants of the reference's pipeline files: (window kind, lo, hi,
+# beta_threshold kwarg, honours is_negation)
+VARIANTS = {
+    "threshold_time": ("t", 780, 1000, True, True),     # *_threshold_time.py  (north-star path)
+    "time": ("t", 800, 1000, False, False),             # *_time.py
+    "threshold": ("i", 0, 50, True, True),              # *_threshold.py
+    "plain": (None, 0, 0, False, True),                 # modified_{safree,sld}_diffusion_pipeline.py: every step
+}
+
+
+class SafeDenoiserPipeline:
+    def __init__(self, unet, scheduler, variant: str = "threshold_time"):
+        if variant not in VARIANTS:
+            raise KeyError(f"unknown variant {variant}; have {sorted(VARIANTS)}")
+        self.unet, self.scheduler, self.variant = unet, scheduler, variant
+        self.vae_scale_factor = 8
+        self.last_stats = {}
+
+    # ------------------------------------------------------------------------------------------------
+    def _noise(self, noise_fn, generators, p: int, shape, device):
+        if noise_fn is not None:
+            return noise_fn(p, shape).to(device=device, dtype=torch.float32)
+        return torch.randn(shape, generator=generators[p], device=device, dtype=torch.float32)
+
+    @torch.no_grad()
+    def __call__(self, prompt=None, height: Optional[int] = None, width: Optional[int] = None,
+                 num_inference_steps: int = 50, guidance_scale: float = 7.5, generator=None, latents=None,
+                 prompt_embeddings: Optional[torch.Tensor] = None, repellency_processor=None, safree_dict=None,
+                 rescaled_text_embeddings: Optional[torch.Tensor] = None, beta_adjusted: Optional[int] = None,
+                 return_latents: bool = True, noise_fn: Optional[Callable] = None, **kwargs):
+        _lib.require_gpu()
+        if prompt_embeddings is None:
+            raise NotImplementedError("the CLIP text encoder is outside the hot path (SURVEY.md section 8f row 4): pass "
+                                      "`prompt_embeddings` ([2P,77,768]) instead of `prompt` strings")
+        if not return_latents:
+            raise NotImplementedError("the VAE decoder is outside the hot path (SURVEY.md section 8f row 2): use "
+                                      "return_latents=True (the reference's parity tap, ...threshold_time.py:585-586)")
+        sf = dict(safree=False, svf=False, lra=False, re_attn_t=(-1, -1))
+        if safree_dict:
+            sf.update(safree_dict)
+        kind, lo_default, hi_default, use_beta, use_flag = VARIANTS[self.variant]
+        hi = kwargs.get("negation_warmup_start", hi_default)          # reference: t <= start and t >= end
+        lo = kwargs.get("negation_warmup_end", lo_default)
+        nb = 3 if sf["lra"] else 2
+        if guidance_scale <= 1.0:
+            raise NotImplementedError("guidance_scale <= 1 (no CFG) is not on the reference's benchmarked path")
+        dev = torch.device("cuda", torch.cuda.current_device())
+        E = prompt_embeddings.to(dev)
+        if E.shape[0] % 2 != 0:
+            raise _lib.SdnError("prompt_embeddings must be [2P,77,768]: P unconditional rows then P text rows")
+        P = E.shape[0] // 2
+        s = self.unet.config.sample_size
+        height = height or s * self.vae_scale_factor
+        width = width or s * self.vae_scale_factor
+        if (height // self.vae_scale_factor, width // self.vae_scale_factor) != (s, s):
+            raise _lib.SdnError(f"this UNet plan is built for {s * 8}x{s * 8} images")
+        C_ = self.unet.config.in_channels
+        shape1 = (1, C_, s, s)
+        D = C_ * s * s
+
+        # text branches: [uncond | E'(or E) | (text_e when lra)]  (...threshold_time.py:525-540)
+        E_plain = self._branches(E, E, nb)
+        E_safe = self._branches(rescaled_text_embeddings.to(dev), E, nb) if (sf["safree"] and rescaled_text_embeddings
+                                                                             is not None) else None
+        tb_plain = self.unet.prepare_text(E_plain)
+        tb_safe = self.unet.prepare_text(E_safe) if E_safe is not None else None
+
+        sch = self.scheduler
+        sch.set_timesteps(num_inference_steps)
+        timesteps = [int(t) for t in sch.timesteps]
+
+        gens = self._generators(generator, P, dev) if noise_fn is None else None
+        if latents is None:
+            lat = torch.empty((P, C_, s, s), dtype=torch.float32, device=dev)
+            for p in range(P):
+                lat[p:p + 1] = self._noise(noise_fn, gens, p, shape1, dev)
+            lat = lat * sch.init_noise_sigma if sch.init_noise_sigma != 1.0 else lat
+        else:
+            lat = latents.to(device=dev, dtype=torch.float32).clone()
+
+        L = _lib.lib()
+        st = _lib.stream_ptr()
+        x_in = torch.empty((nb * P, C_, s, s), dtype=torch.float32, device=dev)
+        model_out = torch.empty_like(x_in)
+        eps = torch.empty((P, C_, s, s), dtype=torch.float32, device=dev)
+        x0 = torch.empty_like(eps)
+        noise = torch.empty_like(eps)
+        nxt = torch.empty_like(eps)
+        is_ddpm = isinstance(sch, DDPMScheduler)
+        n_renoise = 0
+        n_window = 0
+
+        for i, t in enumerate(timesteps):
+            x_in.view(nb, P, C_, s, s).copy_(lat)                                   # cat([latents] * nb)
+            if sf["svf"]:
+                use_safe = tb_safe is not None and beta_adjusted is not None and i <= beta_adjusted
+            else:
+                use_safe = tb_safe is not None and sf["re_attn_t"][0] <= i <= sf["re_attn_t"][1]
+            self.unet.forward_into(x_in, float(t), tb_safe if use_safe else tb_plain, model_out)
+            _lib.check(L.sdn_cfg_combine(model_out.data_ptr(), P, nb, D, float(guidance_scale), eps.data_ptr(), st),
+                       "sdn_cfg_combine")
+
+            in_window = (kind is None) or (kind == "t" and lo <= t <= hi) or (kind == "i" and lo <= i <= hi)
+            if in_window and repellency_processor is not None:
+                n_window += 1
+                sa, s1 = sch.sqrt_pair(t)
+                clip = sch.config.clip_sample_range if sch.config.clip_sample else 0.0
+                _lib.check(L.sdn_pred_x0(lat.data_ptr(), eps.data_ptr(), lat.numel(), sa, s1, clip, x0.data_ptr(), st),
+                           "sdn_pred_x0")
+                if is_ddpm and t > 0:                       # scheduler.step() draws (and the caller discards) a randn
+                    for p in range(P):
+                        self._noise(noise_fn, gens, p, shape1, dev)
+                src, isneg = self._condition(repellency_processor, x0, use_beta)
+                if use_flag:
+                    flags = isneg.cpu().tolist()            # the one readback: decides how many randn are drawn
+                else:
+                    flags = [1] * P
+                    isneg = torch.ones(P, dtype=torch.int32, device=dev)
+                if any(flags):
+                    for p in range(P):
+                        if flags[p]:
+                            noise[p:p + 1] = self._noise(noise_fn, gens, p, shape1, dev)
+                            n_renoise += 1
+                    _lib.check(L.sdn_renoise_select(lat.data_ptr(), src.data_ptr(), noise.data_ptr(), isneg.data_ptr(),
+                                                    P, D, sa, s1, st), "sdn_renoise_select")
+
+            co = sch.step_coefficients(t)
+            z = None
+            if is_ddpm and t > 0:
+                for p in range(P):
+                    noise[p:p + 1] = self._noise(noise_fn, gens, p, shape1, dev)
+                z = noise
+            clip = sch.config.clip_sample_range if sch.config.clip_sample else 0.0
+            _lib.check(L.sdn_sched_step(lat.data_ptr(), eps.data_ptr(), None if z is None else z.data_ptr(),
+                                        lat.numel(), co["sqrt_ac"], co["sqrt_1mac"], co["c_x0"], co["c_x"], co["c_eps"],
+                                        co["sigma"] if z is not None else 0.0, clip, nxt.data_ptr(), st),
+                       "sdn_sched_step")
+            lat, nxt = nxt, lat
+
+        self.last_stats = {"renoise_draws": n_renoise, "window_steps": n_window, "prompts": P, "branches": nb}
+        return lat
+
+    # ------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _branches(first: torch.Tensor, base: torch.Tensor, nb: int) -> torch.Tensor:
+        if nb == 2:
+            return first
+        _, text_e = base.chunk(2)
+        return torch.cat([first, text_e])
+
+    @staticmethod
+    def _generators(generator, P: int, dev) -> Sequence[torch.Generator]:
+        if generator is None:
+            return [torch.Generator(device=dev).manual_seed(1000 + p) for p in range(P)]
+        if isinstance(generator, torch.Generator):
+            if P != 1:
+                raise _lib.SdnError("pass a list of P generators (one per prompt) when batching prompts")
+            return [generator]
+        if len(generator) != P:
+            raise _lib.SdnError(f"need {P} generators, got {len(generator)}")
+        return list(generator)
+
+    @staticmethod
+    def _condition(proc, x0: torch.Tensor, use_beta: bool):
+        """Device-side conditioning.  Returns (tensor to re-noise from, is_negation int32[P])."""
+        from .repellency import repellency_methods_threshold as thr
+        if hasattr(proc, "conditioning_device"):
+            returns_neg = isinstance(proc, thr.RBFKernelRepellency) and not use_beta   # conditioning_1 quirk, :190-193
+            neg, _den, isneg = proc.conditioning_device(x0, beta_threshold=use_beta, want_neg=returns_neg)
+            return (neg if returns_neg else x0), isneg
+        out = proc.conditioning(x0, beta_threshold=use_beta)                            # generic plug-in (host flags)
+        flag = out.get("is_negation", False)
+        isneg = torch.full((x0.shape[0],), int(bool(flag)), dtype=torch.int32, device=x0.device)
+        return out["x_0_hat"].contiguous(), isneg
+
+
+def make_scheduler(name: str = "ddpm"):
+    """"ddpm" = the live SD-v1.4 scheduler of the reference (run_nudity.py:108); "ddim" = the one BASELINE names."""
+    return DDPMScheduler() if name.lower() == "ddpm" else DDIMScheduler()

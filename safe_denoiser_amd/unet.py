@@ -148,6 +148,18 @@ class UNet2DConditionModel:
         total = _lib.lib().sdn_unet_flops(self._h, batch, C.byref(a))
         return total, a.value
 
+    def profile_next(self):
+        """Arm HIP-event profiling of the next forward (diagnostics; see sdn_unet_profile_next)."""
+        _lib.lib().sdn_unet_profile_next(self._h)
+
+    def profile_read(self) -> list:
+        rows = (_lib.ProfileRow * 32)()
+        n = _lib.lib().sdn_unet_profile_read(self._h, rows, 32)
+        if n < 0:
+            raise _lib.SdnError("sdn_unet_profile_read failed (no profiled forward?)")
+        return [dict(kernel=rows[i].kernel.decode(), launches=rows[i].launches, ms=rows[i].ms, flops=rows[i].flops,
+                     bytes=rows[i].bytes) for i in range(n)]
+
     def _workspace(self, batch: int, device):
         ws = self._ws.get(batch)
         if ws is None:

@@ -1,0 +1,69 @@
+"""N > 1 path on CPU: world_size-2 gloo processes exercise the prompt sharding, the proj_ref / threshold
+broadcast with checksum, and the end-of-run reductions bench.py relies on."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from safe_denoiser_amd import dist as sdist
+
+
+def test_shards_partition_every_prompt_exactly_once():
+    for n in (0, 1, 7, 515, 994, 10000):
+        for w in (1, 2, 4, 8):
+            for mode in ("strided", "contiguous"):
+                got = sorted(i for r in range(w) for i in sdist.shard_indices(n, r, w, mode))
+                assert got == list(range(n)), (n, w, mode)
+            sizes = [len(sdist.shard_indices(n, r, w)) for r in range(w)]
+            assert max(sizes) - min(sizes) <= 1
+    assert sdist.valid_case_numbers(515, 1, 8) == (65, 130)           # run_nudity.py --valid_case_numbers 65,130
+    assert sdist.valid_case_numbers(3, 7, 8) == (3, 3)
+    with pytest.raises(ValueError):
+        sdist.shard_indices(5, 2, 2)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    r, w, _ = sdist.init_from_env(backend="gloo")
+    dev = torch.device("cpu")
+    refs = None
+    if r == 0:
+        g = torch.Generator().manual_seed(0)
+        refs = torch.randn(9, 4, 8, 8, generator=g)
+        refs = refs / refs.norm(dim=1, keepdim=True)
+    got = sdist.broadcast_proj_ref(refs, dev)
+    thr = sdist.broadcast_scalar(3.25 if r == 0 else -1.0, dev)
+    mine = sdist.shard_indices(11, r, w)
+    sdist.barrier()
+    slowest = sdist.max_over_ranks(1.0 + r, dev)
+    total = sdist.sum_over_ranks(len(mine), dev)
+    q.put((r, float(got.double().sum()), tuple(got.shape), thr, mine, slowest, total))
+    dist.destroy_process_group()
+
+
+def test_world_size_2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, s0, sh0, t0, m0, sl0, tot0), (r1, s1, sh1, t1, m1, sl1, tot1) = res
+    assert s0 == s1 and sh0 == sh1 == (9, 4, 8, 8)                 # same proj_ref everywhere
+    assert t0 == t1 == 3.25                                        # every rank gates identically
+    assert m0 == [0, 2, 4, 6, 8, 10] and m1 == [1, 3, 5, 7, 9]
+    assert sl0 == sl1 == 2.0 and tot0 == tot1 == 11.0

@@ -193,8 +193,8 @@ def test_conv_in_and_timestep_embedding():
     bias = torch.randn(320, generator=torch.Generator().manual_seed(34))
     ref = F.conv2d(lat, w.float(), bias, padding=1).permute(0, 2, 3, 1)
     out = torch.empty(B, H, H, 320, dtype=BF, device="cuda")
-    wn = w.permute(0, 2, 3, 1).contiguous().cuda()
-    _lib.check(sda.lib().sdn_conv_in_bf16(lat.cuda().data_ptr(), wn.data_ptr(), bias.cuda().data_ptr(), B, 4, H, H, 320,
+    wn, lg, bg = w.permute(0, 2, 3, 1).contiguous().cuda(), lat.cuda(), bias.cuda()     # keep device tensors alive
+    _lib.check(sda.lib().sdn_conv_in_bf16(lg.data_ptr(), wn.data_ptr(), bg.data_ptr(), B, 4, H, H, 320,
                                           out.data_ptr(), _lib.stream_ptr()), "conv_in")
     torch.cuda.synchronize()
     check_bf16(out, ref)

@@ -1,0 +1,136 @@
+"""The batched HIP loop vs the per-prompt CPU oracle loop on the SAME per-prompt noise tapes (seed-for-seed).
+
+Tolerance: final latents, relative L2 <= 3e-2 per prompt vs the oracle run with bf16 storage emulation (the UNet's
+bf16 rounding noise accumulated over the steps; the loop arithmetic itself is fp32 on both sides), and the
+is_negation decisions / number of re-noise draws must match exactly (a mismatch would shift the random stream)."""
+import pytest
+import torch
+
+from oracle import pipeline as opipe
+from oracle import repellency as orp
+from oracle import schedulers as osch
+from oracle.unet import OracleUNet
+from safe_denoiser_amd.pipeline import SafeDenoiserPipeline
+from safe_denoiser_amd.repellency import repellency_methods_fast as fast
+from safe_denoiser_amd.repellency import repellency_methods_threshold as thr
+from safe_denoiser_amd.schedulers import DDIMScheduler, DDPMScheduler
+from safe_denoiser_amd.unet import UNet2DConditionModel
+
+pytestmark = pytest.mark.gpu
+
+SMALL = dict(block_out_channels=(320, 640), down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"),
+             layers_per_block=1, attention_head_dim=8, cross_attention_dim=768, sample_size=16)
+SMALL_O = dict(block_out_channels=(320, 640), level_has_attn=(True, False), layers_per_block=1, n_heads=8,
+               cross_dim=768, sample_size=16)
+STEPS = 20            # t = 951, 901, 851, 801 fall in the 780..1000 window
+
+
+class Tapes:
+    """Per-prompt pre-generated noise, served in draw order; independent cursors for oracle and engine."""
+
+    def __init__(self, n_prompts, shape, n_draws, seed):
+        g = torch.Generator().manual_seed(seed)
+        self.data = [torch.randn((n_draws,) + tuple(shape), generator=g) for _ in range(n_prompts)]
+        self.cur = [0] * n_prompts
+
+    def __call__(self, p, shape):
+        z = self.data[p][self.cur[p]].reshape(shape)
+        self.cur[p] += 1
+        return z.clone()
+
+
+def rel_l2(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / b.norm())
+
+
+@pytest.fixture(scope="module")
+def world():
+    u = UNet2DConditionModel(text_len=77, **SMALL)
+    sd = u.synthetic_state_dict(11)
+    u.load_state_dict(sd)
+    g = torch.Generator().manual_seed(2)
+    P = 3
+    E = torch.randn(2 * P, 77, 768, generator=g)
+    refs = orp.channel_normalise(torch.randn(24, 4, 16, 16, generator=g))
+    return u, sd, E, refs, P
+
+
+def make_proc(mod, refs, tmp_path, **params):
+    path = str(tmp_path / f"pr_{abs(hash(str(params))) % 10**9}.pt")
+    torch.save(refs, path)
+    return mod.get_repellency_method("kernel_fast", torch.zeros(1, device="cuda"), None, None, 50, 1000, 0.00085, 0.012,
+                                     n_embed=4, proj_ref_path=path, cache_proj_ref=True, **params)
+
+
+def run_oracle(sd, E, refs, P, tapes, sched, variant, repel):
+    unet = OracleUNet(sd, SMALL_O, act_dtype=torch.bfloat16)
+    outs, draws = [], 0
+    for p in range(P):
+        pair = torch.stack([E[p], E[P + p]])
+        lat, st = opipe.denoise_one(unet, sched(), pair, p, tapes, num_inference_steps=STEPS, repel=repel,
+                                    variant=variant)
+        outs.append(lat)
+        draws += st["renoise_draws"]
+    return torch.cat(outs), draws
+
+
+@pytest.mark.parametrize("mode", ["ddpm_threshold_time", "ddim_threshold_time", "ddpm_time_fast", "ddpm_norepel"])
+def test_loop_matches_oracle(world, tmp_path, mode):
+    u, sd, E, refs, P = world
+    shape = (1, 4, 16, 16)
+    sched_o, sched_p = (osch.DDIM, DDIMScheduler) if mode.startswith("ddim") else (osch.DDPM, DDPMScheduler)
+    if mode.endswith("threshold_time"):
+        # gate chosen between the denominators the prompts actually produce, so both branches are taken
+        probe = Tapes(P, shape, 3 * STEPS + 4, seed=5)
+        dens = []
+        unet = OracleUNet(sd, SMALL_O, act_dtype=torch.bfloat16)
+        for p in range(P):
+            s = sched_o(); s.set_timesteps(STEPS)
+            lat = probe(p, shape)
+            out = unet(torch.cat([lat] * 2), 951.0, torch.stack([E[p], E[P + p]]))
+            eps = out[0:1] + 7.5 * (out[1:2] - out[0:1])
+            x0 = s.step(eps, 951, lat, generator=torch.Generator().manual_seed(0)).pred_original_sample
+            _, den, _ = orp.kernel_fast_score(x0, refs, 3.15, 1e-8)
+            dens.append(float(den))
+        srt = sorted(dens)
+        gate = 0.5 * (srt[0] + srt[1]) if srt[1] - srt[0] > 1e-3 * srt[1] else srt[0] * 0.9
+        params = dict(sigma=3.15, scale=0.33, beta_threshold=gate + 1.6, beta_threshold_margin=1.6)
+        repel_o = dict(flavour="threshold", proj_refs=refs, **params)
+        proc, variant = make_proc(thr, refs, tmp_path, **params), "threshold_time"
+    elif mode == "ddpm_time_fast":
+        params = dict(scale=0.33)
+        repel_o = dict(flavour="fast", proj_refs=refs, **params)
+        proc, variant = make_proc(fast, refs, tmp_path, **params), "time"
+    else:
+        repel_o, proc, variant = None, None, "threshold_time"
+
+    t_o = Tapes(P, shape, 3 * STEPS + 4, seed=5)
+    ref, draws_o = run_oracle(sd, E, refs, P, t_o, sched_o, variant, repel_o)
+    t_p = Tapes(P, shape, 3 * STEPS + 4, seed=5)
+    pipe = SafeDenoiserPipeline(u, sched_p(), variant=variant)
+    lat = pipe(prompt_embeddings=E.cuda(), num_inference_steps=STEPS, guidance_scale=7.5, repellency_processor=proc,
+               noise_fn=t_p, return_latents=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(lat).all()
+    assert t_p.cur == t_o.cur, (t_p.cur, t_o.cur)                      # identical draw order per prompt
+    assert pipe.last_stats["renoise_draws"] == draws_o
+    errs = [rel_l2(lat[p:p + 1], ref[p:p + 1]) for p in range(P)]
+    print(f"{mode}: renoise draws {draws_o}, per-prompt rel L2 {['%.2e' % e for e in errs]}")
+    assert max(errs) <= 3e-2, errs
+    if mode == "ddpm_threshold_time":
+        assert 0 < draws_o < 4 * P                                     # both gate outcomes occurred
+
+
+def test_device_generators_are_per_prompt(world):
+    """With real generators: prompt p's result does not depend on which other prompts share the batch."""
+    u, sd, E, refs, P = world
+    gens = lambda idx: [torch.Generator(device="cuda").manual_seed(1000 + i) for i in idx]
+    pipe = SafeDenoiserPipeline(u, DDPMScheduler(), variant="threshold_time")
+    full = pipe(prompt_embeddings=E.cuda(), num_inference_steps=5, generator=gens(range(P)))
+    sel = [2]
+    Esel = torch.cat([E[:P][sel], E[P:][sel]])
+    one = pipe(prompt_embeddings=Esel.cuda(), num_inference_steps=5, generator=gens(sel))
+    assert rel_l2(one, full[2:3]) <= 1e-6
+    with pytest.raises(NotImplementedError):
+        pipe(prompt="a photo", num_inference_steps=5)

@@ -79,9 +79,9 @@ def test_renoise_select_is_per_prompt():
     flags = torch.tensor([1, 0, 0, 1, 1, 0], dtype=torch.int32)
     sa, s1 = 0.3, 0.95
     exp = torch.where(flags.bool()[:, None], sa * x0r + s1 * z, lat)
-    lg = lat.clone().cuda()
-    _lib.check(sda.lib().sdn_renoise_select(lg.data_ptr(), x0r.cuda().data_ptr(), z.cuda().data_ptr(),
-                                            flags.cuda().data_ptr(), P, D, sa, s1, _lib.stream_ptr()), "renoise")
+    lg, xg, zg, fg = lat.clone().cuda(), x0r.cuda(), z.cuda(), flags.cuda()     # keep the device tensors alive
+    _lib.check(sda.lib().sdn_renoise_select(lg.data_ptr(), xg.data_ptr(), zg.data_ptr(), fg.data_ptr(), P, D, sa, s1,
+                                            _lib.stream_ptr()), "renoise")
     close(lg, exp)
 
 
@@ -104,6 +104,7 @@ def test_flow_kernels():
                                     _lib.stream_ptr()), "endpoints")
     close(x0, x - s * v); close(x1, x + (1 - s) * v)
     x0r = (x0 * 0.5).contiguous()
-    _lib.check(L.sdn_flow_renoise(x0r.data_ptr(), x1.data_ptr(), z.cuda().data_ptr(), xg.numel(), sn, out.data_ptr(),
+    zg = z.cuda()
+    _lib.check(L.sdn_flow_renoise(x0r.data_ptr(), x1.data_ptr(), zg.data_ptr(), xg.numel(), sn, out.data_ptr(),
                                   _lib.stream_ptr()), "renoise")
     close(out, exp, rt=1e-5, at=1e-5)

@@ -27,7 +27,7 @@ def gemm(a, w, *, bias=None, rowbias=None, residual=None, a2=None, conv=None, ac
     d.M, d.N, d.K, d.act, d.out_kind, d.n_valid = M, N, K, act, out_kind, n_valid
     d.rows_per_batch = rows_per_batch
     if rowbias is not None:
-        d.ld_rowbias = rowbias.shape[1]
+        d.ld_rowbias = rowbias.stride(0)
     nv = n_valid or N
     if out_kind == 0:
         out = torch.empty((M, N // 2 if act == 2 else nv), dtype=BF, device=a.device)
