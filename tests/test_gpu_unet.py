@@ -1,9 +1,12 @@
 """Whole-network parity: libsdn's UNet launch plan vs the CPU oracle on the same synthetic weights and inputs.
 
-Two comparisons, tolerances stated here:
-  * vs the oracle run with bf16 storage emulation (same rounding points as the engine): relative L2 <= 1.5e-2.
-    The residue is accumulation order + the flash kernel's bf16 P (not emulable), amplified through ~60 layers.
-  * vs the pure-fp32 oracle: relative L2 <= 5e-2 (what bf16 storage itself costs; reported, loose bound).
+Tolerance (measured, then bounded with 2x headroom): bf16 storage of activations costs ~1.1e-2 relative L2 on this
+network all by itself -- the CPU oracle with bf16 storage emulation differs from the pure-fp32 oracle by 1.13e-2
+(fp16 emulation: 1.4e-3), because one-ulp rounding flips decorrelate through ~60 normalised layers.  Two bf16
+executions with different accumulation order therefore agree only to that level, so:
+  * vs the oracle with bf16 storage emulation (same rounding points as the engine): relative L2 <= 2.5e-2;
+  * vs the pure-fp32 oracle: relative L2 <= 2.5e-2.
+Operator-level tests (test_gpu_ops.py) carry the tight per-kernel bounds (one bf16 rounding of the output).
 """
 import pytest
 import torch
@@ -40,7 +43,7 @@ def test_small_unet_matches_oracle(batch):
     ref_32 = OracleUNet(sd, SMALL_O, act_dtype=None)(x, 781.0, e)
     r1, r2 = rel_l2(y, ref_bf), rel_l2(y, ref_32)
     print(f"small unet B={batch}: rel L2 vs bf16-emulating oracle {r1:.3e}, vs fp32 oracle {r2:.3e}")
-    assert r1 <= 1.5e-2 and r2 <= 5e-2
+    assert r1 <= 2.5e-2 and r2 <= 2.5e-2
     # batch rows are independent: sample 0 alone gives the same answer
     y0 = u(x[:1].cuda(), 781.0, encoder_hidden_states=e[:1].cuda()).sample
     torch.testing.assert_close(y0, y[:1], rtol=0, atol=0)
@@ -59,4 +62,4 @@ def test_full_sd14_unet_matches_oracle():
     ref_bf = OracleUNet(sd, None, act_dtype=torch.bfloat16)(x, 981.0, e)
     r1 = rel_l2(y, ref_bf)
     print(f"full SD-v1.4 unet: rel L2 vs bf16-emulating oracle {r1:.3e}; |y| rms {float(y.pow(2).mean().sqrt()):.3f}")
-    assert r1 <= 1.5e-2
+    assert r1 <= 2.5e-2
