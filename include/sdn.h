@@ -185,6 +185,9 @@ typedef struct sdn_gemm_desc {
  * (models/transformer_2d.py:810-858), Attention to_q/k/v/out, FeedForward GEGLU (models/transformer_2d.py:335-355). */
 int sdn_gemm_bf16(const sdn_gemm_desc* d_host, const void* a, const void* a2, const void* w,
                   const float* bias, const float* rowbias, const void* residual, void* out, void* stream);
+/* Same operator with IEEE fp16 storage (the reference's SD-v3 dtype; 8x tighter parity than bf16). */
+int sdn_gemm_f16(const sdn_gemm_desc* d_host, const void* a, const void* a2, const void* w,
+                 const float* bias, const float* rowbias, const void* residual, void* out, void* stream);
 
 /* GroupNorm (+ optional SiLU) over an NHWC bf16 map, optionally over the channel-concat of two maps
  * (x [B,HW,C1] ++ x2 [B,HW,C2]) written as ONE normalised map [B,HW,C1+C2].
@@ -207,6 +210,9 @@ int sdn_layernorm_bf16(const void* x, int64_t rows, int32_t c, float eps, const 
 int sdn_attention_bf16(const void* q, const void* k, const void* v, void* out, int32_t batch, int32_t heads,
                        int32_t nq, int32_t nk, int32_t head_dim, int32_t ldq, int32_t ldk, int32_t ldv,
                        int32_t ldo, float scale, void* stream);
+int sdn_attention_f16(const void* q, const void* k, const void* v, void* out, int32_t batch, int32_t heads,
+                      int32_t nq, int32_t nk, int32_t head_dim, int32_t ldq, int32_t ldk, int32_t ldv,
+                      int32_t ldo, float scale, void* stream);
 
 /* conv_in: 3x3 conv of the fp32 NCHW latent [B,Cin<=16,H,W] into an NHWC bf16 map [B,H,W,Cout]
  * (models/unet.py:840).  w is [Cout][3][3][Cin] bf16, bias f32. */

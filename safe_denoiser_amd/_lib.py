@@ -73,10 +73,13 @@ SIGNATURES = {
     "sdn_flow_endpoints": (C.c_int, [_vp, _vp, _i64, _f32, _vp, _vp, _vp]),
     "sdn_flow_renoise": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp, _vp]),
     "sdn_gemm_bf16": (C.c_int, [C.POINTER(GemmDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sdn_gemm_f16": (C.c_int, [C.POINTER(GemmDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sdn_groupnorm_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "sdn_layernorm_bf16": (C.c_int, [_vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp]),
     "sdn_attention_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32,
                                      _vp]),
+    "sdn_attention_f16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32,
+                                    _vp]),
     "sdn_conv_in_bf16": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "sdn_timestep_embed_bf16": (C.c_int, [_f32, _i32, _i32, _vp, _vp]),
     "sdn_unet_create": (C.c_int, [C.POINTER(UnetConfig), C.POINTER(_vp)]),

@@ -1,21 +1,27 @@
-// Fused attention forward (row U6): softmax(Q K^T * scale) V, flash-style, bf16 in / fp32 accumulate,
-// v_mfma_f32_32x32x16_bf16.  Head dims 40/80/160 (SD-v1.4: 8 heads at C=320/640/1280) and 64 (MMDiT).
+// Fused attention forward (row U6): softmax(Q K^T * scale) V, flash-style, 16-bit in / fp32 accumulate,
+// v_mfma_f32_32x32x16.  Head dims 40/80/160 (SD-v1.4: 8 heads at C=320/640/1280) and 64 (MMDiT).
 //
 // Orientation (CDNA4-specific, see the guide's "accumulator tile as the next MFMA's operand"):
 //   S^T = K . Q^T      A = K rows from LDS (ds_read_b128), B = Q rows held in registers for the whole kernel
 //                      -> a lane owns ONE query column (lane & 31) and 16 keys per 32-key block in registers,
-//                         so the softmax max/sum are per-lane loops + one cross-half shuffle;
-//   O^T += V^T . P^T   B = the S^T accumulator itself, converted to bf16 in registers (no LDS round trip),
+//                         so the softmax max is a per-lane loop + one v_permlane32_swap;
+//   O^T += V^T . P^T   B = the S^T accumulator itself, converted to 16 bit in registers (no LDS round trip),
 //                      A = V^T read from the row-major V tile with ds_read_b64_tr_b16 (hardware transpose).
-// The running max / sum and the O^T rescale are per-lane scalars because the query sits on the lane.
-// Head dim is zero-padded inside LDS/registers only (40 -> 48 for QK^T, 64 for PV); HBM tensors stay packed
-// [B, N, heads*d], i.e. the NHWC token matrix the projections write.
+// Small head dims make this kernel VALU-bound (the softmax costs the same per score whatever d is), so the
+// per-score instruction count is what is optimised:
+//   * p = v_exp_f32(fma(s, c, -m c))                      2 VALU per score (scale folded into the exponent);
+//   * the row sum comes out of the MFMA: the zero padding of the V tile (40 -> 64, 80 -> 96 columns) holds a
+//     column of ones, so row `HD` of O^T accumulates sum_k p -- no adds, and it is rescaled with O for free;
+//   * O is rescaled only when some lane's running max moved (wave-uniform skip);
+//   * cross-half max via v_permlane32_swap instead of an LDS permute.
+// K/V tiles are double-buffered in LDS through registers: the global loads of tile t+1 are issued before the
+// MFMAs of tile t and written after them (one barrier per tile).  Head dim is zero-padded inside LDS only; HBM
+// tensors stay packed [B, N, heads*d], i.e. the NHWC token matrix the projections write.
 #include "sdn_common.h"
 #include "sdn_ops.h"
 
-namespace {
+namespace sdn_attn_detail {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -28,40 +34,101 @@ struct AttnArgs {
   const unsigned short* q; const unsigned short* k; const unsigned short* v; unsigned short* out;
   int nq, nk, ldq, ldk, ldv, ldo;
   float c;                   // scale * log2(e)
+  int heads, nqb, npairs;    // q-blocks per (batch, head) pair; number of pairs
 };
 
-__device__ __forceinline__ unsigned pack2(float lo, float hi) {
-  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-  bf16x2 p = {(__bf16)lo, (__bf16)hi};
-  return *reinterpret_cast<unsigned*>(&p);
-}
-
-template <int HD>
+template <typename T, int HD>
 __global__ void __launch_bounds__(THREADS)
 k_attn(const AttnArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
   constexpr int KQ = (HD + 15) / 16;          // 16-deep k-steps of Q K^T
   constexpr int NDB = (HD + 31) / 32;         // 32-row blocks of O^T
+  constexpr bool ONES = (HD % 32) != 0;       // a free padding column exists -> row sums via MFMA
   constexpr int KSTR = KQ * 32 + 16;          // K tile row stride in bytes (+16 B pad against bank conflicts)
   constexpr int VSTR = NDB * 64 + 16;         // V tile row stride in bytes (multiple of 8 for the tr read)
-  __shared__ __attribute__((aligned(16))) unsigned char smem[KV * KSTR + KV * VSTR];
-  unsigned char* sK = smem;
-  unsigned char* sV = smem + KV * KSTR;
+  constexpr int STAGE = KV * KSTR + KV * VSTR;
+  constexpr int CH = HD / 8;                  // valid 16-B chunks per K / V row
+  constexpr int NLOAD = (2 * KV * CH + THREADS - 1) / THREADS;   // staged chunks per thread per tile
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int head = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * QB + wid * 32;
+  // XCD-aware mapping (1-D grid): workgroups are dealt round-robin over the 8 XCDs, so id % 8 labels the XCD.
+  // All q-blocks of one (batch, head) pair go to ONE XCD: its K/V (N*d*4 B = 655 KB at N=4096, d=40) is then fetched
+  // into that XCD's 4 MiB L2 once and re-read from there by the other q-blocks, instead of thrashing all 8 L2s.
+  int pair, qblk;
+  {
+    const int nqb = a.nqb, npairs = a.npairs, id = blockIdx.x;
+    if ((npairs & 7) == 0) {
+      const int x = id & 7, j = id >> 3;
+      pair = (j / nqb) * 8 + x; qblk = j - (j / nqb) * nqb;
+    } else {
+      pair = id / nqb; qblk = id - pair * nqb;
+    }
+  }
+  const int head = pair % a.heads, b = pair / a.heads;
+  const int q0 = qblk * QB + wid * 32;
   const bool qvalid = q0 < a.nq;
 
+  // ---- one-time LDS init: zero the padding columns, plant the ones column (both stages) ----
+  {
+    const unsigned one16 = T::pack2(1.0f, 0.0f) & 0xffffu;
+    for (int e = tid; e < 2 * KV; e += THREADS) {
+      unsigned char* sK = smem + (e / KV) * STAGE + (e % KV) * KSTR;
+      unsigned char* sV = smem + (e / KV) * STAGE + KV * KSTR + (e % KV) * VSTR;
+      for (int c = CH * 16; c < KQ * 32; c += 4) *reinterpret_cast<unsigned*>(sK + c) = 0u;
+      for (int c = CH * 16; c < NDB * 64; c += 4) *reinterpret_cast<unsigned*>(sV + c) = (ONES && c == CH * 16) ? one16 : 0u;
+    }
+  }
+
   // ---- Q fragments (B operand: lane (r,h) holds Q[q0+r][16s + 8h .. +8)) ----
-  bf16x8 qf[KQ];
+  typename T::v8 qf[KQ];
 #pragma unroll
   for (int s = 0; s < KQ; ++s) {
     const int dc = 16 * s + 8 * h;
     u32x4 v = (u32x4){0u, 0u, 0u, 0u};
     if (qvalid && dc < HD) v = *reinterpret_cast<const u32x4*>(a.q + ((long)b * a.nq + q0 + r) * a.ldq + head * HD + dc);
-    qf[s] = *reinterpret_cast<bf16x8*>(&v);
+    qf[s] = *reinterpret_cast<typename T::v8*>(&v);
   }
+
+  // ---- register-staged K/V tile loads: chunk e -> (matrix, row, 16-B chunk) ----
+  // Loads are UNCONDITIONAL (clamped, always-valid addresses) so hipcc can count them (vmcnt(N)) and keep them in
+  // flight across the MFMAs; rows past nk are zeroed when the registers are written to LDS.
+  u32x4 stg[NLOAD];
+  int ld_row[NLOAD], ld_dst[NLOAD];
+  const unsigned short* ld_src[NLOAD];
+  long ld_stride[NLOAD];
+#pragma unroll
+  for (int i = 0; i < NLOAD; ++i) {
+    int e = tid + i * THREADS;
+    const bool live = e < 2 * KV * CH;
+    if (!live) e = 2 * KV * CH - 1;
+    const int isv = e >= KV * CH;
+    const int e2 = isv ? e - KV * CH : e;
+    const int row = e2 / CH, ch = e2 - row * CH;
+    ld_row[i] = row;
+    ld_dst[i] = live ? (isv ? KV * KSTR + row * VSTR : row * KSTR) + ch * 16 : -1;
+    ld_src[i] = (isv ? a.v + (long)b * a.nk * a.ldv : a.k + (long)b * a.nk * a.ldk) + head * HD + ch * 8;
+    ld_stride[i] = isv ? a.ldv : a.ldk;
+  }
+  auto g_load = [&](int t) {
+    const int k0 = t * KV;
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+      const int krow = min(k0 + ld_row[i], a.nk - 1);
+      stg[i] = *reinterpret_cast<const u32x4*>(ld_src[i] + (long)krow * ld_stride[i]);
+    }
+  };
+  auto s_store = [&](int buf, int t) {
+    const int k0 = t * KV;
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+      if (ld_dst[i] >= 0) {
+        const u32x4 v = (k0 + ld_row[i] < a.nk) ? stg[i] : (u32x4){0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4*>(smem + buf * STAGE + ld_dst[i]) = v;
+      }
+    }
+  };
 
   f32x16 o[NDB];
 #pragma unroll
@@ -74,25 +141,15 @@ k_attn(const AttnArgs a) {
   const int gi = lane & 15, gq = gi >> 2, gp = gi & 3, gcol = 16 * ((lane >> 4) & 1);
 
   const int ntiles = (a.nk + KV - 1) / KV;
+  g_load(0);
+  s_store(0, 0);
+  __syncthreads();
+
   for (int t = 0; t < ntiles; ++t) {
-    const int k0 = t * KV;
-    __syncthreads();
-    // ---- cooperative K / V tile load, zero-filled outside [0,nk) x [0,HD) ----
-    for (int e = tid; e < KV * KQ * 2; e += THREADS) {
-      const int row = e / (KQ * 2), ch = e - row * (KQ * 2);
-      u32x4 v = (u32x4){0u, 0u, 0u, 0u};
-      if (k0 + row < a.nk && ch * 8 < HD)
-        v = *reinterpret_cast<const u32x4*>(a.k + ((long)b * a.nk + k0 + row) * a.ldk + head * HD + ch * 8);
-      *reinterpret_cast<u32x4*>(sK + row * KSTR + ch * 16) = v;
-    }
-    for (int e = tid; e < KV * NDB * 4; e += THREADS) {
-      const int row = e / (NDB * 4), ch = e - row * (NDB * 4);
-      u32x4 v = (u32x4){0u, 0u, 0u, 0u};
-      if (k0 + row < a.nk && ch * 8 < HD)
-        v = *reinterpret_cast<const u32x4*>(a.v + ((long)b * a.nk + k0 + row) * a.ldv + head * HD + ch * 8);
-      *reinterpret_cast<u32x4*>(sV + row * VSTR + ch * 16) = v;
-    }
-    __syncthreads();
+    const int buf = t & 1;
+    const unsigned char* sK = smem + buf * STAGE;
+    const unsigned char* sV = sK + KV * KSTR;
+    if (t + 1 < ntiles) g_load(t + 1);            // in flight during this tile's MFMAs / softmax (uniform branch)
 
     // ---- S^T = K Q^T : two 32-key blocks ----
     f32x16 st[2];
@@ -102,11 +159,12 @@ k_attn(const AttnArgs a) {
       for (int i = 0; i < 16; ++i) st[kb][i] = 0.f;
 #pragma unroll
       for (int s = 0; s < KQ; ++s) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (32 * kb + r) * KSTR + (16 * s + 8 * h) * 2);
-        st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[kb], 0, 0, 0);
+        const typename T::v8 kf = *reinterpret_cast<const typename T::v8*>(sK + (32 * kb + r) * KSTR + (16 * s + 8 * h) * 2);
+        st[kb] = T::mfma32(kf, qf[s], st[kb]);
       }
     }
-    if (k0 + KV > a.nk) {                        // ragged last tile (cross-attention: 77 keys)
+    if ((t + 1) * KV > a.nk) {                    // ragged last tile (cross-attention: 77 keys)
+      const int k0 = t * KV;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -116,30 +174,36 @@ k_attn(const AttnArgs a) {
         }
     }
     // ---- online softmax: the query is on the lane, its 32 keys of this tile are in st[0], st[1] ----
-    float mx = st[0][0];
+    float mx = fmaxf(st[0][0], st[1][0]);
 #pragma unroll
-    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, st[0][i]);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) mx = fmaxf(mx, st[1][i]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    for (int i = 1; i < 16; ++i) mx = fmaxf(fmaxf(mx, st[0][i]), st[1][i]);
+    {
+      const unsigned u = __float_as_uint(mx);
+      const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // both halves of the same query
+      mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = exp2f((m_run - m_new) * a.c);
-    m_run = m_new;
+    const bool moved = m_new != m_run;
     const float mc = m_new * a.c;
-    float ps = 0.f;
+    if (__builtin_amdgcn_ballot_w64(moved) != 0) {                       // wave-uniform: rescale only when needed
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * a.c);
+      if (!ONES) l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
+      m_run = m_new;
+    }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float p = exp2f(fmaf(st[kb][i], a.c, -mc));
-        st[kb][i] = p;
-        ps += p;
-      }
-    l_run = l_run * alpha + ps;
+      for (int i = 0; i < 16; ++i) st[kb][i] = __builtin_amdgcn_exp2f(fmaf(st[kb][i], a.c, -mc));
+    if (!ONES) {
+      float ps = 0.f;
 #pragma unroll
-    for (int d = 0; d < NDB; ++d)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
+      for (int i = 0; i < 16; ++i) ps += st[0][i] + st[1][i];
+      l_run += ps;
+    }
 
     // ---- O^T += V^T P^T ----
 #pragma unroll
@@ -147,25 +211,36 @@ k_attn(const AttnArgs a) {
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         u32x4 pw;
-        pw.x = pack2(st[kb][8 * s2 + 0], st[kb][8 * s2 + 1]);
-        pw.y = pack2(st[kb][8 * s2 + 2], st[kb][8 * s2 + 3]);
-        pw.z = pack2(st[kb][8 * s2 + 4], st[kb][8 * s2 + 5]);
-        pw.w = pack2(st[kb][8 * s2 + 6], st[kb][8 * s2 + 7]);
-        const bf16x8 pf = *reinterpret_cast<bf16x8*>(&pw);
+        pw.x = T::pack2(st[kb][8 * s2 + 0], st[kb][8 * s2 + 1]);
+        pw.y = T::pack2(st[kb][8 * s2 + 2], st[kb][8 * s2 + 3]);
+        pw.z = T::pack2(st[kb][8 * s2 + 4], st[kb][8 * s2 + 5]);
+        pw.w = T::pack2(st[kb][8 * s2 + 6], st[kb][8 * s2 + 7]);
+        const typename T::v8 pf = *reinterpret_cast<typename T::v8*>(&pw);
         const int keyb = 32 * kb + 16 * s2 + 4 * h + gq;
 #pragma unroll
         for (int d = 0; d < NDB; ++d) {
           const unsigned char* pa = sV + keyb * VSTR + (32 * d + gcol + 4 * gp) * 2;
-          union { s16x4 hlf[2]; bf16x8 full; } vf;
+          union { s16x4 hlf[2]; typename T::v8 full; } vf;
           vf.hlf[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pa));
           vf.hlf[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pa + 8 * VSTR));
-          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.full, pf, o[d], 0, 0, 0);
+          o[d] = T::mfma32(vf.full, pf, o[d]);
         }
       }
+
+    if (t + 1 < ntiles) s_store(buf ^ 1, t + 1);  // the other stage: nobody reads it during this iteration
+    __syncthreads();
   }
 
-  // ---- epilogue: normalise by the row sum (both lane halves hold partial sums of the same query) ----
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  // ---- epilogue: normalise by the row sum ----
+  float l_tot;
+  if (ONES) {
+    constexpr int row = HD % 32;                  // row of the last O^T block that accumulated sum_k p
+    constexpr int ri = (row >> 3) * 4 + (row & 3);
+    static_assert(((row >> 2) & 1) == 0, "ones row must live in lane half 0");
+    l_tot = __shfl(o[NDB - 1][ri], r, 64);        // lane r (half 0) holds it for query r
+  } else {
+    l_tot = l_run + __shfl_xor(l_run, 32, 64);    // both halves hold partial sums of the same query
+  }
   const float inv = 1.f / l_tot;
   if (qvalid) {
     unsigned short* orow = a.out + ((long)b * a.nq + q0 + r) * a.ldo + head * HD;
@@ -176,25 +251,24 @@ k_attn(const AttnArgs a) {
         const int dc = 32 * d + 8 * tq + 4 * h;
         if (dc < HD) {
           uint2 pk;
-          pk.x = pack2(o[d][4 * tq + 0] * inv, o[d][4 * tq + 1] * inv);
-          pk.y = pack2(o[d][4 * tq + 2] * inv, o[d][4 * tq + 3] * inv);
+          pk.x = T::pack2(o[d][4 * tq + 0] * inv, o[d][4 * tq + 1] * inv);
+          pk.y = T::pack2(o[d][4 * tq + 2] * inv, o[d][4 * tq + 3] * inv);
           *reinterpret_cast<uint2*>(orow + dc) = pk;
         }
       }
   }
+#endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int HD>
+template <typename T, int HD>
 int launch(const AttnArgs& a, int batch, int heads, hipStream_t st) {
-  hipLaunchKernelGGL((k_attn<HD>), dim3((a.nq + QB - 1) / QB, heads, batch), dim3(THREADS), 0, st, a);
+  hipLaunchKernelGGL((k_attn<T, HD>), dim3(a.nqb * a.npairs), dim3(THREADS), 0, st, a);
   return sdn_launch_status();
 }
 
-}  // namespace
-
-extern "C" int sdn_attention_bf16(const void* q, const void* k, const void* v, void* out, int32_t batch,
-                                  int32_t heads, int32_t nq, int32_t nk, int32_t head_dim, int32_t ldq,
-                                  int32_t ldk, int32_t ldv, int32_t ldo, float scale, void* stream) {
+template <typename T>
+int run(const void* q, const void* k, const void* v, void* out, int32_t batch, int32_t heads, int32_t nq, int32_t nk,
+        int32_t head_dim, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo, float scale, void* stream) {
   if (!q || !k || !v || !out || batch < 0 || heads <= 0 || nq <= 0 || nk <= 0) return SDN_E_INVALID;
   if ((nq & 31) || (ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3)) return SDN_E_INVALID;
   if (ldq < heads * head_dim || ldk < heads * head_dim || ldv < heads * head_dim || ldo < heads * head_dim)
@@ -203,13 +277,26 @@ extern "C" int sdn_attention_bf16(const void* q, const void* k, const void* v, v
   if (!al(q, 16) || !al(k, 16) || !al(v, 16) || !al(out, 8)) return SDN_E_INVALID;
   if (batch == 0) return SDN_OK;
   AttnArgs a{(const unsigned short*)q, (const unsigned short*)k, (const unsigned short*)v, (unsigned short*)out,
-             nq, nk, ldq, ldk, ldv, ldo, scale * 1.4426950408889634f};
+             nq, nk, ldq, ldk, ldv, ldo, scale * 1.4426950408889634f, heads, (nq + QB - 1) / QB, batch * heads};
   hipStream_t st = (hipStream_t)stream;
   switch (head_dim) {
-    case 40: return launch<40>(a, batch, heads, st);
-    case 64: return launch<64>(a, batch, heads, st);
-    case 80: return launch<80>(a, batch, heads, st);
-    case 160: return launch<160>(a, batch, heads, st);
+    case 40: return launch<T, 40>(a, batch, heads, st);
+    case 64: return launch<T, 64>(a, batch, heads, st);
+    case 80: return launch<T, 80>(a, batch, heads, st);
+    case 160: return launch<T, 160>(a, batch, heads, st);
     default: return SDN_E_INVALID;
   }
+}
+
+}  // namespace sdn_attn_detail
+
+extern "C" int sdn_attention_bf16(const void* q, const void* k, const void* v, void* out, int32_t batch,
+                                  int32_t heads, int32_t nq, int32_t nk, int32_t head_dim, int32_t ldq,
+                                  int32_t ldk, int32_t ldv, int32_t ldo, float scale, void* stream) {
+  return sdn_attn_detail::run<SdnBF16>(q, k, v, out, batch, heads, nq, nk, head_dim, ldq, ldk, ldv, ldo, scale, stream);
+}
+extern "C" int sdn_attention_f16(const void* q, const void* k, const void* v, void* out, int32_t batch,
+                                 int32_t heads, int32_t nq, int32_t nk, int32_t head_dim, int32_t ldq,
+                                 int32_t ldk, int32_t ldv, int32_t ldo, float scale, void* stream) {
+  return sdn_attn_detail::run<SdnF16>(q, k, v, out, batch, heads, nq, nk, head_dim, ldq, ldk, ldv, ldo, scale, stream);
 }

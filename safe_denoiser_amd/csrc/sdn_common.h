@@ -35,3 +35,45 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   for (int i = 0; i < NW; ++i) t += red[i];
   return t;
 }
+
+// ---- 16-bit storage types (bf16 = BASELINE's dtype; f16 = the reference's SD-v3 dtype / tight-parity mode) ----
+typedef __attribute__((ext_vector_type(8))) __bf16 sdn_bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 sdn_f16x8;
+typedef __attribute__((ext_vector_type(4))) float sdn_f32x4;
+typedef __attribute__((ext_vector_type(16))) float sdn_f32x16;
+
+struct SdnBF16 {
+  typedef sdn_bf16x8 v8;
+  static constexpr int kDtype = 0;
+  static __device__ __forceinline__ float to_f(unsigned v16) { return __uint_as_float(v16 << 16); }
+  static __device__ __forceinline__ unsigned pack2(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 v2;
+    v2 p = {(__bf16)lo, (__bf16)hi};                      // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+    return *reinterpret_cast<unsigned*>(&p);
+  }
+  static __device__ __forceinline__ sdn_f32x4 mfma16(v8 a, v8 b, sdn_f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ sdn_f32x16 mfma32(v8 a, v8 b, sdn_f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+struct SdnF16 {
+  typedef sdn_f16x8 v8;
+  static constexpr int kDtype = 1;
+  static __device__ __forceinline__ float to_f(unsigned v16) {
+    unsigned short s = (unsigned short)v16;
+    return (float)(*reinterpret_cast<_Float16*>(&s));
+  }
+  static __device__ __forceinline__ unsigned pack2(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 v2;
+    v2 p = {(_Float16)lo, (_Float16)hi};                  // v_cvt_f16_f32 x2 (RNE) + pack
+    return *reinterpret_cast<unsigned*>(&p);
+  }
+  static __device__ __forceinline__ sdn_f32x4 mfma16(v8 a, v8 b, sdn_f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ sdn_f32x16 mfma32(v8 a, v8 b, sdn_f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};

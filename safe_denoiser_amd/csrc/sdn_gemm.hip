@@ -15,10 +15,12 @@
 // Pipeline: register-staged double buffer (global loads for tile k+1 issued before the MFMAs of tile k, LDS
 // write after them; one barrier per k-tile).  Zero padding of the conv halo and of the M tail is done by
 // predicated loads (zeros), so no padded copies of the activations exist in HBM.
+#include <stdlib.h>
+
 #include "sdn_common.h"
 #include "sdn_ops.h"
 
-namespace {
+namespace sdn_gemm_detail {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -33,6 +35,7 @@ struct GemmArgs {
   int a_mode, Hs, Ws, Cin, Ho, Wo, stride, upsample;
   int act, out_kind, rows_per_batch, ld_rowbias, n_valid, ldc;
   int tiles_m, tiles_n;
+  int dbg;                   // timing-only ablations (tools/bench_gemm.py): 1 = no global stores, 2 = DMA only for k-tile 0
 };
 
 __device__ __forceinline__ float bf2f(unsigned short v) { return __uint_as_float((unsigned)v << 16); }
@@ -237,6 +240,249 @@ k_gemm(const GemmArgs g) {
   }
 }
 
+
+// ================================================================================================
+// v2: same tile, same LDS image, same epilogue -- but both operands are staged by LDS-DMA
+// (buffer_load_dwordx4 ... lds): no staging VGPRs, no ds_write pass, and the conv halo / M tail is zero-filled
+// by the buffer descriptor's range check (out-of-range voffset -> the DMA writes zeros).
+// One wave-instruction writes 1 KiB = 8 rows x 128 B of the tile linearly, so the chunk ^ (row & 7) swizzle
+// is applied to the per-lane SOURCE address (lane (row = l>>3, slot = l&7) fetches logical chunk slot ^ row&7)
+// and to the fragment reads -- never to the LDS destination (guide, rule 21).
+// ================================================================================================
+#if defined(__HIP_DEVICE_COMPILE__)     // buffer-resource builtins exist only in the device pass
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+#endif
+
+template <typename T, int NREP>
+__global__ void __launch_bounds__(THREADS, 2)
+k_gemm_dma(const GemmArgs g) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BN = 32 * NREP;
+  constexpr int A_PIECES = BM / 8 / 4;                       // 1-KiB pieces per wave: 4
+  constexpr int W_PIECES = (BN / 8 + 3) / 4;                 // 5 @160, 4 @128, 2 @64, 1 @32
+  constexpr int STAGE = (BM + BN) * 128;
+  constexpr unsigned OOB = 0x80000000u;                      // > any tensor size handled here
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+
+  const int nt = g.tiles_m * g.tiles_n;
+  int tile;
+  {
+    const int bid = blockIdx.x, q = nt >> 3, r = nt & 7, x = bid & 7;
+    tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  }
+  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: LDS-DMA bases go to M0, no waterfall
+  const int wm = wid >> 1, wn = wid & 1;
+  const int lrow = lane >> 3;                                // row inside a piece
+  const int lchunk = (lane & 7) ^ lrow;                      // logical 16-B chunk this lane fetches
+
+  // ---- per-lane source rows (fixed across k) ----
+  unsigned a_off[A_PIECES];                                  // PLAIN: byte offset of the row start (or OOB)
+  int a_b[A_PIECES], a_y[A_PIECES], a_x[A_PIECES];
+  bool a_ok[A_PIECES];
+#pragma unroll
+  for (int i = 0; i < A_PIECES; ++i) {
+    const int m = m0 + (wid * A_PIECES + i) * 8 + lrow;
+    a_ok[i] = m < g.M;
+    const int mm = a_ok[i] ? m : 0;
+    if (g.a_mode == 1) {
+      const int hw = g.Ho * g.Wo;
+      const int b = mm / hw, p = mm - b * hw;
+      a_b[i] = b; a_y[i] = p / g.Wo; a_x[i] = p - a_y[i] * g.Wo; a_off[i] = 0;
+    } else {
+      a_b[i] = a_y[i] = a_x[i] = 0; a_off[i] = 0;
+    }
+  }
+  unsigned w_off[W_PIECES];
+  bool w_ok[W_PIECES];
+#pragma unroll
+  for (int i = 0; i < W_PIECES; ++i) {
+    const int piece = wid * W_PIECES + i;
+    w_ok[i] = piece * 8 < BN;
+    w_off[i] = (unsigned)(((long)(n0 + piece * 8 + lrow) * g.K + lchunk * 8) * 2);
+  }
+  const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(g.w, (unsigned)((long)g.N * g.K * 2));
+  const long a_rows = g.a_mode == 1 ? (long)(g.M / (g.Ho * g.Wo)) * g.Hs * g.Ws : (long)g.M;
+  const int ld1 = g.a_mode == 1 ? g.Cin : g.K1, ld2 = g.K - g.K1;
+  const __amdgpu_buffer_rsrc_t rs_a1 = make_rsrc(g.a, (unsigned)(a_rows * ld1 * 2));
+  const __amdgpu_buffer_rsrc_t rs_a2 = make_rsrc(g.a2 ? g.a2 : g.a, (unsigned)(g.a2 ? a_rows * ld2 * 2 : 0));
+
+  auto issue = [&](int kt, int buf) {
+    const int k0 = kt * BK;
+    unsigned char* sa = smem + buf * STAGE;
+    unsigned char* sw = sa + BM * 128;
+    if (g.a_mode == 1) {
+      const int tap = k0 / g.Cin, c0 = k0 - tap * g.Cin;
+      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+      const int Hi = g.upsample ? g.Hs * 2 : g.Hs, Wi = g.upsample ? g.Ws * 2 : g.Ws;
+#pragma unroll
+      for (int i = 0; i < A_PIECES; ++i) {
+        int iy = a_y[i] * g.stride + dy, ix = a_x[i] * g.stride + dx;
+        const bool ok = a_ok[i] && iy >= 0 && iy < Hi && ix >= 0 && ix < Wi;
+        if (g.upsample) { iy >>= 1; ix >>= 1; }
+        const unsigned off = ok ? (unsigned)(((((long)a_b[i] * g.Hs + iy) * g.Ws + ix) * g.Cin + c0 + lchunk * 8) * 2) : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a1, (lds_ptr_t)(sa + (wid * A_PIECES + i) * 1024), 16, off, 0, 0, 0);
+      }
+    } else {
+      const bool second = k0 >= g.K1;
+      const int ld = second ? ld2 : ld1, kk = second ? k0 - g.K1 : k0;
+#pragma unroll
+      for (int i = 0; i < A_PIECES; ++i) {
+        const int m = m0 + (wid * A_PIECES + i) * 8 + lrow;
+        const unsigned off = a_ok[i] ? (unsigned)(((long)m * ld + kk + lchunk * 8) * 2) : OOB;
+        if (second)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a2, (lds_ptr_t)(sa + (wid * A_PIECES + i) * 1024), 16, off, 0, 0, 0);
+        else
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a1, (lds_ptr_t)(sa + (wid * A_PIECES + i) * 1024), 16, off, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < W_PIECES; ++i) {
+      if (w_ok[i])
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(sw + (wid * W_PIECES + i) * 1024), 16,
+                                                 w_off[i] + (unsigned)(k0 * 2), 0, 0, 0);
+    }
+  };
+
+  f32x4 acc[4][NREP];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = g.K / BK;
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk && !(g.dbg & 2)) issue(kt + 1, buf ^ 1);
+    const unsigned char* sa = smem + buf * STAGE + (wm * 64) * 128;
+    const unsigned char* sw = smem + buf * STAGE + BM * 128 + (wn * 16 * NREP) * 128;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      typename T::v8 fa[4], fw[NREP];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const typename T::v8*>(sa + lds_off(i * 16 + fr, ks * 4 + fq));
+#pragma unroll
+      for (int j = 0; j < NREP; ++j) fw[j] = *reinterpret_cast<const typename T::v8*>(sw + lds_off(j * 16 + fr, ks * 4 + fq));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) acc[i][j] = T::mfma16(fw[j], fa[i], acc[i][j]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+  // 16-bit outputs are staged through LDS (free after the k loop) so that HBM sees whole 16-byte-per-lane, row-
+  // contiguous stores instead of 8-byte fragments at a row stride (guide T21: "widen the epilogue stores").
+  constexpr int CW = (BN + 8) * 2;                           // staged row stride in bytes (+16 B pad)
+  const bool staged = g.out_kind == 0 && g.n_valid == g.N;
+  const int out_cols = g.act == 2 ? BN / 2 : BN;             // columns this tile contributes to `out`
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ml = wm * 64 + i * 16 + fr;                    // row inside the tile
+    const int m = m0 + ml;
+    const bool row_ok = m < g.M;
+    const int b = (g.rows_per_batch > 0 && row_ok) ? m / g.rows_per_batch : 0;
+    unsigned short* out16 = reinterpret_cast<unsigned short*>(g.out);
+    if (g.act == 2) {
+#pragma unroll
+      for (int j = 0; j + 1 < NREP; j += 2) {
+        const int np = n0 + wn * 16 * NREP + j * 16 + fq * 4;
+        f32x4 hv = acc[i][j], gv = acc[i][j + 1];
+        if (g.bias) {
+          const float4 bh = *reinterpret_cast<const float4*>(g.bias + np);
+          const float4 bg = *reinterpret_cast<const float4*>(g.bias + np + 16);
+          hv[0] += bh.x; hv[1] += bh.y; hv[2] += bh.z; hv[3] += bh.w;
+          gv[0] += bg.x; gv[1] += bg.y; gv[2] += bg.z; gv[3] += bg.w;
+        }
+        uint2 pk;
+        pk.x = T::pack2(hv[0] * gelu_erf(gv[0]), hv[1] * gelu_erf(gv[1]));
+        pk.y = T::pack2(hv[2] * gelu_erf(gv[2]), hv[3] * gelu_erf(gv[3]));
+        const int nl = ((wn * 16 * NREP + j * 16) >> 1) + fq * 4;        // column inside the (half-width) tile
+        *reinterpret_cast<uint2*>(smem + ml * CW + nl * 2) = pk;
+      }
+      continue;
+    }
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) {
+      const int nl = wn * 16 * NREP + j * 16 + fq * 4;
+      const int n = n0 + nl;
+      f32x4 v = acc[i][j];
+      if (g.bias) {
+        const float4 bb = *reinterpret_cast<const float4*>(g.bias + n);
+        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+      }
+      if (g.rowbias && row_ok) {
+        const float4 rb = *reinterpret_cast<const float4*>(g.rowbias + (long)b * g.ld_rowbias + n);
+        v[0] += rb.x; v[1] += rb.y; v[2] += rb.z; v[3] += rb.w;
+      }
+      if (g.residual && row_ok) {
+        const uint2 rr = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(g.residual) + (long)m * g.ldc + n);
+        v[0] += T::to_f(rr.x & 0xffff); v[1] += T::to_f(rr.x >> 16); v[2] += T::to_f(rr.y & 0xffff); v[3] += T::to_f(rr.y >> 16);
+      }
+      if (g.act == 1) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+      if (staged) {
+        uint2 pk; pk.x = T::pack2(v[0], v[1]); pk.y = T::pack2(v[2], v[3]);
+        *reinterpret_cast<uint2*>(smem + ml * CW + nl * 2) = pk;
+      } else if (!row_ok) {
+      } else if (g.out_kind == 0) {
+        for (int e = 0; e < 4; ++e)
+          if (n + e < g.n_valid) out16[(long)m * g.ldc + n + e] = (unsigned short)(T::pack2(v[e], 0.f) & 0xffff);
+      } else if (g.out_kind == 1) {
+        for (int e = 0; e < 4; ++e)
+          if (n + e < g.n_valid) reinterpret_cast<float*>(g.out)[(long)m * g.ldc + n + e] = v[e];
+      } else {
+        const int p = m - b * g.rows_per_batch;
+        for (int e = 0; e < 4; ++e)
+          if (n + e < g.n_valid)
+            reinterpret_cast<float*>(g.out)[((long)b * g.n_valid + n + e) * g.rows_per_batch + p] = v[e];
+      }
+    }
+  }
+  if (staged || g.act == 2) {
+    __syncthreads();
+    const int cpr = out_cols / 8;                            // 16-byte chunks per staged row
+    const int col0 = g.act == 2 ? (n0 >> 1) : n0;
+    unsigned short* out16 = reinterpret_cast<unsigned short*>(g.out);
+    for (int e = tid; e < BM * cpr; e += THREADS) {
+      const int r = e / cpr, c = e - r * cpr;
+      const int m = m0 + r;
+      if (m < g.M && !(g.dbg & 1))
+        *reinterpret_cast<u32x4*>(out16 + (long)m * g.ldc + col0 + c * 8) = *reinterpret_cast<const u32x4*>(smem + r * CW + c * 16);
+    }
+  }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+template <typename T, int NREP>
+int launch_dma(const GemmArgs& ga, hipStream_t st) {
+  const int grid = ga.tiles_m * ga.tiles_n;
+  hipLaunchKernelGGL((k_gemm_dma<T, NREP>), dim3(grid), dim3(THREADS), 0, st, ga);
+  return sdn_launch_status();
+}
+
+template <typename T>
+int dispatch_dma(int nrep, const GemmArgs& g, hipStream_t st) {
+  switch (nrep) {
+    case 5: return launch_dma<T, 5>(g, st);
+    case 4: return launch_dma<T, 4>(g, st);
+    case 2: return launch_dma<T, 2>(g, st);
+    default: return launch_dma<T, 1>(g, st);
+  }
+}
+
 template <int NREP>
 int launch(const GemmArgs& ga, hipStream_t st) {
   const int grid = ga.tiles_m * ga.tiles_n;
@@ -246,7 +492,8 @@ int launch(const GemmArgs& ga, hipStream_t st) {
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-}  // namespace
+}  // namespace sdn_gemm_detail
+using namespace sdn_gemm_detail;
 
 // Picks the widest N tile that divides N (160 for SD-v1.4 widths, 128 for GEGLU / MMDiT widths, 64, 32).
 int sdn_gemm_pick_nrep(int n_padded, int act) {
@@ -258,16 +505,29 @@ int sdn_gemm_pick_nrep(int n_padded, int act) {
   return 0;
 }
 
-extern "C" int sdn_gemm_bf16(const sdn_gemm_desc* d, const void* a, const void* a2, const void* w,
-                             const float* bias, const float* rowbias, const void* residual, void* out,
-                             void* stream) {
+static int g_gemm_variant = 0;
+// Undeclared debug hook for in-process A/B timing (tools/bench_gemm.py): 0 = LDS-DMA kernel, 1 = register-staged v1.
+extern "C" void sdn_debug_set_gemm_variant(int v) { g_gemm_variant = v; }
+
+// Tile choice with the grid in mind: when the widest tile leaves the 256 CUs (x2 resident blocks) underfilled
+// (the 8x8 / 16x16 levels at small batch), fall back to BN = 64 to multiply the number of workgroups.
+static int pick_nrep_for(int M, int N, int act) {
+  int nrep = sdn_gemm_pick_nrep(N, act);
+  if (g_gemm_variant == 2) return nrep;                      // debug: heuristic off
+  const int tiles_m = (M + BM - 1) / BM;
+  if (nrep > 2 && N % 64 == 0 && tiles_m * (N / (32 * nrep)) < 256) nrep = 2;
+  return nrep;
+}
+
+static int sdn_gemm_impl(int dtype, const sdn_gemm_desc* d, const void* a, const void* a2, const void* w,
+                         const float* bias, const float* rowbias, const void* residual, void* out, void* stream) {
   if (!d || !a || !w || !out) return SDN_E_INVALID;
   if (d->M < 0 || d->N <= 0 || d->K <= 0 || (d->K % BK) != 0) return SDN_E_INVALID;
   if (d->M == 0) return SDN_OK;
   const int n_valid = d->n_valid > 0 ? d->n_valid : d->N;
   if (n_valid > d->N) return SDN_E_INVALID;
-  const int nrep = sdn_gemm_pick_nrep(d->N, d->act);
-  if (nrep == 0) return SDN_E_INVALID;
+  if (sdn_gemm_pick_nrep(d->N, d->act) == 0) return SDN_E_INVALID;
+  const int nrep = pick_nrep_for(d->M, d->N, d->act);
   if (!al16(a) || !al16(w) || (a2 && !al16(a2)) || (residual && (reinterpret_cast<uintptr_t>(residual) & 7)) ||
       (reinterpret_cast<uintptr_t>(out) & 7) || (bias && !al16(bias)) || (rowbias && !al16(rowbias)))
     return SDN_E_INVALID;
@@ -297,14 +557,31 @@ extern "C" int sdn_gemm_bf16(const sdn_gemm_desc* d, const void* a, const void* 
   g.act = d->act; g.out_kind = d->out_kind; g.rows_per_batch = d->rows_per_batch; g.ld_rowbias = d->ld_rowbias;
   g.n_valid = n_valid;
   g.ldc = d->ldc > 0 ? d->ldc : (d->act == SDN_ACT_GEGLU ? d->N / 2 : n_valid);
-  if (d->out_kind == SDN_OUT_BF16 && (g.ldc & 3)) return SDN_E_INVALID;
+  if (d->out_kind == SDN_OUT_BF16 && ((g.ldc & 7) || !al16(out))) return SDN_E_INVALID;
   const int bn = 32 * nrep;
   g.tiles_m = (d->M + BM - 1) / BM; g.tiles_n = d->N / bn;
+  g.dbg = g_gemm_variant >= 16 ? (g_gemm_variant >> 4) : 0;
   hipStream_t st = (hipStream_t)stream;
-  switch (nrep) {
-    case 5: return launch<5>(g, st);
-    case 4: return launch<4>(g, st);
-    case 2: return launch<2>(g, st);
-    default: return launch<1>(g, st);
+  // operands must stay below the LDS-DMA out-of-range sentinel (2 GiB per tensor)
+  const long a_rows = d->a_mode == SDN_A_CONV3X3 ? (long)(d->M / (d->Ho * d->Wo)) * d->Hs * d->Ws : (long)d->M;
+  if (a_rows * (long)(d->a_mode == SDN_A_CONV3X3 ? d->Cin : d->K) * 2 >= (1L << 31) || (long)d->N * d->K * 2 >= (1L << 31))
+    return SDN_E_INVALID;
+  if (g_gemm_variant == 1 && dtype == 0) {                           // A/B switch: register-staged v1 (bf16 only)
+    switch (nrep) {
+      case 5: return launch<5>(g, st);
+      case 4: return launch<4>(g, st);
+      case 2: return launch<2>(g, st);
+      default: return launch<1>(g, st);
+    }
   }
+  return dtype == 0 ? dispatch_dma<SdnBF16>(nrep, g, st) : dispatch_dma<SdnF16>(nrep, g, st);
+}
+
+extern "C" int sdn_gemm_bf16(const sdn_gemm_desc* d, const void* a, const void* a2, const void* w, const float* bias,
+                             const float* rowbias, const void* residual, void* out, void* stream) {
+  return sdn_gemm_impl(0, d, a, a2, w, bias, rowbias, residual, out, stream);
+}
+extern "C" int sdn_gemm_f16(const sdn_gemm_desc* d, const void* a, const void* a2, const void* w, const float* bias,
+                            const float* rowbias, const void* residual, void* out, void* stream) {
+  return sdn_gemm_impl(1, d, a, a2, w, bias, rowbias, residual, out, stream);
 }

@@ -171,9 +171,12 @@ k_layernorm(const unsigned short* __restrict__ x, long rows, int C, float eps, c
 __global__ void __launch_bounds__(THREADS)
 k_conv_in(const float* __restrict__ lat, const unsigned short* __restrict__ w, const float* __restrict__ bias,
           int B, int cin, int H, int W, int cout, unsigned short* __restrict__ out) {
-  extern __shared__ float wl[];                   // [cout][9*cin] as f32
-  const int kk = 9 * cin;
-  for (int i = threadIdx.x; i < cout * kk; i += THREADS) wl[i] = bf2f(w[i]);
+  extern __shared__ float wl[];                   // [9*cin][cout] as f32: lanes (consecutive channel chunks) read
+  const int kk = 9 * cin;                         // consecutive addresses -> conflict-free ds_read_b128
+  for (int i = threadIdx.x; i < cout * kk; i += THREADS) {
+    const int co = i / kk, k = i - co * kk;
+    wl[k * cout + co] = bf2f(w[i]);
+  }
   __syncthreads();
   const int cchunks = cout / 8;
   const long total = (long)B * H * W * cchunks;
@@ -190,7 +193,7 @@ k_conv_in(const float* __restrict__ lat, const unsigned short* __restrict__ w, c
       for (int c = 0; c < cin; ++c) {
         const float v = lat[(((long)b * cin + c) * H + iy) * W + ix];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] = fmaf(v, wl[(cc * 8 + k) * kk + tap * cin + c], acc[k]);
+        for (int k = 0; k < 8; ++k) acc[k] = fmaf(v, wl[(tap * cin + c) * cout + cc * 8 + k], acc[k]);
       }
     }
     *reinterpret_cast<u32x4*>(out + pix * cout + cc * 8) = pack8(acc);
