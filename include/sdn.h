@@ -191,7 +191,7 @@ int sdn_gemm_f16(const sdn_gemm_desc* d_host, const void* a, const void* a2, con
 
 /* GroupNorm (+ optional SiLU) over an NHWC bf16 map, optionally over the channel-concat of two maps
  * (x [B,HW,C1] ++ x2 [B,HW,C2]) written as ONE normalised map [B,HW,C1+C2].
- * stats_ws: B*16*groups*2 floats of scratch (deterministic two-level reduction).  Replaces GroupNorm+SiLU of ResnetBlock2D (eps 1e-5) and the
+ * stats_ws: B*129*groups*2 floats of scratch (row-tile partials + final mean/rstd; deterministic reduction).  Replaces GroupNorm+SiLU of ResnetBlock2D (eps 1e-5) and the
  * GroupNorm of Transformer2DModel (eps 1e-6, no SiLU; models/transformer_2d.py:506-512). */
 int sdn_groupnorm_bf16(const void* x, const void* x2, int32_t batch, int32_t hw, int32_t c1, int32_t c2,
                        int32_t groups, float eps, int32_t silu, const float* gamma, const float* beta,

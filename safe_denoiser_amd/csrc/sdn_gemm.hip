@@ -282,21 +282,38 @@ k_gemm_dma(const GemmArgs g) {
   const int lrow = lane >> 3;                                // row inside a piece
   const int lchunk = (lane & 7) ^ lrow;                      // logical 16-B chunk this lane fetches
 
-  // ---- per-lane source rows (fixed across k) ----
-  unsigned a_off[A_PIECES];                                  // PLAIN: byte offset of the row start (or OOB)
-  int a_b[A_PIECES], a_y[A_PIECES], a_x[A_PIECES];
-  bool a_ok[A_PIECES];
+  // ---- per-lane source rows (fixed across k).  All per-k-tile address work is strength-reduced to
+  //      "lane base + wave-uniform delta" (+ a validity bit test for the conv halo) ----
+  unsigned a_base[A_PIECES];        // PLAIN: byte offset of (row, lane chunk) in source 1 (or OOB); CONV: centre pixel
+  unsigned a_base2[A_PIECES];       // PLAIN: same for source 2
+  unsigned a_mask[A_PIECES];        // CONV: bit t = tap t reads inside the (virtual) input map
+  int a_ey[A_PIECES], a_ex[A_PIECES];   // CONV + upsample: parity of the output coordinate
+  const int ld1 = g.a_mode == 1 ? g.Cin : g.K1, ld2 = g.K - g.K1;
 #pragma unroll
   for (int i = 0; i < A_PIECES; ++i) {
     const int m = m0 + (wid * A_PIECES + i) * 8 + lrow;
-    a_ok[i] = m < g.M;
-    const int mm = a_ok[i] ? m : 0;
+    const bool ok = m < g.M;
+    a_base2[i] = OOB; a_mask[i] = 0; a_ey[i] = a_ex[i] = 0;
     if (g.a_mode == 1) {
+      const int mm = ok ? m : 0;
       const int hw = g.Ho * g.Wo;
-      const int b = mm / hw, p = mm - b * hw;
-      a_b[i] = b; a_y[i] = p / g.Wo; a_x[i] = p - a_y[i] * g.Wo; a_off[i] = 0;
+      const int bb = mm / hw, p = mm - bb * hw;
+      const int oy = p / g.Wo, ox = p - oy * g.Wo;
+      const int Hi = g.upsample ? g.Hs * 2 : g.Hs, Wi = g.upsample ? g.Ws * 2 : g.Ws;
+      const int cy = oy * g.stride, cx = ox * g.stride;          // centre in the virtual (upsampled) input
+      unsigned mask = 0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int iy = cy + t / 3 - 1, ix = cx + t % 3 - 1;
+        if (ok && iy >= 0 && iy < Hi && ix >= 0 && ix < Wi) mask |= 1u << t;
+      }
+      a_mask[i] = mask;
+      a_ey[i] = cy & 1; a_ex[i] = cx & 1;
+      const int sy = g.upsample ? cy >> 1 : cy, sx = g.upsample ? cx >> 1 : cx;
+      a_base[i] = (unsigned)((((bb * g.Hs + sy) * g.Ws + sx) * g.Cin + lchunk * 8) * 2);
     } else {
-      a_b[i] = a_y[i] = a_x[i] = 0; a_off[i] = 0;
+      a_base[i] = ok ? (unsigned)(((long)m * ld1 + lchunk * 8) * 2) : OOB;
+      if (g.a2) a_base2[i] = ok ? (unsigned)(((long)m * ld2 + lchunk * 8) * 2) : OOB;
     }
   }
   unsigned w_off[W_PIECES];
@@ -309,45 +326,54 @@ k_gemm_dma(const GemmArgs g) {
   }
   const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(g.w, (unsigned)((long)g.N * g.K * 2));
   const long a_rows = g.a_mode == 1 ? (long)(g.M / (g.Ho * g.Wo)) * g.Hs * g.Ws : (long)g.M;
-  const int ld1 = g.a_mode == 1 ? g.Cin : g.K1, ld2 = g.K - g.K1;
   const __amdgpu_buffer_rsrc_t rs_a1 = make_rsrc(g.a, (unsigned)(a_rows * ld1 * 2));
   const __amdgpu_buffer_rsrc_t rs_a2 = make_rsrc(g.a2 ? g.a2 : g.a, (unsigned)(g.a2 ? a_rows * ld2 * 2 : 0));
 
-  auto issue = [&](int kt, int buf) {
-    const int k0 = kt * BK;
+  // k-tile cursor (issue() is always called for consecutive k-tiles)
+  int cur_k0 = 0, cur_c0 = 0, cur_ty = 0, cur_tx = 0;
+  auto issue = [&](int buf) {
     unsigned char* sa = smem + buf * STAGE;
     unsigned char* sw = sa + BM * 128;
     if (g.a_mode == 1) {
-      const int tap = k0 / g.Cin, c0 = k0 - tap * g.Cin;
-      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-      const int Hi = g.upsample ? g.Hs * 2 : g.Hs, Wi = g.upsample ? g.Ws * 2 : g.Ws;
+      const int dy = cur_ty - 1, dx = cur_tx - 1, tap = cur_ty * 3 + cur_tx;
+      if (!g.upsample) {
+        const int delta = ((dy * g.Ws + dx) * g.Cin + cur_c0) * 2;                    // wave-uniform
 #pragma unroll
-      for (int i = 0; i < A_PIECES; ++i) {
-        int iy = a_y[i] * g.stride + dy, ix = a_x[i] * g.stride + dx;
-        const bool ok = a_ok[i] && iy >= 0 && iy < Hi && ix >= 0 && ix < Wi;
-        if (g.upsample) { iy >>= 1; ix >>= 1; }
-        const unsigned off = ok ? (unsigned)(((((long)a_b[i] * g.Hs + iy) * g.Ws + ix) * g.Cin + c0 + lchunk * 8) * 2) : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a1, (lds_ptr_t)(sa + (wid * A_PIECES + i) * 1024), 16, off, 0, 0, 0);
-      }
-    } else {
-      const bool second = k0 >= g.K1;
-      const int ld = second ? ld2 : ld1, kk = second ? k0 - g.K1 : k0;
-#pragma unroll
-      for (int i = 0; i < A_PIECES; ++i) {
-        const int m = m0 + (wid * A_PIECES + i) * 8 + lrow;
-        const unsigned off = a_ok[i] ? (unsigned)(((long)m * ld + kk + lchunk * 8) * 2) : OOB;
-        if (second)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a2, (lds_ptr_t)(sa + (wid * A_PIECES + i) * 1024), 16, off, 0, 0, 0);
-        else
+        for (int i = 0; i < A_PIECES; ++i) {
+          const unsigned off = ((a_mask[i] >> tap) & 1u) ? a_base[i] + (unsigned)delta : OOB;
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a1, (lds_ptr_t)(sa + (wid * A_PIECES + i) * 1024), 16, off, 0, 0, 0);
+        }
+      } else {                                      // nearest-2x: stored row = (y + dy) >> 1 = (y >> 1) + ((y & 1) + dy) >> 1
+#pragma unroll
+        for (int i = 0; i < A_PIECES; ++i) {
+          const int sy = (a_ey[i] + dy) >> 1, sx = (a_ex[i] + dx) >> 1;
+          const int delta = ((sy * g.Ws + sx) * g.Cin + cur_c0) * 2;
+          const unsigned off = ((a_mask[i] >> tap) & 1u) ? a_base[i] + (unsigned)delta : OOB;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a1, (lds_ptr_t)(sa + (wid * A_PIECES + i) * 1024), 16, off, 0, 0, 0);
+        }
+      }
+      cur_c0 += BK;
+      if (cur_c0 == g.Cin) { cur_c0 = 0; if (++cur_tx == 3) { cur_tx = 0; ++cur_ty; } }
+    } else {
+      if (cur_k0 >= g.K1) {
+        const unsigned kb = (unsigned)((cur_k0 - g.K1) * 2);
+#pragma unroll
+        for (int i = 0; i < A_PIECES; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a2, (lds_ptr_t)(sa + (wid * A_PIECES + i) * 1024), 16, a_base2[i] + kb, 0, 0, 0);
+      } else {
+        const unsigned kb = (unsigned)(cur_k0 * 2);
+#pragma unroll
+        for (int i = 0; i < A_PIECES; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a1, (lds_ptr_t)(sa + (wid * A_PIECES + i) * 1024), 16, a_base[i] + kb, 0, 0, 0);
       }
     }
 #pragma unroll
     for (int i = 0; i < W_PIECES; ++i) {
       if (w_ok[i])
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(sw + (wid * W_PIECES + i) * 1024), 16,
-                                                 w_off[i] + (unsigned)(k0 * 2), 0, 0, 0);
+                                                 w_off[i] + (unsigned)(cur_k0 * 2), 0, 0, 0);
     }
+    cur_k0 += BK;
   };
 
   f32x4 acc[4][NREP];
@@ -357,14 +383,14 @@ k_gemm_dma(const GemmArgs g) {
     for (int j = 0; j < NREP; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nk = g.K / BK;
-  issue(0, 0);
+  issue(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   const int fr = lane & 15, fq = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk && !(g.dbg & 2)) issue(kt + 1, buf ^ 1);
+    if (kt + 1 < nk && !(g.dbg & 2)) issue(buf ^ 1);
     const unsigned char* sa = smem + buf * STAGE + (wm * 64) * 128;
     const unsigned char* sw = smem + buf * STAGE + BM * 128 + (wn * 16 * NREP) * 128;
 #pragma unroll

@@ -7,7 +7,7 @@ namespace {
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 constexpr int THREADS = 256;
-constexpr int GN_MAX_TILES = 16;
+constexpr int GN_MAX_TILES = 128;
 
 __device__ __forceinline__ float bf2f(unsigned v16) { return __uint_as_float(v16 << 16); }
 __device__ __forceinline__ void unpack8(const u32x4 v, float* f) {
@@ -45,12 +45,23 @@ k_gn_stats(const unsigned short* __restrict__ x, const unsigned short* __restric
       float s[8], ss[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
-      for (int r = r_lo + rl; r < r_hi; r += rt) {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(src + ((long)b * hw + r) * ld + cc);
-        float f[8];
-        unpack8(v, f);
+      // 4 rows in flight per thread: the loop is latency-bound otherwise (one dependent 16-B load per iteration)
+      for (int r = r_lo + rl; r < r_hi; r += 4 * rt) {
+        u32x4 v[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { s[e] += f[e]; ss[e] = fmaf(f[e], f[e], ss[e]); }
+        for (int j = 0; j < 4; ++j) {
+          const int rr = min(r + j * rt, r_hi - 1);
+          v[j] = *reinterpret_cast<const u32x4*>(src + ((long)b * hw + rr) * ld + cc);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (r + j * rt < r_hi) {
+            float f[8];
+            unpack8(v[j], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s[e] += f[e]; ss[e] = fmaf(f[e], f[e], ss[e]); }
+          }
+        }
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -73,25 +84,33 @@ k_gn_stats(const unsigned short* __restrict__ x, const unsigned short* __restric
   }
 }
 
+// GroupNorm pass 1b: reduce the row-tile partials in fixed order -> mean / rstd per (sample, group).
+__global__ void k_gn_finalize(const float* __restrict__ partials, int ntiles, int groups, float n, float eps,
+                              float* __restrict__ stats) {
+  const int b = blockIdx.x, gi = threadIdx.x;
+  if (gi >= groups) return;
+  float s = 0.f, ss = 0.f;
+  for (int t = 0; t < ntiles; ++t) {
+    const float* p = partials + (((long)b * ntiles + t) * groups + gi) * 2;
+    s += p[0]; ss += p[1];
+  }
+  const float mean = s / n;
+  const float var = fmaxf(ss / n - mean * mean, 0.f);
+  stats[((long)b * groups + gi) * 2 + 0] = mean;
+  stats[((long)b * groups + gi) * 2 + 1] = rsqrtf(var + eps);
+}
+
 // GroupNorm pass 2: normalise + affine (+SiLU), write the (concatenated) map.
 __global__ void __launch_bounds__(THREADS)
 k_gn_apply(const unsigned short* __restrict__ x, const unsigned short* __restrict__ x2, int hw, int c1, int c2,
-           int groups, int ntiles, int rows_per_block, float eps, int silu, const float* __restrict__ gamma,
-           const float* __restrict__ beta, const float* __restrict__ partials, unsigned short* __restrict__ out) {
+           int groups, int rows_per_block, int silu, const float* __restrict__ gamma,
+           const float* __restrict__ beta, const float* __restrict__ stats, unsigned short* __restrict__ out) {
   __shared__ float s_mean[64], s_rstd[64];
   const int C = c1 + c2, cpg = C / groups, cchunks = C / 8;
   const int b = blockIdx.x;
   if (threadIdx.x < groups) {
-    float s = 0.f, ss = 0.f;
-    for (int t = 0; t < ntiles; ++t) {
-      const float* p = partials + (((long)b * ntiles + t) * groups + threadIdx.x) * 2;
-      s += p[0]; ss += p[1];
-    }
-    const float n = (float)hw * (float)cpg;
-    const float mean = s / n;
-    const float var = fmaxf(ss / n - mean * mean, 0.f);
-    s_mean[threadIdx.x] = mean;
-    s_rstd[threadIdx.x] = rsqrtf(var + eps);
+    s_mean[threadIdx.x] = stats[((long)b * groups + threadIdx.x) * 2 + 0];
+    s_rstd[threadIdx.x] = stats[((long)b * groups + threadIdx.x) * 2 + 1];
   }
   __syncthreads();
   const int r_lo = blockIdx.y * rows_per_block, r_hi = min(hw, r_lo + rows_per_block);
@@ -237,21 +256,23 @@ int sdn_groupnorm_bf16(const void* x, const void* x2, int32_t batch, int32_t hw,
   const int ct = cch / nch;
   if (ct > THREADS) return SDN_E_INVALID;
   const int rt = THREADS / ct;
-  int ntiles = hw / 256;                      // >= 256 rows per stats tile
-  if (ntiles < 1) ntiles = 1;
+  int ntiles = (hw + 31) / 32;                // 32 rows per stats tile: thousands of workgroups at the 64x64 level
   if (ntiles > GN_MAX_TILES) ntiles = GN_MAX_TILES;
   const int rows_per_tile = (hw + ntiles - 1) / ntiles;
   ntiles = (hw + rows_per_tile - 1) / rows_per_tile;
   hipStream_t st = (hipStream_t)stream;
   const size_t lds = (size_t)rt * C * 2 * sizeof(float);
   if (lds > 64 * 1024) return SDN_E_INVALID;
+  float* partials = stats_ws + (size_t)batch * groups * 2;          // [B][ntiles][G][2] after the final stats
   hipLaunchKernelGGL(k_gn_stats, dim3(batch, ntiles), dim3(THREADS), lds, st, (const unsigned short*)x,
-                     (const unsigned short*)x2, hw, c1, c2, groups, rows_per_tile, ct, nch, stats_ws);
+                     (const unsigned short*)x2, hw, c1, c2, groups, rows_per_tile, ct, nch, partials);
+  hipLaunchKernelGGL(k_gn_finalize, dim3(batch), dim3(64), 0, st, partials, ntiles, groups,
+                     (float)hw * (float)(C / groups), eps, stats_ws);
   int rows_per_block = (256 * 8 * 4) / C;     // ~4 chunks per thread
   if (rows_per_block < 1) rows_per_block = 1;
   const int nblk = (hw + rows_per_block - 1) / rows_per_block;
   hipLaunchKernelGGL(k_gn_apply, dim3(batch, nblk), dim3(THREADS), 0, st, (const unsigned short*)x,
-                     (const unsigned short*)x2, hw, c1, c2, groups, ntiles, rows_per_block, eps, silu, gamma, beta,
+                     (const unsigned short*)x2, hw, c1, c2, groups, rows_per_block, silu, gamma, beta,
                      stats_ws, (unsigned short*)out);
   return sdn_launch_status();
 }

@@ -367,7 +367,7 @@ struct Builder {
       }
     }
     u->tproj_total = total;
-    gn_stats = Ref{SP_WS, arena.alloc((int64_t)B * 16 * 64 * 2 * 4)};
+    gn_stats = Ref{SP_WS, arena.alloc((int64_t)B * 129 * 64 * 2 * 4)};
     Act tsin = act(B, ch0);
     { Op o; o.kind = OP_TEMB; o.batch = B; o.c1 = ch0; o.out = R(tsin); snprintf(o.label, sizeof(o.label), "k_temb"); plan->ops.push_back(o); }
     Act t1 = act(B, tdim);

@@ -45,7 +45,7 @@ def groupnorm(x, x2, groups, eps, silu, gamma, beta):
     B, hw, c1 = x.shape
     c2 = 0 if x2 is None else x2.shape[2]
     out = torch.empty((B, hw, c1 + c2), dtype=BF, device=x.device)
-    ws = torch.empty(B * 16 * groups * 2, dtype=torch.float32, device=x.device)
+    ws = torch.empty(B * 129 * groups * 2, dtype=torch.float32, device=x.device)
     _lib.check(sda.lib().sdn_groupnorm_bf16(x.data_ptr(), None if x2 is None else x2.data_ptr(), B, hw, c1, c2, groups,
                                             eps, silu, gamma.data_ptr(), beta.data_ptr(), out.data_ptr(),
                                             ws.data_ptr(), _lib.stream_ptr()), "sdn_groupnorm_bf16")
