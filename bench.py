@@ -35,7 +35,7 @@ def build_engine(args, rank, world, dev):
     from safe_denoiser_amd.repellency import repellency_methods_threshold as thr
     from safe_denoiser_amd.unet import UNet2DConditionModel
 
-    unet = UNet2DConditionModel()
+    unet = UNet2DConditionModel(dtype=torch.float16 if args.dtype == "f16" else torch.bfloat16)
     unet.load_state_dict(unet.synthetic_state_dict(1234), device=dev)
     sched = make_scheduler(args.scheduler)
 
@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--prompts-per-batch", type=int, default=16)
     ap.add_argument("--inference-steps", type=int, default=50)
     ap.add_argument("--scheduler", default="ddpm", choices=["ddpm", "ddim"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"], help="16-bit storage type of the UNet")
     ap.add_argument("--refs", type=int, default=515)
     ap.add_argument("--total-prompts", type=int, default=515)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -183,7 +184,7 @@ def main():
     line = {
         "metric": "images/sec (512x512, 50 steps, SD-v1.4 + repellency)", "value": value, "unit": "images/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"SD-v1.4 UNet (random weights) + safe_denoiser.yaml repellency (kernel_fast, M={args.refs}, "
                                f"sigma 3.15, scale .33, margin 1.6, window 780<=t<=1000), {args.total_prompts}-prompt job "
                                f"sharded r::{world}, CFG 7.5 (2 branches), {args.scheduler.upper()} {args.inference_steps} "

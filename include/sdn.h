@@ -196,11 +196,16 @@ int sdn_gemm_f16(const sdn_gemm_desc* d_host, const void* a, const void* a2, con
 int sdn_groupnorm_bf16(const void* x, const void* x2, int32_t batch, int32_t hw, int32_t c1, int32_t c2,
                        int32_t groups, float eps, int32_t silu, const float* gamma, const float* beta,
                        void* out, float* stats_ws, void* stream);
+int sdn_groupnorm_f16(const void* x, const void* x2, int32_t batch, int32_t hw, int32_t c1, int32_t c2,
+                      int32_t groups, float eps, int32_t silu, const float* gamma, const float* beta,
+                      void* out, float* stats_ws, void* stream);
 
 /* LayerNorm over the last axis of [rows, C] bf16 (eps 1e-5, affine) -- BasicTransformerBlock norm1/2/3
  * (models/transformer_2d.py:265,305,335). */
 int sdn_layernorm_bf16(const void* x, int64_t rows, int32_t c, float eps, const float* gamma,
                        const float* beta, void* out, void* stream);
+int sdn_layernorm_f16(const void* x, int64_t rows, int32_t c, float eps, const float* gamma,
+                      const float* beta, void* out, void* stream);
 
 /* softmax(Q K^T * scale) V per (batch, head); flash-style, never materialises the score matrix.
  *   q [B, Nq, ldq] (head h at columns h*d .. h*d+d), k/v [B, Nk, ldk/ldv] likewise, out [B, Nq, ldo].
@@ -218,10 +223,13 @@ int sdn_attention_f16(const void* q, const void* k, const void* v, void* out, in
  * (models/unet.py:840).  w is [Cout][3][3][Cin] bf16, bias f32. */
 int sdn_conv_in_bf16(const float* latents_nchw, const void* w, const float* bias, int32_t batch, int32_t cin,
                      int32_t h, int32_t wd, int32_t cout, void* out_nhwc, void* stream);
+int sdn_conv_in_f16(const float* latents_nchw, const void* w, const float* bias, int32_t batch, int32_t cin,
+                    int32_t h, int32_t wd, int32_t cout, void* out_nhwc, void* stream);
 
 /* Sinusoidal timestep features, flip_sin_to_cos, shift 0: out[b] = [cos(t f_k) | sin(t f_k)], f_k =
  * exp(-ln(1e4) k / half) -> bf16 [B, dim]  (Timesteps(320), models/unet.py:764-786). */
 int sdn_timestep_embed_bf16(float timestep, int32_t batch, int32_t dim, void* out, void* stream);
+int sdn_timestep_embed_f16(float timestep, int32_t batch, int32_t dim, void* out, void* stream);
 
 /* ---- whole-network entry: SD-v1.4-family UNet2DConditionModel forward -------------------------- */
 typedef struct sdn_unet_config {
@@ -233,6 +241,7 @@ typedef struct sdn_unet_config {
   int32_t n_heads;                                     /* 8 (config key attention_head_dim, legacy) */
   int32_t cross_dim, text_len;                         /* 768, 77                                   */
   int32_t norm_groups;                                 /* 32                                        */
+  int32_t dtype;                                       /* 0 = bf16 storage, 1 = fp16 storage        */
 } sdn_unet_config;
 
 typedef struct sdn_unet sdn_unet;   /* opaque: op plan + parameter manifest (host memory only) */
@@ -262,7 +271,7 @@ size_t sdn_unet_workspace_bytes(sdn_unet* u, int32_t batch);
  * attention-core share -- the numerators of the MFMA roofline. */
 double sdn_unet_flops(sdn_unet* u, int32_t batch, double* attention_core_flops_host);
 
-/* eps = UNet(latents, t, text):  latents [B, in_ch, S, S] fp32 NCHW, text [B, text_len, cross_dim] bf16,
+/* eps = UNet(latents, t, text):  latents [B, in_ch, S, S] fp32 NCHW, text [B, text_len, cross_dim] in the plan's 16-bit dtype,
  * out [B, out_ch, S, S] fp32 NCHW.  One timestep for the whole batch (the reference passes a scalar t,
  * ...threshold_time.py:538).  Replaces self.unet(latent_model_input, t, encoder_hidden_states=E).sample. */
 int sdn_unet_forward(sdn_unet* u, const void* weights, const float* latents, float timestep, const void* text,

@@ -42,7 +42,7 @@ class UnetConfig(C.Structure):
     _fields_ = [("in_channels", C.c_int32), ("out_channels", C.c_int32), ("sample_size", C.c_int32),
                 ("n_levels", C.c_int32), ("block_out_channels", C.c_int32 * 4), ("level_has_attn", C.c_int32 * 4),
                 ("layers_per_block", C.c_int32), ("n_heads", C.c_int32), ("cross_dim", C.c_int32),
-                ("text_len", C.c_int32), ("norm_groups", C.c_int32)]
+                ("text_len", C.c_int32), ("norm_groups", C.c_int32), ("dtype", C.c_int32)]
 
 
 class ProfileRow(C.Structure):
@@ -75,6 +75,10 @@ SIGNATURES = {
     "sdn_gemm_bf16": (C.c_int, [C.POINTER(GemmDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sdn_gemm_f16": (C.c_int, [C.POINTER(GemmDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sdn_groupnorm_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "sdn_groupnorm_f16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "sdn_layernorm_f16": (C.c_int, [_vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp]),
+    "sdn_conv_in_f16": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "sdn_timestep_embed_f16": (C.c_int, [_f32, _i32, _i32, _vp, _vp]),
     "sdn_layernorm_bf16": (C.c_int, [_vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp]),
     "sdn_attention_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32,
                                      _vp]),

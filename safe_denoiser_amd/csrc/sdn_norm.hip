@@ -3,24 +3,20 @@
 #include "sdn_common.h"
 #include "sdn_ops.h"
 
-namespace {
+namespace sdn_norm_detail {
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 constexpr int THREADS = 256;
 constexpr int GN_MAX_TILES = 128;
 
-__device__ __forceinline__ float bf2f(unsigned v16) { return __uint_as_float(v16 << 16); }
+template <typename T>
 __device__ __forceinline__ void unpack8(const u32x4 v, float* f) {
-  f[0] = bf2f(v.x & 0xffff); f[1] = bf2f(v.x >> 16); f[2] = bf2f(v.y & 0xffff); f[3] = bf2f(v.y >> 16);
-  f[4] = bf2f(v.z & 0xffff); f[5] = bf2f(v.z >> 16); f[6] = bf2f(v.w & 0xffff); f[7] = bf2f(v.w >> 16);
+  f[0] = T::to_f(v.x & 0xffff); f[1] = T::to_f(v.x >> 16); f[2] = T::to_f(v.y & 0xffff); f[3] = T::to_f(v.y >> 16);
+  f[4] = T::to_f(v.z & 0xffff); f[5] = T::to_f(v.z >> 16); f[6] = T::to_f(v.w & 0xffff); f[7] = T::to_f(v.w >> 16);
 }
-__device__ __forceinline__ unsigned pack2(float lo, float hi) {
-  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-  bf16x2 p = {(__bf16)lo, (__bf16)hi};
-  return *reinterpret_cast<unsigned*>(&p);
-}
+template <typename T>
 __device__ __forceinline__ u32x4 pack8(const float* f) {
-  return (u32x4){pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7])};
+  return (u32x4){T::pack2(f[0], f[1]), T::pack2(f[2], f[3]), T::pack2(f[4], f[5]), T::pack2(f[6], f[7])};
 }
 __device__ __forceinline__ float silu_f(float v) { return v / (1.f + __expf(-v)); }
 
@@ -28,6 +24,7 @@ __device__ __forceinline__ float silu_f(float v) { return v / (1.f + __expf(-v))
 // GroupNorm pass 1: per (sample, row tile) partial sums per group, deterministic.
 // Thread (cl, rl): cl owns NCH fixed 8-channel chunks, rl strides over the tile's rows.
 // ------------------------------------------------------------------------------------------------
+template <typename T>
 __global__ void __launch_bounds__(THREADS)
 k_gn_stats(const unsigned short* __restrict__ x, const unsigned short* __restrict__ x2, int hw, int c1, int c2,
            int groups, int rows_per_tile, int ct, int nch, float* __restrict__ partials) {
@@ -57,7 +54,7 @@ k_gn_stats(const unsigned short* __restrict__ x, const unsigned short* __restric
         for (int j = 0; j < 4; ++j) {
           if (r + j * rt < r_hi) {
             float f[8];
-            unpack8(v[j], f);
+            unpack8<T>(v[j], f);
 #pragma unroll
             for (int e = 0; e < 8; ++e) { s[e] += f[e]; ss[e] = fmaf(f[e], f[e], ss[e]); }
           }
@@ -101,6 +98,7 @@ __global__ void k_gn_finalize(const float* __restrict__ partials, int ntiles, in
 }
 
 // GroupNorm pass 2: normalise + affine (+SiLU), write the (concatenated) map.
+template <typename T>
 __global__ void __launch_bounds__(THREADS)
 k_gn_apply(const unsigned short* __restrict__ x, const unsigned short* __restrict__ x2, int hw, int c1, int c2,
            int groups, int rows_per_block, int silu, const float* __restrict__ gamma,
@@ -121,7 +119,7 @@ k_gn_apply(const unsigned short* __restrict__ x, const unsigned short* __restric
     if (ch0 < c1) { src = x; ld = c1; cc = ch0; } else { src = x2; ld = c2; cc = ch0 - c1; }
     const u32x4 v = *reinterpret_cast<const u32x4*>(src + ((long)b * hw + r) * ld + cc);
     float f[8];
-    unpack8(v, f);
+    unpack8<T>(v, f);
     const float4 g0 = *reinterpret_cast<const float4*>(gamma + ch0), g1 = *reinterpret_cast<const float4*>(gamma + ch0 + 4);
     const float4 b0 = *reinterpret_cast<const float4*>(beta + ch0), b1 = *reinterpret_cast<const float4*>(beta + ch0 + 4);
     const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
@@ -132,13 +130,14 @@ k_gn_apply(const unsigned short* __restrict__ x, const unsigned short* __restric
       float y = (f[k] - s_mean[gi]) * s_rstd[gi] * gm[k] + bt[k];
       f[k] = silu ? silu_f(y) : y;
     }
-    *reinterpret_cast<u32x4*>(out + ((long)b * hw + r) * C + ch0) = pack8(f);
+    *reinterpret_cast<u32x4*>(out + ((long)b * hw + r) * C + ch0) = pack8<T>(f);
   }
 }
 
 // ------------------------------------------------------------------------------------------------
 // LayerNorm: one wave per row, up to 4 chunks (C <= 2048) held in registers; two-pass variance.
 // ------------------------------------------------------------------------------------------------
+template <typename T>
 __global__ void __launch_bounds__(THREADS)
 k_layernorm(const unsigned short* __restrict__ x, long rows, int C, float eps, const float* __restrict__ gamma,
             const float* __restrict__ beta, unsigned short* __restrict__ out) {
@@ -152,7 +151,7 @@ k_layernorm(const unsigned short* __restrict__ x, long rows, int C, float eps, c
   for (int q = 0; q < 4; ++q) {
     const int cc = lane + q * 64;
     if (cc < cchunks) {
-      unpack8(*reinterpret_cast<const u32x4*>(x + row * C + cc * 8), f[q]);
+      unpack8<T>(*reinterpret_cast<const u32x4*>(x + row * C + cc * 8), f[q]);
 #pragma unroll
       for (int k = 0; k < 8; ++k) s += f[q][k];
     }
@@ -179,7 +178,7 @@ k_layernorm(const unsigned short* __restrict__ x, long rows, int C, float eps, c
       float y[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) y[k] = (f[q][k] - mean) * rstd * gm[k] + bt[k];
-      *reinterpret_cast<u32x4*>(out + row * C + cc * 8) = pack8(y);
+      *reinterpret_cast<u32x4*>(out + row * C + cc * 8) = pack8<T>(y);
     }
   }
 }
@@ -187,6 +186,7 @@ k_layernorm(const unsigned short* __restrict__ x, long rows, int C, float eps, c
 // ------------------------------------------------------------------------------------------------
 // conv_in: direct 3x3 conv, fp32 NCHW latent -> NHWC bf16.  One thread = one pixel x 8 output channels.
 // ------------------------------------------------------------------------------------------------
+template <typename T>
 __global__ void __launch_bounds__(THREADS)
 k_conv_in(const float* __restrict__ lat, const unsigned short* __restrict__ w, const float* __restrict__ bias,
           int B, int cin, int H, int W, int cout, unsigned short* __restrict__ out) {
@@ -194,7 +194,7 @@ k_conv_in(const float* __restrict__ lat, const unsigned short* __restrict__ w, c
   const int kk = 9 * cin;                         // consecutive addresses -> conflict-free ds_read_b128
   for (int i = threadIdx.x; i < cout * kk; i += THREADS) {
     const int co = i / kk, k = i - co * kk;
-    wl[k * cout + co] = bf2f(w[i]);
+    wl[k * cout + co] = T::to_f(w[i]);
   }
   __syncthreads();
   const int cchunks = cout / 8;
@@ -215,10 +215,11 @@ k_conv_in(const float* __restrict__ lat, const unsigned short* __restrict__ w, c
         for (int k = 0; k < 8; ++k) acc[k] = fmaf(v, wl[(tap * cin + c) * cout + cc * 8 + k], acc[k]);
       }
     }
-    *reinterpret_cast<u32x4*>(out + pix * cout + cc * 8) = pack8(acc);
+    *reinterpret_cast<u32x4*>(out + pix * cout + cc * 8) = pack8<T>(acc);
   }
 }
 
+template <typename T>
 __global__ void k_temb(float t, int B, int dim, unsigned short* __restrict__ out) {
   const int half = dim / 2;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * dim; i += gridDim.x * blockDim.x) {
@@ -227,21 +228,17 @@ __global__ void k_temb(float t, int B, int dim, unsigned short* __restrict__ out
     const float f = expf(-9.210340371976184f * (float)kk / (float)half);   // ln(10000)
     const float a = t * f;
     const float v = k < half ? cosf(a) : sinf(a);
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-    bf16x2 p = {(__bf16)v, (__bf16)0.f};
-    out[i] = (unsigned short)(*reinterpret_cast<unsigned*>(&p) & 0xffff);
+    out[i] = (unsigned short)(T::pack2(v, 0.f) & 0xffff);
   }
 }
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-}  // namespace
 
-extern "C" {
-
-int sdn_groupnorm_bf16(const void* x, const void* x2, int32_t batch, int32_t hw, int32_t c1, int32_t c2,
-                       int32_t groups, float eps, int32_t silu, const float* gamma, const float* beta, void* out,
-                       float* stats_ws, void* stream) {
+template <typename T>
+int groupnorm_impl(const void* x, const void* x2, int32_t batch, int32_t hw, int32_t c1, int32_t c2, int32_t groups,
+                   float eps, int32_t silu, const float* gamma, const float* beta, void* out, float* stats_ws,
+                   void* stream) {
   if (!x || !gamma || !beta || !out || !stats_ws || batch < 0 || hw <= 0 || c1 <= 0 || c2 < 0 || groups <= 0 ||
       groups > 64)
     return SDN_E_INVALID;
@@ -264,31 +261,33 @@ int sdn_groupnorm_bf16(const void* x, const void* x2, int32_t batch, int32_t hw,
   const size_t lds = (size_t)rt * C * 2 * sizeof(float);
   if (lds > 64 * 1024) return SDN_E_INVALID;
   float* partials = stats_ws + (size_t)batch * groups * 2;          // [B][ntiles][G][2] after the final stats
-  hipLaunchKernelGGL(k_gn_stats, dim3(batch, ntiles), dim3(THREADS), lds, st, (const unsigned short*)x,
+  hipLaunchKernelGGL((k_gn_stats<T>), dim3(batch, ntiles), dim3(THREADS), lds, st, (const unsigned short*)x,
                      (const unsigned short*)x2, hw, c1, c2, groups, rows_per_tile, ct, nch, partials);
   hipLaunchKernelGGL(k_gn_finalize, dim3(batch), dim3(64), 0, st, partials, ntiles, groups,
                      (float)hw * (float)(C / groups), eps, stats_ws);
   int rows_per_block = (256 * 8 * 4) / C;     // ~4 chunks per thread
   if (rows_per_block < 1) rows_per_block = 1;
   const int nblk = (hw + rows_per_block - 1) / rows_per_block;
-  hipLaunchKernelGGL(k_gn_apply, dim3(batch, nblk), dim3(THREADS), 0, st, (const unsigned short*)x,
-                     (const unsigned short*)x2, hw, c1, c2, groups, rows_per_block, silu, gamma, beta,
-                     stats_ws, (unsigned short*)out);
+  hipLaunchKernelGGL((k_gn_apply<T>), dim3(batch, nblk), dim3(THREADS), 0, st, (const unsigned short*)x,
+                     (const unsigned short*)x2, hw, c1, c2, groups, rows_per_block, silu, gamma, beta, stats_ws,
+                     (unsigned short*)out);
   return sdn_launch_status();
 }
 
-int sdn_layernorm_bf16(const void* x, int64_t rows, int32_t c, float eps, const float* gamma, const float* beta,
-                       void* out, void* stream) {
+template <typename T>
+int layernorm_impl(const void* x, int64_t rows, int32_t c, float eps, const float* gamma, const float* beta, void* out,
+                   void* stream) {
   if (!x || !gamma || !beta || !out || rows < 0 || c <= 0 || (c & 7) || c > 2048) return SDN_E_INVALID;
   if (!al16(x) || !al16(out) || !al16(gamma) || !al16(beta)) return SDN_E_INVALID;
   if (rows == 0) return SDN_OK;
-  hipLaunchKernelGGL(k_layernorm, dim3((unsigned)((rows + 3) / 4)), dim3(THREADS), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL((k_layernorm<T>), dim3((unsigned)((rows + 3) / 4)), dim3(THREADS), 0, (hipStream_t)stream,
                      (const unsigned short*)x, (long)rows, c, eps, gamma, beta, (unsigned short*)out);
   return sdn_launch_status();
 }
 
-int sdn_conv_in_bf16(const float* lat, const void* w, const float* bias, int32_t batch, int32_t cin, int32_t h,
-                     int32_t wd, int32_t cout, void* out, void* stream) {
+template <typename T>
+int conv_in_impl(const float* lat, const void* w, const float* bias, int32_t batch, int32_t cin, int32_t h, int32_t wd,
+                 int32_t cout, void* out, void* stream) {
   if (!lat || !w || !bias || !out || batch < 0 || cin <= 0 || cin > 16 || h <= 0 || wd <= 0 || cout <= 0 ||
       (cout & 7) || !al16(out))
     return SDN_E_INVALID;
@@ -298,18 +297,40 @@ int sdn_conv_in_bf16(const float* lat, const void* w, const float* bias, int32_t
   const long total = (long)batch * h * wd * (cout / 8);
   long grid = (total + THREADS - 1) / THREADS;
   if (grid > 2048) grid = 2048;
-  hipLaunchKernelGGL(k_conv_in, dim3((unsigned)grid), dim3(THREADS), lds, (hipStream_t)stream, lat,
+  hipLaunchKernelGGL((k_conv_in<T>), dim3((unsigned)grid), dim3(THREADS), lds, (hipStream_t)stream, lat,
                      (const unsigned short*)w, bias, batch, cin, h, wd, cout, (unsigned short*)out);
   return sdn_launch_status();
 }
 
-int sdn_timestep_embed_bf16(float timestep, int32_t batch, int32_t dim, void* out, void* stream) {
+template <typename T>
+int temb_impl(float timestep, int32_t batch, int32_t dim, void* out, void* stream) {
   if (!out || batch < 0 || dim <= 0 || (dim & 1)) return SDN_E_INVALID;
   if (batch == 0) return SDN_OK;
   const int n = batch * dim;
-  hipLaunchKernelGGL(k_temb, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, timestep, batch, dim,
+  hipLaunchKernelGGL((k_temb<T>), dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, timestep, batch, dim,
                      (unsigned short*)out);
   return sdn_launch_status();
 }
 
-}  // extern "C"
+}  // namespace sdn_norm_detail
+using namespace sdn_norm_detail;
+
+#define SDN_NORM_ENTRY(SUF, T)                                                                                          \
+  extern "C" int sdn_groupnorm_##SUF(const void* x, const void* x2, int32_t batch, int32_t hw, int32_t c1, int32_t c2, \
+                                     int32_t groups, float eps, int32_t silu, const float* gamma, const float* beta,   \
+                                     void* out, float* stats_ws, void* stream) {                                        \
+    return groupnorm_impl<T>(x, x2, batch, hw, c1, c2, groups, eps, silu, gamma, beta, out, stats_ws, stream);         \
+  }                                                                                                                     \
+  extern "C" int sdn_layernorm_##SUF(const void* x, int64_t rows, int32_t c, float eps, const float* gamma,            \
+                                     const float* beta, void* out, void* stream) {                                      \
+    return layernorm_impl<T>(x, rows, c, eps, gamma, beta, out, stream);                                                \
+  }                                                                                                                     \
+  extern "C" int sdn_conv_in_##SUF(const float* lat, const void* w, const float* bias, int32_t batch, int32_t cin,     \
+                                   int32_t h, int32_t wd, int32_t cout, void* out, void* stream) {                      \
+    return conv_in_impl<T>(lat, w, bias, batch, cin, h, wd, cout, out, stream);                                         \
+  }                                                                                                                     \
+  extern "C" int sdn_timestep_embed_##SUF(float timestep, int32_t batch, int32_t dim, void* out, void* stream) {       \
+    return temb_impl<T>(timestep, batch, dim, out, stream);                                                             \
+  }
+SDN_NORM_ENTRY(bf16, SdnBF16)
+SDN_NORM_ENTRY(f16, SdnF16)

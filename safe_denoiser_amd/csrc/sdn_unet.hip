@@ -497,7 +497,7 @@ int sdn_unet_create(const sdn_unet_config* cfg, sdn_unet** out) {
   if (cfg->n_levels < 1 || cfg->n_levels > 4 || cfg->layers_per_block < 1 || cfg->n_heads <= 0 ||
       cfg->in_channels <= 0 || cfg->in_channels > 16 || cfg->out_channels <= 0 || cfg->out_channels > 32 ||
       cfg->sample_size <= 0 || (cfg->sample_size % (1 << (cfg->n_levels - 1))) != 0 || cfg->cross_dim % 64 != 0 ||
-      cfg->text_len <= 0 || cfg->norm_groups <= 0 || cfg->norm_groups > 64)
+      cfg->text_len <= 0 || cfg->norm_groups <= 0 || cfg->norm_groups > 64 || cfg->dtype < 0 || cfg->dtype > 1)
     return SDN_E_INVALID;
   for (int i = 0; i < cfg->n_levels; ++i) {
     const int c = cfg->block_out_channels[i];
@@ -556,31 +556,32 @@ int sdn_unet_forward(sdn_unet* u, const void* weights, const float* latents, flo
     u->profiled_batch = batch;
   }
   size_t opi = 0;
+  const bool f16 = u->cfg.dtype == 1;
   for (const Op& o : p->ops) {
     int rc = SDN_OK;
     if (prof) (void)hipEventRecord(u->ev[2 * opi], (hipStream_t)stream);
     switch (o.kind) {
       case OP_TEMB:
-        rc = sdn_timestep_embed_bf16(timestep, o.batch, o.c1, (void*)P(o.out), stream);
+        rc = (f16 ? sdn_timestep_embed_f16 : sdn_timestep_embed_bf16)(timestep, o.batch, o.c1, (void*)P(o.out), stream);
         break;
       case OP_CONV_IN:
-        rc = sdn_conv_in_bf16((const float*)P(o.a), P(o.w), (const float*)P(o.bias), o.batch, o.c1, o.hw, o.hw, o.c2,
+        rc = (f16 ? sdn_conv_in_f16 : sdn_conv_in_bf16)((const float*)P(o.a), P(o.w), (const float*)P(o.bias), o.batch, o.c1, o.hw, o.hw, o.c2,
                               (void*)P(o.out), stream);
         break;
       case OP_GEMM:
-        rc = sdn_gemm_bf16(&o.gd, P(o.a), P(o.a2), P(o.w), (const float*)P(o.bias), (const float*)P(o.rowbias),
+        rc = (f16 ? sdn_gemm_f16 : sdn_gemm_bf16)(&o.gd, P(o.a), P(o.a2), P(o.w), (const float*)P(o.bias), (const float*)P(o.rowbias),
                            P(o.residual), (void*)P(o.out), stream);
         break;
       case OP_GN:
-        rc = sdn_groupnorm_bf16(P(o.a), P(o.a2), o.batch, o.hw, o.c1, o.c2, o.groups, o.eps, o.silu,
+        rc = (f16 ? sdn_groupnorm_f16 : sdn_groupnorm_bf16)(P(o.a), P(o.a2), o.batch, o.hw, o.c1, o.c2, o.groups, o.eps, o.silu,
                                 (const float*)P(o.w), (const float*)P(o.bias), (void*)P(o.out), (float*)P(o.aux), stream);
         break;
       case OP_LN:
-        rc = sdn_layernorm_bf16(P(o.a), o.rows, o.c1, o.eps, (const float*)P(o.w), (const float*)P(o.bias),
+        rc = (f16 ? sdn_layernorm_f16 : sdn_layernorm_bf16)(P(o.a), o.rows, o.c1, o.eps, (const float*)P(o.w), (const float*)P(o.bias),
                                 (void*)P(o.out), stream);
         break;
       case OP_ATTN:
-        rc = sdn_attention_bf16(P(o.a), P(o.k), P(o.v), (void*)P(o.out), o.batch, o.heads, o.nq, o.nk, o.hd, o.ldq,
+        rc = (f16 ? sdn_attention_f16 : sdn_attention_bf16)(P(o.a), P(o.k), P(o.v), (void*)P(o.out), o.batch, o.heads, o.nq, o.nk, o.hd, o.ldq,
                                 o.ldk, o.ldv, o.ldo, o.scale, stream);
         break;
     }

@@ -40,7 +40,10 @@ def _interleave16(t: torch.Tensor) -> torch.Tensor:
 
 
 class UNet2DConditionModel:
-    def __init__(self, text_len: int = 77, **config):
+    def __init__(self, text_len: int = 77, dtype=torch.bfloat16, **config):
+        if dtype not in (torch.bfloat16, torch.float16):
+            raise _lib.SdnError("storage dtype must be torch.bfloat16 or torch.float16")
+        self.dtype = dtype
         cfg = dict(SD14_CONFIG)
         cfg.update(config)
         self.config = SimpleNamespace(**cfg)
@@ -55,7 +58,7 @@ class UNet2DConditionModel:
                                                               for t in cfg["down_block_types"]] + [0] * (4 - n))),
                             layers_per_block=cfg["layers_per_block"], n_heads=cfg["attention_head_dim"],
                             cross_dim=cfg["cross_attention_dim"], text_len=text_len,
-                            norm_groups=cfg["norm_num_groups"])
+                            norm_groups=cfg["norm_num_groups"], dtype=0 if dtype == torch.bfloat16 else 1)
         h = C.c_void_p()
         _lib.check(_lib.lib().sdn_unet_create(C.byref(c), C.byref(h)), "sdn_unet_create")
         self._h = h
@@ -130,7 +133,7 @@ class UNet2DConditionModel:
             if k in (P_VEC_F32, P_GEGLU_VEC):
                 raw = t.contiguous().view(torch.uint8)
             else:
-                raw = t.to(torch.bfloat16).contiguous().view(torch.uint8).reshape(-1)
+                raw = t.to(self.dtype).contiguous().view(torch.uint8).reshape(-1)
             buf[p["offset"]:p["offset"] + raw.numel()] = raw.reshape(-1)
         return buf
 
@@ -172,14 +175,14 @@ class UNet2DConditionModel:
         e = encoder_hidden_states
         if e.shape[1] != self.text_len or e.shape[2] != self.config.cross_attention_dim:
             raise _lib.SdnError(f"encoder_hidden_states must be [B,{self.text_len},{self.config.cross_attention_dim}]")
-        return e.to(torch.bfloat16).contiguous()
+        return e.to(self.dtype).contiguous()
 
     def forward_into(self, sample, timestep, text_bf16, out):
         """No-allocation form used by the engine loop (text already bf16, `out` preallocated fp32)."""
         b = sample.shape[0]
         ws = self._workspace(b, sample.device)
         _lib.check(_lib.lib().sdn_unet_forward(self._h, _lib.dptr(self._weights), _lib.dptr(sample, torch.float32),
-                                               float(timestep), _lib.dptr(text_bf16, torch.bfloat16),
+                                               float(timestep), _lib.dptr(text_bf16, self.dtype),
                                                _lib.dptr(out, torch.float32), b, _lib.dptr(ws), ws.numel(),
                                                _lib.stream_ptr()), "sdn_unet_forward")
         return out

@@ -204,3 +204,29 @@ def test_conv_in_and_timestep_embedding():
         _lib.check(sda.lib().sdn_timestep_embed_bf16(t, 3, 320, te.data_ptr(), _lib.stream_ptr()), "temb")
         exp = OracleUNet({}, None).timestep_features(t, 3, 320)
         assert float((te.float().cpu() - exp).abs().max()) <= 2 ** -8 + 2e-4     # bf16 rounding + fp32 sin/cos argument
+
+
+# ------------------------------------------------------------------------------------------ fp16 storage twins
+def test_f16_twins_are_8x_tighter():
+    """The _f16 entry points (IEEE half storage, same kernels through the dtype traits): one output rounding is 2^-12
+    relative -> rel L2 <= 5e-4 (attention 1.5e-3: P is rounded to fp16 before the PV product)."""
+    H16 = torch.float16
+    g = torch.Generator().manual_seed(40)
+    a = torch.randn(512, 640, generator=g).to(H16); w = (torch.randn(320, 640, generator=g) * 640 ** -0.5).to(H16)
+    bias = torch.randn(320, generator=g)
+    assert rel_l2(ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda()), a.float() @ w.float().T + bias) <= 5e-4
+    x = torch.randn(2, 16, 16, 320, generator=g).to(H16); cw = (torch.randn(320, 320, 3, 3, generator=g) / 54).to(H16)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), cw.float(), None, padding=1)
+    out = ops.gemm(x.cuda(), cw.permute(0, 2, 3, 1).reshape(320, -1).contiguous().cuda(),
+                   conv=dict(Hs=16, Ws=16, Cin=320, Ho=16, Wo=16))
+    assert rel_l2(out.reshape(2, 16, 16, 320).permute(0, 3, 1, 2), ref) <= 5e-4
+    xx = (torch.randn(2, 256, 640, generator=g) * 2 + 0.5).to(H16)
+    gm = 1 + 0.1 * torch.randn(640, generator=g); bt = 0.1 * torch.randn(640, generator=g)
+    ref = F.silu(F.group_norm(xx.float().permute(0, 2, 1), 32, gm, bt, eps=1e-5)).permute(0, 2, 1)
+    assert rel_l2(ops.groupnorm(xx.cuda(), None, 32, 1e-5, 1, gm.cuda(), bt.cuda()), ref) <= 5e-4
+    ref = F.layer_norm(xx[0].float(), (640,), gm, bt, eps=1e-5)
+    assert rel_l2(ops.layernorm(xx[0].contiguous().cuda(), gm.cuda(), bt.cuda()), ref) <= 5e-4
+    q, k, v = (torch.randn(1, 256, 320, generator=g).to(H16) for _ in range(3))
+    sp = lambda t: t.float().reshape(1, 256, 8, 40).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(sp(q), sp(k), sp(v)).transpose(1, 2).reshape(1, 256, 320)
+    assert rel_l2(ops.attention(q.cuda(), k.cuda(), v.cuda(), 8), ref) <= 1.5e-3

@@ -136,3 +136,23 @@ def test_device_generators_are_per_prompt(world):
     assert rel_l2(one, full[2:3]) <= 1e-6
     with pytest.raises(NotImplementedError):
         pipe(prompt="a photo", num_inference_steps=5)
+
+
+def test_fp16_storage_loop_parity(tmp_path):
+    """Same tape test with fp16 storage: final 20-step latents within 1.5e-2 rel L2 (bf16: 2.5-4e-2)."""
+    u = UNet2DConditionModel(text_len=77, dtype=torch.float16, **SMALL)
+    sd = u.synthetic_state_dict(11)
+    u.load_state_dict(sd)
+    g = torch.Generator().manual_seed(2)
+    P = 2
+    E = torch.randn(2 * P, 77, 768, generator=g)
+    shape = (1, 4, 16, 16)
+    unet_o = OracleUNet(sd, SMALL_O, act_dtype=torch.float16)
+    t_o = Tapes(P, shape, 3 * STEPS + 4, seed=9)
+    ref = torch.cat([opipe.denoise_one(unet_o, osch.DDPM(), torch.stack([E[p], E[P + p]]), p, t_o,
+                                       num_inference_steps=STEPS)[0] for p in range(P)])
+    t_p = Tapes(P, shape, 3 * STEPS + 4, seed=9)
+    lat = SafeDenoiserPipeline(u, DDPMScheduler())(prompt_embeddings=E.cuda(), num_inference_steps=STEPS, noise_fn=t_p)
+    errs = [rel_l2(lat[p:p + 1], ref[p:p + 1]) for p in range(P)]
+    print(f"fp16 loop: per-prompt rel L2 {['%.2e' % e for e in errs]}")
+    assert t_p.cur == t_o.cur and max(errs) <= 1.5e-2

@@ -9,6 +9,11 @@ from safe_denoiser_amd import _lib
 BF = torch.bfloat16
 
 
+def _fn(base: str, t: torch.Tensor):
+    """sdn_<base>_bf16 or sdn_<base>_f16 by the tensor's storage dtype."""
+    return getattr(sda.lib(), f"sdn_{base}_{'f16' if t.dtype == torch.float16 else 'bf16'}")
+
+
 def gemm(a, w, *, bias=None, rowbias=None, residual=None, a2=None, conv=None, act=0, out_kind=0, n_valid=0,
          rows_per_batch=0):
     """a [M,K] bf16 (or NHWC map for conv=dict(Hs,Ws,Cin,Ho,Wo,stride,upsample)), w [N,K] bf16."""
@@ -30,13 +35,13 @@ def gemm(a, w, *, bias=None, rowbias=None, residual=None, a2=None, conv=None, ac
         d.ld_rowbias = rowbias.stride(0)
     nv = n_valid or N
     if out_kind == 0:
-        out = torch.empty((M, N // 2 if act == 2 else nv), dtype=BF, device=a.device)
+        out = torch.empty((M, N // 2 if act == 2 else nv), dtype=a.dtype, device=a.device)
     elif out_kind == 1:
         out = torch.empty((M, nv), dtype=torch.float32, device=a.device)
     else:
         out = torch.empty((M // rows_per_batch, nv, rows_per_batch), dtype=torch.float32, device=a.device)
     p = lambda t: None if t is None else t.data_ptr()
-    _lib.check(sda.lib().sdn_gemm_bf16(C.byref(d), p(a), p(a2), p(w), p(bias), p(rowbias), p(residual), p(out),
+    _lib.check(_fn("gemm", a)(C.byref(d), p(a), p(a2), p(w), p(bias), p(rowbias), p(residual), p(out),
                                        _lib.stream_ptr()), "sdn_gemm_bf16")
     return out
 
@@ -44,9 +49,9 @@ def gemm(a, w, *, bias=None, rowbias=None, residual=None, a2=None, conv=None, ac
 def groupnorm(x, x2, groups, eps, silu, gamma, beta):
     B, hw, c1 = x.shape
     c2 = 0 if x2 is None else x2.shape[2]
-    out = torch.empty((B, hw, c1 + c2), dtype=BF, device=x.device)
+    out = torch.empty((B, hw, c1 + c2), dtype=x.dtype, device=x.device)
     ws = torch.empty(B * 129 * groups * 2, dtype=torch.float32, device=x.device)
-    _lib.check(sda.lib().sdn_groupnorm_bf16(x.data_ptr(), None if x2 is None else x2.data_ptr(), B, hw, c1, c2, groups,
+    _lib.check(_fn("groupnorm", x)(x.data_ptr(), None if x2 is None else x2.data_ptr(), B, hw, c1, c2, groups,
                                             eps, silu, gamma.data_ptr(), beta.data_ptr(), out.data_ptr(),
                                             ws.data_ptr(), _lib.stream_ptr()), "sdn_groupnorm_bf16")
     return out
@@ -55,7 +60,7 @@ def groupnorm(x, x2, groups, eps, silu, gamma, beta):
 def layernorm(x, gamma, beta, eps=1e-5):
     rows, c = x.shape
     out = torch.empty_like(x)
-    _lib.check(sda.lib().sdn_layernorm_bf16(x.data_ptr(), rows, c, eps, gamma.data_ptr(), beta.data_ptr(),
+    _lib.check(_fn("layernorm", x)(x.data_ptr(), rows, c, eps, gamma.data_ptr(), beta.data_ptr(),
                                             out.data_ptr(), _lib.stream_ptr()), "sdn_layernorm_bf16")
     return out
 
@@ -65,9 +70,9 @@ def attention(q, k, v, heads, scale=None):
     B, nq, c = q.shape
     nk = k.shape[1]
     d = c // heads
-    out = torch.empty((B, nq, c), dtype=BF, device=q.device)
+    out = torch.empty((B, nq, c), dtype=q.dtype, device=q.device)
     scale = scale if scale is not None else d ** -0.5
-    _lib.check(sda.lib().sdn_attention_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, heads, nq, nk,
+    _lib.check(_fn("attention", q)(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, heads, nq, nk,
                                             d, q.stride(1), k.stride(1), v.stride(1), c, scale, _lib.stream_ptr()),
                "sdn_attention_bf16")
     return out
