@@ -158,6 +158,7 @@ int sdn_flow_renoise(const float* x0r, const float* x1, const float* z, int64_t 
 #define SDN_ACT_NONE   0
 #define SDN_ACT_SILU   1
 #define SDN_ACT_GEGLU  2   /* W rows interleaved value/gate in blocks of 16; out = v*gelu(g)  */
+#define SDN_ACT_GELU_TANH 3 /* GELU(approximate="tanh") -- MMDiT feed-forward                   */
 #define SDN_OUT_BF16      0   /* [M, ldc] bf16                                                */
 #define SDN_OUT_F32       1   /* [M, ldc] f32                                                 */
 #define SDN_OUT_F32_NCHW  2   /* [B, n_valid, rows_per_batch] f32 (conv_out -> latent layout) */
@@ -175,19 +176,23 @@ typedef struct sdn_gemm_desc {
   int32_t out_kind;         /* SDN_OUT_*                                                       */
   int32_t rows_per_batch;   /* rows of one sample (H*W): row -> sample for rowbias / NCHW      */
   int32_t ld_rowbias;       /* leading dimension of rowbias [B, ld_rowbias]                    */
+  int32_t ld_rowgate;       /* leading dimension of rowgate [B, ld_rowgate]                    */
+  int32_t residual_bcast;   /* 1 = residual is [rows_per_batch, N], shared by every sample     */
   int32_t n_valid;          /* columns actually stored (0 = N); W is zero-padded to N rows     */
   int32_t ldc;              /* leading dimension of out/residual (0 = natural)                 */
 } sdn_gemm_desc;
 
-/* out = act(A.W^T + bias[n] + rowbias[b(m), n] + residual[m, n]).
+/* out = act((A.W^T + bias[n] + rowbias[b(m), n]) * rowgate[b(m), n] + residual[m, n])   (rowgate NULL = 1).
  * Replaces F.linear / conv2d(3x3 | 1x1) + the adds around them: ResnetBlock2D conv1 (+ time_emb_proj
  * broadcast), conv2 (+ shortcut), Downsample2D, Upsample2D, Transformer2DModel proj_in/proj_out
  * (models/transformer_2d.py:810-858), Attention to_q/k/v/out, FeedForward GEGLU (models/transformer_2d.py:335-355). */
 int sdn_gemm_bf16(const sdn_gemm_desc* d_host, const void* a, const void* a2, const void* w,
-                  const float* bias, const float* rowbias, const void* residual, void* out, void* stream);
+                  const float* bias, const float* rowbias, const float* rowgate, const void* residual, void* out,
+                  void* stream);
 /* Same operator with IEEE fp16 storage (the reference's SD-v3 dtype; 8x tighter parity than bf16). */
 int sdn_gemm_f16(const sdn_gemm_desc* d_host, const void* a, const void* a2, const void* w,
-                 const float* bias, const float* rowbias, const void* residual, void* out, void* stream);
+                 const float* bias, const float* rowbias, const float* rowgate, const void* residual, void* out,
+                 void* stream);
 
 /* GroupNorm (+ optional SiLU) over an NHWC bf16 map, optionally over the channel-concat of two maps
  * (x [B,HW,C1] ++ x2 [B,HW,C2]) written as ONE normalised map [B,HW,C1+C2].
@@ -209,7 +214,7 @@ int sdn_layernorm_f16(const void* x, int64_t rows, int32_t c, float eps, const f
 
 /* softmax(Q K^T * scale) V per (batch, head); flash-style, never materialises the score matrix.
  *   q [B, Nq, ldq] (head h at columns h*d .. h*d+d), k/v [B, Nk, ldk/ldv] likewise, out [B, Nq, ldo].
- * d in {40, 80, 160} (SD-v1.4: 8 heads at C = 320/640/1280) or 64 (MMDiT).  Nq % 32 == 0.
+ * d in {40, 80, 160} (SD-v1.4: 8 heads at C = 320/640/1280) or 64 (MMDiT).
  * Replaces F.scaled_dot_product_attention in diffusers' AttnProcessor2_0 (imported at
  * models/unet_2d_blocks.py:24; called from BasicTransformerBlock, models/transformer_2d.py:284-328). */
 int sdn_attention_bf16(const void* q, const void* k, const void* v, void* out, int32_t batch, int32_t heads,
@@ -218,6 +223,34 @@ int sdn_attention_bf16(const void* q, const void* k, const void* v, void* out, i
 int sdn_attention_f16(const void* q, const void* k, const void* v, void* out, int32_t batch, int32_t heads,
                       int32_t nq, int32_t nk, int32_t head_dim, int32_t ldq, int32_t ldk, int32_t ldv,
                       int32_t ldo, float scale, void* stream);
+
+/* Joint attention over TWO token streams kept in separate buffers (MMDiT: image tokens then text tokens):
+ * rows [0, n1) of the sequence come from q/k/v/out ([B, n1, ld*]), rows [n1, n_total) from the *2 pointers
+ * ([B, n_total - n1, ld*2]); the concatenated sequence is never materialised.  dtype 0 = bf16, 1 = f16.
+ * Replaces JointAttnProcessor2_0 (diffusers 0.29.0; reached through self.transformer(...),
+ * models/sdv3/safe_denoiser_pipeline.py:1120-1127). */
+typedef struct sdn_attn_segment2 {
+  const void* q2; const void* k2; const void* v2; void* out2;
+  int32_t n1, ldq2, ldk2, ldv2, ldo2;
+} sdn_attn_segment2;
+int sdn_joint_attention(int32_t dtype, const void* q, const void* k, const void* v, void* out,
+                        const sdn_attn_segment2* seg2_host, int32_t batch, int32_t heads, int32_t n_total,
+                        int32_t head_dim, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo, float scale,
+                        void* stream);
+
+/* adaLN layer norm: out = LN(x) * (1 + scale[b]) + shift[b]  (no affine; scale/shift are per-sample fp32 rows of
+ * leading dimension ld_mod; sample of a row = row / rows_per_batch).  AdaLayerNormZero / AdaLayerNormContinuous of
+ * the MMDiT blocks (diffusers 0.29.0). */
+int sdn_layernorm_mod_bf16(const void* x, int64_t rows, int32_t c, float eps, const float* scale, const float* shift,
+                           int32_t ld_mod, int32_t rows_per_batch, void* out, void* stream);
+int sdn_layernorm_mod_f16(const void* x, int64_t rows, int32_t c, float eps, const float* scale, const float* shift,
+                          int32_t ld_mod, int32_t rows_per_batch, void* out, void* stream);
+
+/* MMDiT PatchEmbed front end: fp32 NCHW latent -> 16-bit [B*(H/p)*(W/p), C*p*p] (column order (c,py,px)), so the
+ * patch embedding conv (k = s = p) is one GEMM; and the back end: fp32 tokens [.., p*p*C] -> fp32 NCHW latent. */
+int sdn_patchify_bf16(const float* latents, int32_t batch, int32_t c, int32_t h, int32_t w, int32_t p, void* out, void* stream);
+int sdn_patchify_f16(const float* latents, int32_t batch, int32_t c, int32_t h, int32_t w, int32_t p, void* out, void* stream);
+int sdn_unpatchify_f32(const float* tokens, int32_t batch, int32_t c, int32_t h, int32_t w, int32_t p, float* out, void* stream);
 
 /* conv_in: 3x3 conv of the fp32 NCHW latent [B,Cin<=16,H,W] into an NHWC bf16 map [B,H,W,Cout]
  * (models/unet.py:840).  w is [Cout][3][3][Cin] bf16, bias f32. */
@@ -252,6 +285,7 @@ typedef struct sdn_unet sdn_unet;   /* opaque: op plan + parameter manifest (hos
 #define SDN_P_CONV3X3     2   /* [out,in,3,3] -> bf16 [out][ky][kx][in], rows zero-padded      */
 #define SDN_P_GEGLU_MAT   3   /* [2F,in] -> bf16, rows interleaved value/gate in blocks of 16  */
 #define SDN_P_GEGLU_VEC   4   /* [2F] -> f32, interleaved the same way                         */
+#define SDN_P_POS_CROP    5   /* [1, max*max, C] -> 16-bit [h*w, C], centre crop (MMDiT pos_embed) */
 
 typedef struct sdn_param_info {
   char     name[128];       /* diffusers state_dict key                                          */
@@ -276,6 +310,25 @@ double sdn_unet_flops(sdn_unet* u, int32_t batch, double* attention_core_flops_h
  * ...threshold_time.py:538).  Replaces self.unet(latent_model_input, t, encoder_hidden_states=E).sample. */
 int sdn_unet_forward(sdn_unet* u, const void* weights, const float* latents, float timestep, const void* text,
                      float* out, int32_t batch, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- SD-v3 MMDiT (SD3Transformer2DModel, diffusers 0.29.0) -- same opaque handle type and the same
+ * param / workspace / flops / profile / destroy entry points as the UNet --------------------------------- */
+typedef struct sdn_mmdit_config {
+  int32_t in_channels, out_channels;     /* 16, 16                                                     */
+  int32_t sample_size, patch_size;       /* latent side (64 for 512x512 images, 128 for 1024x1024), 2  */
+  int32_t num_layers;                    /* 24                                                         */
+  int32_t num_heads, head_dim;           /* 24, 64                                                     */
+  int32_t joint_dim, pooled_dim;         /* 4096, 2048                                                 */
+  int32_t text_len;                      /* 333 = 77 CLIP + 256 T5 tokens                              */
+  int32_t time_dim;                      /* 256 sinusoidal features                                    */
+  int32_t dtype;                         /* 0 = bf16, 1 = fp16 (the reference runs SD-v3 in fp16)      */
+} sdn_mmdit_config;
+int sdn_mmdit_create(const sdn_mmdit_config* cfg_host, sdn_unet** out_host);
+/* v = transformer(latents [B,16,S,S] fp32, t, text [B,text_len,joint_dim] 16-bit, pooled [B,pooled_dim] 16-bit)
+ * -> out [B,16,S,S] fp32.  Replaces self.transformer(...)[0], models/sdv3/safe_denoiser_pipeline.py:1120-1127. */
+int sdn_mmdit_forward(sdn_unet* m, const void* weights, const float* latents, float timestep, const void* text,
+                      const void* pooled, float* out, int32_t batch, void* workspace, size_t workspace_bytes,
+                      void* stream);
 
 /* ---- opt-in measurement: HIP events around every launch of ONE forward, on the forward's own stream ---- */
 typedef struct sdn_profile_row {

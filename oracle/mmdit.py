@@ -1,0 +1,110 @@
+"""CPU oracle: SD-v3 MMDiT forward and the SD-v3 loop body (row P4), plain torch ops.
+
+TEST INFRASTRUCTURE -- see oracle/__init__.py.
+
+PARITY UNPINNED at the reference level: SD3Transformer2DModel lives only in diffusers==0.29.0 (absent here; the
+reference imports it at models/sdv3/safe_denoiser_pipeline.py:30 and calls it at :1120-1127) and the reference holds no
+tests for it.  This restates the published diffusers-0.29.0 definitions: PatchEmbed (conv k=s=2 + centre-cropped
+pos_embed), CombinedTimestepTextProjEmbeddings, JointTransformerBlock with AdaLayerNormZero (chunk order shift_msa,
+scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp), AdaLayerNormContinuous for the last block's context and for
+norm_out (chunk order scale, shift), JointAttnProcessor2_0 (image tokens then text tokens), FeedForward with
+GELU(approximate="tanh"), proj_out + unpatchify ("nhwpqc->nchpwq").  One structural fact pins the wiring: the
+SD3-medium configuration yields 2,028,328,000 transformer parameters (tests/test_unet_host.py).
+
+`act_dtype` emulates the engine's 16-bit storage points (weights and every tensor written to HBM as 16 bit).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+SD3 = dict(in_channels=16, out_channels=16, sample_size=64, patch_size=2, num_layers=24, num_heads=24, head_dim=64,
+           joint_dim=4096, pooled_dim=2048, pos_embed_max_size=192, time_dim=256)
+
+
+class OracleMMDiT:
+    def __init__(self, state_dict: dict, config: dict | None = None, act_dtype=None):
+        self.cfg = dict(SD3)
+        if config:
+            self.cfg.update(config)
+        self.q_dtype = act_dtype
+        self.sd = {}
+        for k, v in state_dict.items():
+            v = v.detach().float()
+            if act_dtype is not None and v.dim() > 1:
+                v = v.to(act_dtype).float()
+            self.sd[k] = v
+
+    def q(self, x):
+        return x if self.q_dtype is None else x.to(self.q_dtype).float()
+
+    def P(self, n):
+        return self.sd[n]
+
+    def lin(self, x, pfx):
+        return F.linear(x, self.P(pfx + ".weight"), self.P(pfx + ".bias"))
+
+    @staticmethod
+    def ln(x):
+        return F.layer_norm(x, (x.shape[-1],), eps=1e-6)
+
+    @torch.no_grad()
+    def __call__(self, hidden_states, timestep: float, encoder_hidden_states, pooled_projections):
+        c = self.cfg
+        C_ = c["num_heads"] * c["head_dim"]
+        b = hidden_states.shape[0]
+        ps, m = c["patch_size"], c["pos_embed_max_size"]
+        hp = c["sample_size"] // ps
+        # PatchEmbed
+        x = F.conv2d(self.q(hidden_states.float()), self.P("pos_embed.proj.weight"), self.P("pos_embed.proj.bias"), stride=ps)
+        x = x.flatten(2).transpose(1, 2)                                        # [B, N, C]
+        top = (m - hp) // 2
+        pos = self.P("pos_embed.pos_embed").reshape(m, m, -1)[top:top + hp, top:top + hp].reshape(1, hp * hp, -1)
+        x = self.q(x + pos)
+        # conditioning
+        half = c["time_dim"] // 2
+        fr = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+        ang = torch.full((b, 1), float(timestep)) * fr[None]
+        tsin = self.q(torch.cat([torch.cos(ang), torch.sin(ang)], -1))
+        te = self.q(F.silu(self.lin(tsin, "time_text_embed.timestep_embedder.linear_1")))
+        te = self.lin(te, "time_text_embed.timestep_embedder.linear_2")           # f32
+        pe = self.q(F.silu(self.lin(self.q(pooled_projections.float()), "time_text_embed.text_embedder.linear_1")))
+        pe = self.lin(pe, "time_text_embed.text_embedder.linear_2")
+        scond = self.q(F.silu(te + pe))
+        ctx = self.q(self.lin(self.q(encoder_hidden_states.float()), "context_embedder"))
+        L = c["num_layers"]
+        for i in range(L):
+            pfx = f"transformer_blocks.{i}"
+            last = i == L - 1
+            sh_a, sc_a, g_a, sh_m, sc_m, g_m = self.lin(scond, pfx + ".norm1.linear").chunk(6, dim=1)
+            xn = self.q(self.ln(x) * (1 + sc_a[:, None]) + sh_a[:, None])
+            if last:
+                c_sc, c_sh = self.lin(scond, pfx + ".norm1_context.linear").chunk(2, dim=1)
+                cn = self.q(self.ln(ctx) * (1 + c_sc[:, None]) + c_sh[:, None])
+            else:
+                c_sh_a, c_sc_a, c_g_a, c_sh_m, c_sc_m, c_g_m = self.lin(scond, pfx + ".norm1_context.linear").chunk(6, dim=1)
+                cn = self.q(self.ln(ctx) * (1 + c_sc_a[:, None]) + c_sh_a[:, None])
+            qx, kx, vx = (self.q(self.lin(xn, f"{pfx}.attn.to_{n}")) for n in "qkv")
+            qc, kc, vc = (self.q(self.lin(cn, f"{pfx}.attn.add_{n}_proj")) for n in "qkv")
+            N = x.shape[1]
+            sp = lambda t: t.reshape(b, -1, c["num_heads"], c["head_dim"]).transpose(1, 2)
+            a = F.scaled_dot_product_attention(sp(torch.cat([qx, qc], 1)), sp(torch.cat([kx, kc], 1)), sp(torch.cat([vx, vc], 1)))
+            a = self.q(a.transpose(1, 2).reshape(b, -1, C_))
+            ax, ac = a[:, :N], a[:, N:]
+            x = self.q(x + g_a[:, None] * self.lin(ax, pfx + ".attn.to_out.0"))
+            xm = self.q(self.ln(x) * (1 + sc_m[:, None]) + sh_m[:, None])
+            h = self.q(F.gelu(self.lin(xm, pfx + ".ff.net.0.proj"), approximate="tanh"))
+            x = self.q(x + g_m[:, None] * self.lin(h, pfx + ".ff.net.2"))
+            if not last:
+                ctx = self.q(ctx + c_g_a[:, None] * self.lin(ac, pfx + ".attn.to_add_out"))
+                cm = self.q(self.ln(ctx) * (1 + c_sc_m[:, None]) + c_sh_m[:, None])
+                hc = self.q(F.gelu(self.lin(cm, pfx + ".ff_context.net.0.proj"), approximate="tanh"))
+                ctx = self.q(ctx + c_g_m[:, None] * self.lin(hc, pfx + ".ff_context.net.2"))
+        sc, sh = self.lin(scond, "norm_out.linear").chunk(2, dim=1)
+        x = self.q(self.ln(x) * (1 + sc[:, None]) + sh[:, None])
+        tok = self.lin(x, "proj_out")                                               # [B, N, p*p*Cout] f32
+        co = c["out_channels"]
+        tok = tok.reshape(b, hp, hp, ps, ps, co)
+        return torch.einsum("nhwpqc->nchpwq", tok).reshape(b, co, hp * ps, hp * ps)

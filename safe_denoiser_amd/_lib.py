@@ -34,8 +34,8 @@ class RepelParams(C.Structure):
 
 class GemmDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("M", "N", "K", "a_mode", "K1", "Hs", "Ws", "Cin", "Ho", "Wo", "stride",
-                                         "upsample", "act", "out_kind", "rows_per_batch", "ld_rowbias", "n_valid",
-                                         "ldc")]
+                                         "upsample", "act", "out_kind", "rows_per_batch", "ld_rowbias", "ld_rowgate",
+                                         "residual_bcast", "n_valid", "ldc")]
 
 
 class UnetConfig(C.Structure):
@@ -48,6 +48,17 @@ class UnetConfig(C.Structure):
 class ProfileRow(C.Structure):
     _fields_ = [("kernel", C.c_char * 24), ("launches", C.c_int32), ("ms", C.c_double), ("flops", C.c_double),
                 ("bytes", C.c_double)]
+
+
+class MmditConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("in_channels", "out_channels", "sample_size", "patch_size", "num_layers",
+                                         "num_heads", "head_dim", "joint_dim", "pooled_dim", "text_len", "time_dim",
+                                         "dtype")]
+
+
+class AttnSegment2(C.Structure):
+    _fields_ = [("q2", C.c_void_p), ("k2", C.c_void_p), ("v2", C.c_void_p), ("out2", C.c_void_p), ("n1", C.c_int32),
+                ("ldq2", C.c_int32), ("ldk2", C.c_int32), ("ldv2", C.c_int32), ("ldo2", C.c_int32)]
 
 
 class ParamInfo(C.Structure):
@@ -72,8 +83,8 @@ SIGNATURES = {
     "sdn_flow_euler_step": (C.c_int, [_vp, _vp, _i64, _f32, _f32, _vp, _vp]),
     "sdn_flow_endpoints": (C.c_int, [_vp, _vp, _i64, _f32, _vp, _vp, _vp]),
     "sdn_flow_renoise": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp, _vp]),
-    "sdn_gemm_bf16": (C.c_int, [C.POINTER(GemmDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "sdn_gemm_f16": (C.c_int, [C.POINTER(GemmDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sdn_gemm_bf16": (C.c_int, [C.POINTER(GemmDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sdn_gemm_f16": (C.c_int, [C.POINTER(GemmDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sdn_groupnorm_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "sdn_groupnorm_f16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "sdn_layernorm_f16": (C.c_int, [_vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp]),
@@ -94,6 +105,15 @@ SIGNATURES = {
     "sdn_unet_workspace_bytes": (_sz, [_vp, _i32]),
     "sdn_unet_flops": (C.c_double, [_vp, _i32, C.POINTER(C.c_double)]),
     "sdn_unet_forward": (C.c_int, [_vp, _vp, _vp, _f32, _vp, _vp, _i32, _vp, _sz, _vp]),
+    "sdn_mmdit_create": (C.c_int, [C.POINTER(MmditConfig), C.POINTER(_vp)]),
+    "sdn_mmdit_forward": (C.c_int, [_vp, _vp, _vp, _f32, _vp, _vp, _vp, _i32, _vp, _sz, _vp]),
+    "sdn_joint_attention": (C.c_int, [_i32, _vp, _vp, _vp, _vp, C.POINTER(AttnSegment2), _i32, _i32, _i32, _i32, _i32,
+                                      _i32, _i32, _i32, _f32, _vp]),
+    "sdn_layernorm_mod_bf16": (C.c_int, [_vp, _i64, _i32, _f32, _vp, _vp, _i32, _i32, _vp, _vp]),
+    "sdn_layernorm_mod_f16": (C.c_int, [_vp, _i64, _i32, _f32, _vp, _vp, _i32, _i32, _vp, _vp]),
+    "sdn_patchify_bf16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "sdn_patchify_f16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "sdn_unpatchify_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "sdn_unet_profile_next": (None, [_vp]),
     "sdn_unet_profile_read": (C.c_int, [_vp, C.POINTER(ProfileRow), _i32]),
 }

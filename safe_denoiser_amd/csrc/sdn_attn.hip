@@ -35,9 +35,21 @@ struct AttnArgs {
   int nq, nk, ldq, ldk, ldv, ldo;
   float c;                   // scale * log2(e)
   int heads, nqb, npairs;    // q-blocks per (batch, head) pair; number of pairs
+  // optional second segment (MMDiT joint attention: rows [0,n1) = image tokens, [n1, n) = text tokens, each stream
+  // in its own buffer -> the concatenated sequence is never materialised)
+  const unsigned short* q2; const unsigned short* k2; const unsigned short* v2; unsigned short* out2;
+  int n1, ldq2, ldk2, ldv2, ldo2;
 };
 
-template <typename T, int HD>
+// Row `row` of sample b in a (possibly two-segment) [B, n, ld] tensor.
+template <bool SEG>
+__device__ __forceinline__ const unsigned short* row_ptr(const unsigned short* p1, const unsigned short* p2, int ld1,
+                                                          int ld2, int n1, int n, int b, int row) {
+  if (SEG && row >= n1) return p2 + ((long)b * (n - n1) + (row - n1)) * ld2;
+  return p1 + ((long)b * (SEG ? n1 : n) + row) * ld1;
+}
+
+template <typename T, int HD, bool SEG>
 __global__ void __launch_bounds__(THREADS)
 k_attn(const AttnArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -68,7 +80,7 @@ k_attn(const AttnArgs a) {
   }
   const int head = pair % a.heads, b = pair / a.heads;
   const int q0 = qblk * QB + wid * 32;
-  const bool qvalid = q0 < a.nq;
+  const bool qvalid = q0 + r < a.nq;             // per lane: the query tail (nq % 32 != 0) is clamped, not stored
 
   // ---- one-time LDS init: zero the padding columns, plant the ones column (both stages) ----
   {
@@ -87,7 +99,8 @@ k_attn(const AttnArgs a) {
   for (int s = 0; s < KQ; ++s) {
     const int dc = 16 * s + 8 * h;
     u32x4 v = (u32x4){0u, 0u, 0u, 0u};
-    if (qvalid && dc < HD) v = *reinterpret_cast<const u32x4*>(a.q + ((long)b * a.nq + q0 + r) * a.ldq + head * HD + dc);
+    if (qvalid && dc < HD)
+      v = *reinterpret_cast<const u32x4*>(row_ptr<SEG>(a.q, a.q2, a.ldq, a.ldq2, a.n1, a.nq, b, q0 + r) + head * HD + dc);
     qf[s] = *reinterpret_cast<typename T::v8*>(&v);
   }
 
@@ -110,13 +123,21 @@ k_attn(const AttnArgs a) {
     ld_dst[i] = live ? (isv ? KV * KSTR + row * VSTR : row * KSTR) + ch * 16 : -1;
     ld_src[i] = (isv ? a.v + (long)b * a.nk * a.ldv : a.k + (long)b * a.nk * a.ldk) + head * HD + ch * 8;
     ld_stride[i] = isv ? a.ldv : a.ldk;
+    if (SEG) { ld_stride[i] = isv; ld_src[i] = nullptr; ld_row[i] |= ch << 16; }    // segmented: resolved per tile
   }
   auto g_load = [&](int t) {
     const int k0 = t * KV;
 #pragma unroll
     for (int i = 0; i < NLOAD; ++i) {
-      const int krow = min(k0 + ld_row[i], a.nk - 1);
-      stg[i] = *reinterpret_cast<const u32x4*>(ld_src[i] + (long)krow * ld_stride[i]);
+      if (SEG) {
+        const int krow = min(k0 + (ld_row[i] & 0xffff), a.nk - 1), ch = ld_row[i] >> 16;
+        const unsigned short* rp = ld_stride[i] ? row_ptr<true>(a.v, a.v2, a.ldv, a.ldv2, a.n1, a.nk, b, krow)
+                                                : row_ptr<true>(a.k, a.k2, a.ldk, a.ldk2, a.n1, a.nk, b, krow);
+        stg[i] = *reinterpret_cast<const u32x4*>(rp + head * HD + ch * 8);
+      } else {
+        const int krow = min(k0 + ld_row[i], a.nk - 1);
+        stg[i] = *reinterpret_cast<const u32x4*>(ld_src[i] + (long)krow * ld_stride[i]);
+      }
     }
   };
   auto s_store = [&](int buf, int t) {
@@ -124,7 +145,7 @@ k_attn(const AttnArgs a) {
 #pragma unroll
     for (int i = 0; i < NLOAD; ++i) {
       if (ld_dst[i] >= 0) {
-        const u32x4 v = (k0 + ld_row[i] < a.nk) ? stg[i] : (u32x4){0u, 0u, 0u, 0u};
+        const u32x4 v = (k0 + (ld_row[i] & 0xffff) < a.nk) ? stg[i] : (u32x4){0u, 0u, 0u, 0u};
         *reinterpret_cast<u32x4*>(smem + buf * STAGE + ld_dst[i]) = v;
       }
     }
@@ -243,7 +264,7 @@ k_attn(const AttnArgs a) {
   }
   const float inv = 1.f / l_tot;
   if (qvalid) {
-    unsigned short* orow = a.out + ((long)b * a.nq + q0 + r) * a.ldo + head * HD;
+    unsigned short* orow = const_cast<unsigned short*>(row_ptr<SEG>(a.out, a.out2, a.ldo, a.ldo2, a.n1, a.nq, b, q0 + r)) + head * HD;
 #pragma unroll
     for (int d = 0; d < NDB; ++d)
 #pragma unroll
@@ -262,22 +283,33 @@ k_attn(const AttnArgs a) {
 
 template <typename T, int HD>
 int launch(const AttnArgs& a, int batch, int heads, hipStream_t st) {
-  hipLaunchKernelGGL((k_attn<T, HD>), dim3(a.nqb * a.npairs), dim3(THREADS), 0, st, a);
+  if (a.q2) hipLaunchKernelGGL((k_attn<T, HD, true>), dim3(a.nqb * a.npairs), dim3(THREADS), 0, st, a);
+  else hipLaunchKernelGGL((k_attn<T, HD, false>), dim3(a.nqb * a.npairs), dim3(THREADS), 0, st, a);
   return sdn_launch_status();
 }
 
 template <typename T>
 int run(const void* q, const void* k, const void* v, void* out, int32_t batch, int32_t heads, int32_t nq, int32_t nk,
-        int32_t head_dim, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo, float scale, void* stream) {
+        int32_t head_dim, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo, float scale, void* stream,
+        const sdn_attn_segment2* s2 = nullptr) {
   if (!q || !k || !v || !out || batch < 0 || heads <= 0 || nq <= 0 || nk <= 0) return SDN_E_INVALID;
-  if ((nq & 31) || (ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3)) return SDN_E_INVALID;
+  if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3) || nk > 65535) return SDN_E_INVALID;
   if (ldq < heads * head_dim || ldk < heads * head_dim || ldv < heads * head_dim || ldo < heads * head_dim)
     return SDN_E_INVALID;
   auto al = [](const void* p, int n) { return (reinterpret_cast<uintptr_t>(p) & (n - 1)) == 0; };
   if (!al(q, 16) || !al(k, 16) || !al(v, 16) || !al(out, 8)) return SDN_E_INVALID;
   if (batch == 0) return SDN_OK;
   AttnArgs a{(const unsigned short*)q, (const unsigned short*)k, (const unsigned short*)v, (unsigned short*)out,
-             nq, nk, ldq, ldk, ldv, ldo, scale * 1.4426950408889634f, heads, (nq + QB - 1) / QB, batch * heads};
+             nq, nk, ldq, ldk, ldv, ldo, scale * 1.4426950408889634f, heads, (nq + QB - 1) / QB, batch * heads,
+             nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0};
+  if (s2) {                                                  // joint attention over two token streams (nq == nk)
+    if (!s2->q2 || !s2->k2 || !s2->v2 || !s2->out2 || s2->n1 <= 0 || s2->n1 >= nq || nq != nk) return SDN_E_INVALID;
+    if ((s2->ldq2 & 7) || (s2->ldk2 & 7) || (s2->ldv2 & 7) || (s2->ldo2 & 3)) return SDN_E_INVALID;
+    if (!al(s2->q2, 16) || !al(s2->k2, 16) || !al(s2->v2, 16) || !al(s2->out2, 8)) return SDN_E_INVALID;
+    a.q2 = (const unsigned short*)s2->q2; a.k2 = (const unsigned short*)s2->k2; a.v2 = (const unsigned short*)s2->v2;
+    a.out2 = (unsigned short*)s2->out2; a.n1 = s2->n1;
+    a.ldq2 = s2->ldq2; a.ldk2 = s2->ldk2; a.ldv2 = s2->ldv2; a.ldo2 = s2->ldo2;
+  }
   hipStream_t st = (hipStream_t)stream;
   switch (head_dim) {
     case 40: return launch<T, 40>(a, batch, heads, st);
@@ -299,4 +331,15 @@ extern "C" int sdn_attention_f16(const void* q, const void* k, const void* v, vo
                                  int32_t heads, int32_t nq, int32_t nk, int32_t head_dim, int32_t ldq,
                                  int32_t ldk, int32_t ldv, int32_t ldo, float scale, void* stream) {
   return sdn_attn_detail::run<SdnF16>(q, k, v, out, batch, heads, nq, nk, head_dim, ldq, ldk, ldv, ldo, scale, stream);
+}
+extern "C" int sdn_joint_attention(int32_t dtype, const void* q, const void* k, const void* v, void* out,
+                                   const sdn_attn_segment2* seg2, int32_t batch, int32_t heads, int32_t n_total,
+                                   int32_t head_dim, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo, float scale,
+                                   void* stream) {
+  if (!seg2) return SDN_E_INVALID;
+  if (dtype == 1)
+    return sdn_attn_detail::run<SdnF16>(q, k, v, out, batch, heads, n_total, n_total, head_dim, ldq, ldk, ldv, ldo, scale,
+                                        stream, seg2);
+  return sdn_attn_detail::run<SdnBF16>(q, k, v, out, batch, heads, n_total, n_total, head_dim, ldq, ldk, ldv, ldo, scale,
+                                       stream, seg2);
 }

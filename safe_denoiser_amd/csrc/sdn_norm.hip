@@ -140,10 +140,16 @@ k_gn_apply(const unsigned short* __restrict__ x, const unsigned short* __restric
 template <typename T>
 __global__ void __launch_bounds__(THREADS)
 k_layernorm(const unsigned short* __restrict__ x, long rows, int C, float eps, const float* __restrict__ gamma,
-            const float* __restrict__ beta, unsigned short* __restrict__ out) {
+            const float* __restrict__ beta, unsigned short* __restrict__ out, int mod, int rows_per_batch, int ld_mod) {
+  // mod = 0: y = LN(x) * gamma[c] + beta[c]            (BasicTransformerBlock norms)
+  // mod = 1: y = LN(x) * (1 + gamma[b, c]) + beta[b, c] (adaLN: gamma = scale, beta = shift, per-sample rows of ld_mod)
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
+  if (mod) {
+    const long b = row / rows_per_batch;
+    gamma += b * ld_mod; beta += b * ld_mod;
+  }
   const int cchunks = C / 8;
   float f[4][8];
   float s = 0.f;
@@ -177,7 +183,7 @@ k_layernorm(const unsigned short* __restrict__ x, long rows, int C, float eps, c
       const float bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
       float y[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) y[k] = (f[q][k] - mean) * rstd * gm[k] + bt[k];
+      for (int k = 0; k < 8; ++k) y[k] = (f[q][k] - mean) * rstd * (mod ? 1.f + gm[k] : gm[k]) + bt[k];
       *reinterpret_cast<u32x4*>(out + row * C + cc * 8) = pack8<T>(y);
     }
   }
@@ -276,12 +282,54 @@ int groupnorm_impl(const void* x, const void* x2, int32_t batch, int32_t hw, int
 
 template <typename T>
 int layernorm_impl(const void* x, int64_t rows, int32_t c, float eps, const float* gamma, const float* beta, void* out,
-                   void* stream) {
+                   void* stream, int mod = 0, int rows_per_batch = 0, int ld_mod = 0) {
   if (!x || !gamma || !beta || !out || rows < 0 || c <= 0 || (c & 7) || c > 2048) return SDN_E_INVALID;
   if (!al16(x) || !al16(out) || !al16(gamma) || !al16(beta)) return SDN_E_INVALID;
+  if (mod && (rows_per_batch <= 0 || ld_mod < c || (ld_mod & 3))) return SDN_E_INVALID;
   if (rows == 0) return SDN_OK;
   hipLaunchKernelGGL((k_layernorm<T>), dim3((unsigned)((rows + 3) / 4)), dim3(THREADS), 0, (hipStream_t)stream,
-                     (const unsigned short*)x, (long)rows, c, eps, gamma, beta, (unsigned short*)out);
+                     (const unsigned short*)x, (long)rows, c, eps, gamma, beta, (unsigned short*)out, mod, rows_per_batch,
+                     ld_mod);
+  return sdn_launch_status();
+}
+
+// ---- MMDiT patch embedding front / back ends ----------------------------------------------------------
+// patchify: fp32 NCHW latent [B,C,H,W] -> 16-bit [B*(H/p)*(W/p), C*p*p], column order (c, py, px) = the flattened
+// conv weight [O, C, p, p] of PatchEmbed.proj, so the patch embedding is one GEMM (K = C*p*p = 64 for SD-v3).
+template <typename T>
+__global__ void __launch_bounds__(THREADS)
+k_patchify(const float* __restrict__ lat, int B, int C, int H, int W, int p, unsigned short* __restrict__ out) {
+  const int hp = H / p, wp = W / p, K = C * p * p;
+  const long total = (long)B * hp * wp * K;
+  for (long e = (long)blockIdx.x * THREADS + threadIdx.x; e < total; e += (long)gridDim.x * THREADS) {
+    const int k = (int)(e % K);
+    const long tok = e / K;
+    const int px = k % p, py = (k / p) % p, c = k / (p * p);
+    const int tx = (int)(tok % wp), ty = (int)((tok / wp) % hp), b = (int)(tok / ((long)wp * hp));
+    const float v = lat[(((long)b * C + c) * H + ty * p + py) * W + tx * p + px];
+    out[e] = (unsigned short)(T::pack2(v, 0.f) & 0xffff);
+  }
+}
+// unpatchify: fp32 tokens [B*hp*wp, p*p*C] (column = (py*p + px)*C + c, diffusers' "nhwpqc->nchpwq") -> fp32 NCHW.
+__global__ void __launch_bounds__(THREADS)
+k_unpatchify(const float* __restrict__ tok, int B, int C, int H, int W, int p, float* __restrict__ out) {
+  const int hp = H / p, wp = W / p;
+  const long total = (long)B * C * H * W;
+  for (long e = (long)blockIdx.x * THREADS + threadIdx.x; e < total; e += (long)gridDim.x * THREADS) {
+    const int x = (int)(e % W), y = (int)((e / W) % H), c = (int)((e / ((long)W * H)) % C), b = (int)(e / ((long)W * H * C));
+    const long t = ((long)b * hp + y / p) * wp + x / p;
+    out[e] = tok[t * (p * p * C) + ((y % p) * p + (x % p)) * C + c];
+  }
+}
+template <typename T>
+int patchify_impl(const float* lat, int32_t B, int32_t C, int32_t H, int32_t W, int32_t p, void* out, void* stream) {
+  if (!lat || !out || B < 0 || C <= 0 || H <= 0 || W <= 0 || p <= 0 || H % p || W % p) return SDN_E_INVALID;
+  if (B == 0) return SDN_OK;
+  const long total = (long)B * C * H * W;
+  long grid = (total + THREADS - 1) / THREADS;
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL((k_patchify<T>), dim3((unsigned)grid), dim3(THREADS), 0, (hipStream_t)stream, lat, B, C, H, W, p,
+                     (unsigned short*)out);
   return sdn_launch_status();
 }
 
@@ -325,6 +373,15 @@ using namespace sdn_norm_detail;
                                      const float* beta, void* out, void* stream) {                                      \
     return layernorm_impl<T>(x, rows, c, eps, gamma, beta, out, stream);                                                \
   }                                                                                                                     \
+  extern "C" int sdn_layernorm_mod_##SUF(const void* x, int64_t rows, int32_t c, float eps, const float* scale,        \
+                                         const float* shift, int32_t ld_mod, int32_t rows_per_batch, void* out,        \
+                                         void* stream) {                                                                \
+    return layernorm_impl<T>(x, rows, c, eps, scale, shift, out, stream, 1, rows_per_batch, ld_mod);                    \
+  }                                                                                                                     \
+  extern "C" int sdn_patchify_##SUF(const float* lat, int32_t B, int32_t C, int32_t H, int32_t W, int32_t p, void* out, \
+                                    void* stream) {                                                                     \
+    return patchify_impl<T>(lat, B, C, H, W, p, out, stream);                                                           \
+  }                                                                                                                     \
   extern "C" int sdn_conv_in_##SUF(const float* lat, const void* w, const float* bias, int32_t batch, int32_t cin,     \
                                    int32_t h, int32_t wd, int32_t cout, void* out, void* stream) {                      \
     return conv_in_impl<T>(lat, w, bias, batch, cin, h, wd, cout, out, stream);                                         \
@@ -334,3 +391,14 @@ using namespace sdn_norm_detail;
   }
 SDN_NORM_ENTRY(bf16, SdnBF16)
 SDN_NORM_ENTRY(f16, SdnF16)
+
+extern "C" int sdn_unpatchify_f32(const float* tok, int32_t B, int32_t C, int32_t H, int32_t W, int32_t p, float* out,
+                                  void* stream) {
+  if (!tok || !out || B < 0 || C <= 0 || H <= 0 || W <= 0 || p <= 0 || H % p || W % p) return SDN_E_INVALID;
+  if (B == 0) return SDN_OK;
+  const long total = (long)B * C * H * W;
+  long grid = (total + THREADS - 1) / THREADS;
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(k_unpatchify, dim3((unsigned)grid), dim3(THREADS), 0, (hipStream_t)stream, tok, B, C, H, W, p, out);
+  return sdn_launch_status();
+}

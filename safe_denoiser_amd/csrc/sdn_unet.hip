@@ -32,15 +32,17 @@
 
 namespace {
 
-enum Space { SP_NONE = 0, SP_W = 1, SP_WS = 2, SP_LATENTS = 3, SP_TEXT = 4, SP_OUT = 5 };
+enum Space { SP_NONE = 0, SP_W = 1, SP_WS = 2, SP_LATENTS = 3, SP_TEXT = 4, SP_OUT = 5, SP_POOLED = 6 };
 struct Ref { int space = SP_NONE; int64_t off = 0; };
 
-enum OpKind { OP_TEMB, OP_CONV_IN, OP_GEMM, OP_GN, OP_LN, OP_ATTN };
+enum OpKind { OP_TEMB, OP_CONV_IN, OP_GEMM, OP_GN, OP_LN, OP_ATTN, OP_PATCHIFY, OP_UNPATCHIFY };
 
 struct Op {
   int kind;
   sdn_gemm_desc gd;
-  Ref a, a2, w, bias, rowbias, residual, out, aux;
+  Ref a, a2, w, bias, rowbias, rowgate, residual, out, aux;
+  Ref q2, k2, v2, out2;      // joint attention: second token stream
+  int n1 = 0, mod = 0, ld_mod = 0, patch = 0;
   // GN / LN / conv_in / attention scalars
   int batch = 0, hw = 0, c1 = 0, c2 = 0, groups = 0, silu = 0;
   float eps = 0.f;
@@ -110,6 +112,8 @@ struct Plan {
 
 struct sdn_unet {
   sdn_unet_config cfg;
+  sdn_mmdit_config mcfg;
+  bool is_mmdit = false;
   std::vector<sdn_param_info> params;
   std::map<std::string, int> param_index;
   int64_t weight_bytes = 0;
@@ -318,6 +322,195 @@ struct Builder {
     return out;
   }
 
+
+  // =====================================================================================================
+  //  SD-v3 MMDiT (SD3Transformer2DModel, diffusers 0.29.0; row U7) -- reached through self.transformer(...) at
+  //  models/sdv3/safe_denoiser_pipeline.py:1120-1127.  Two token streams (image, text) with adaLN-zero
+  //  modulation from (timestep, pooled text); joint attention over both streams without concatenating them.
+  // =====================================================================================================
+  void gemm_ex(int64_t M, int N, int K, Ref a, Ref w, Ref bias, Ref out, int act_, Ref residual, int out_kind,
+               Ref rowbias, Ref rowgate, int rows_per_batch, int ld_row, int residual_bcast = 0) {
+    Op o; o.kind = OP_GEMM; memset(&o.gd, 0, sizeof(o.gd));
+    o.gd.M = (int)M; o.gd.N = N; o.gd.K = K; o.gd.a_mode = SDN_A_PLAIN; o.gd.act = act_; o.gd.out_kind = out_kind;
+    o.gd.rows_per_batch = rows_per_batch; o.gd.ld_rowbias = ld_row; o.gd.ld_rowgate = ld_row;
+    o.gd.residual_bcast = residual_bcast;
+    o.a = a; o.w = w; o.bias = bias; o.rowbias = rowbias; o.rowgate = rowgate; o.residual = residual; o.out = out;
+    o.flops = 2.0 * (double)M * N * K;
+    o.bytes = 2.0 * ((double)M * K + (double)N * K + (double)M * N);
+    snprintf(o.label, sizeof(o.label), "k_gemm<%d>", sdn_gemm_pick_nrep(N, act_));
+    plan->ops.push_back(o);
+    plan->flops += o.flops;
+  }
+  void ln_mod(const Act& x, int64_t rows, int rows_per_batch, Ref scale, Ref shift, int ld, const Act& out) {
+    Op o; o.kind = OP_LN; o.a = R(x); o.rows = rows; o.c1 = x.C; o.eps = 1e-6f; o.w = scale; o.bias = shift; o.out = R(out);
+    o.mod = 1; o.ld_mod = ld; o.hw = rows_per_batch;
+    o.bytes = 2.0 * 2.0 * (double)rows * x.C;
+    snprintf(o.label, sizeof(o.label), "k_layernorm");
+    plan->ops.push_back(o);
+  }
+  Ref fcol(int col) const { return Ref{SP_WS, tproj.off + (int64_t)col * 4}; }   // column of the stacked adaLN output
+
+  void build_mmdit() {
+    const sdn_mmdit_config& c = u->mcfg;
+    const int C = c.num_heads * c.head_dim, S = c.sample_size, ps = c.patch_size, hp = S / ps, N = hp * hp;
+    const int T = c.text_len, L = c.num_layers, KP = c.in_channels * ps * ps;
+    char buf[128];
+    auto nm = [&](int i, const char* suffix) { snprintf(buf, sizeof(buf), "transformer_blocks.%d.%s", i, suffix); return std::string(buf); };
+
+    // ---- parameters of the conditioning path ----
+    Ref pew = param("pos_embed.proj.weight", SDN_P_MAT, C, KP), peb = param("pos_embed.proj.bias", SDN_P_VEC_F32, C, 0);
+    Ref pos = param("pos_embed.pos_embed", SDN_P_POS_CROP, N, C);
+    Ref t1w = param("time_text_embed.timestep_embedder.linear_1.weight", SDN_P_MAT, C, c.time_dim), t1b = param("time_text_embed.timestep_embedder.linear_1.bias", SDN_P_VEC_F32, C, 0);
+    Ref t2w = param("time_text_embed.timestep_embedder.linear_2.weight", SDN_P_MAT, C, C), t2b = param("time_text_embed.timestep_embedder.linear_2.bias", SDN_P_VEC_F32, C, 0);
+    Ref p1w = param("time_text_embed.text_embedder.linear_1.weight", SDN_P_MAT, C, c.pooled_dim), p1b = param("time_text_embed.text_embedder.linear_1.bias", SDN_P_VEC_F32, C, 0);
+    Ref p2w = param("time_text_embed.text_embedder.linear_2.weight", SDN_P_MAT, C, C), p2b = param("time_text_embed.text_embedder.linear_2.bias", SDN_P_VEC_F32, C, 0);
+    Ref cew = param("context_embedder.weight", SDN_P_MAT, C, c.joint_dim), ceb = param("context_embedder.bias", SDN_P_VEC_F32, C, 0);
+
+    // ---- ALL adaLN linears stacked into one [sum, C] matrix: one GEMM per forward ----
+    // column layout per block i: img 6C at col_img[i], ctx 6C (2C for the last, context_pre_only block) at col_ctx[i]
+    std::vector<int> col_img(L), col_ctx(L);
+    int total = 0;
+    Ref adw, adb;
+    {
+      std::vector<std::pair<std::string, int>> mods;
+      for (int i = 0; i < L; ++i) {
+        col_img[i] = total; mods.push_back({nm(i, "norm1.linear"), 6 * C}); total += 6 * C;
+        const int nc = (i == L - 1) ? 2 * C : 6 * C;
+        col_ctx[i] = total; mods.push_back({nm(i, "norm1_context.linear"), nc}); total += nc;
+      }
+      const int col_out = total; mods.push_back({"norm_out.linear", 2 * C}); total += 2 * C;
+      (void)col_out;
+      int64_t expect = -1;
+      for (size_t j = 0; j < mods.size(); ++j) {
+        Ref r = param(mods[j].first + ".weight", SDN_P_MAT, mods[j].second, C);
+        if (j == 0) adw = r; else if (r.off != expect) { fprintf(stderr, "libsdn: adaLN weights not contiguous\n"); abort(); }
+        expect = r.off + (int64_t)mods[j].second * C * 2;
+      }
+      expect = -1;
+      for (size_t j = 0; j < mods.size(); ++j) {
+        Ref r = param(mods[j].first + ".bias", SDN_P_VEC_F32, mods[j].second, 0);
+        if (j == 0) adb = r; else if (r.off != expect) { fprintf(stderr, "libsdn: adaLN biases not contiguous\n"); abort(); }
+        expect = r.off + (int64_t)mods[j].second * 4;
+      }
+    }
+    u->tproj_total = total;
+
+    // ---- conditioning: silu(time_emb + pooled_emb) -> all modulation vectors ----
+    Act tsin = act(B, c.time_dim);
+    { Op o; o.kind = OP_TEMB; o.batch = B; o.c1 = c.time_dim; o.out = R(tsin); snprintf(o.label, sizeof(o.label), "k_temb"); plan->ops.push_back(o); }
+    Act th = act(B, C);
+    gemm_ex(B, C, c.time_dim, R(tsin), t1w, t1b, R(th), SDN_ACT_SILU, Ref(), SDN_OUT_BF16, Ref(), Ref(), 0, 0);
+    drop(tsin);
+    Act temb = act(B, C, 0, 0, 4);                                                 // f32 [B, C]
+    gemm_ex(B, C, C, R(th), t2w, t2b, R(temb), SDN_ACT_NONE, Ref(), SDN_OUT_F32, Ref(), Ref(), 0, 0);
+    drop(th);
+    Act ph = act(B, C);
+    gemm_ex(B, C, c.pooled_dim, Ref{SP_POOLED, 0}, p1w, p1b, R(ph), SDN_ACT_SILU, Ref(), SDN_OUT_BF16, Ref(), Ref(), 0, 0);
+    Act scond = act(B, C);                                                         // silu(time_emb + pooled_emb)
+    gemm_ex(B, C, C, R(ph), p2w, p2b, R(scond), SDN_ACT_SILU, Ref(), SDN_OUT_BF16, R(temb), Ref(), 1, C);
+    drop(ph); drop(temb);
+    Act mods = act(B, total, 0, 0, 4);
+    tproj = R(mods);
+    gemm_ex(B, total, C, R(scond), adw, adb, R(mods), SDN_ACT_NONE, Ref(), SDN_OUT_F32, Ref(), Ref(), 0, 0);
+    drop(scond);
+
+    // ---- token streams ----
+    Act patches = act((int64_t)B * N, KP);
+    { Op o; o.kind = OP_PATCHIFY; o.batch = B; o.c1 = c.in_channels; o.hw = S; o.patch = ps; o.a = Ref{SP_LATENTS, 0}; o.out = R(patches);
+      o.bytes = (double)B * N * KP * 6.0; snprintf(o.label, sizeof(o.label), "k_patchify"); plan->ops.push_back(o); }
+    Act x = act((int64_t)B * N, C, N);
+    gemm_ex((int64_t)B * N, C, KP, R(patches), pew, peb, R(x), SDN_ACT_NONE, pos, SDN_OUT_BF16, Ref(), Ref(), N, 0, 1);
+    drop(patches);
+    Act ctx = act((int64_t)B * T, C, T);
+    gemm_ex((int64_t)B * T, C, c.joint_dim, Ref{SP_TEXT, 0}, cew, ceb, R(ctx), SDN_ACT_NONE, Ref(), SDN_OUT_BF16, Ref(), Ref(), 0, 0);
+
+    for (int i = 0; i < L; ++i) {
+      const bool last = (i == L - 1);
+      const int ci = col_img[i], cc = col_ctx[i];
+      // AdaLayerNormZero chunk order: shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+      // AdaLayerNormContinuous (last block's context): scale, shift
+      Ref qkvw = stacked({nm(i, "attn.to_q.weight"), nm(i, "attn.to_k.weight"), nm(i, "attn.to_v.weight")}, C, C);
+      Ref qkvb; { Ref r0 = param(nm(i, "attn.to_q.bias"), SDN_P_VEC_F32, C, 0); param(nm(i, "attn.to_k.bias"), SDN_P_VEC_F32, C, 0); param(nm(i, "attn.to_v.bias"), SDN_P_VEC_F32, C, 0); qkvb = r0; }
+      Ref aqkvw = stacked({nm(i, "attn.add_q_proj.weight"), nm(i, "attn.add_k_proj.weight"), nm(i, "attn.add_v_proj.weight")}, C, C);
+      Ref aqkvb; { Ref r0 = param(nm(i, "attn.add_q_proj.bias"), SDN_P_VEC_F32, C, 0); param(nm(i, "attn.add_k_proj.bias"), SDN_P_VEC_F32, C, 0); param(nm(i, "attn.add_v_proj.bias"), SDN_P_VEC_F32, C, 0); aqkvb = r0; }
+      Ref ow = param(nm(i, "attn.to_out.0.weight"), SDN_P_MAT, C, C), ob = param(nm(i, "attn.to_out.0.bias"), SDN_P_VEC_F32, C, 0);
+      Ref f1w = param(nm(i, "ff.net.0.proj.weight"), SDN_P_MAT, 4 * C, C), f1b = param(nm(i, "ff.net.0.proj.bias"), SDN_P_VEC_F32, 4 * C, 0);
+      Ref f2w = param(nm(i, "ff.net.2.weight"), SDN_P_MAT, C, 4 * C), f2b = param(nm(i, "ff.net.2.bias"), SDN_P_VEC_F32, C, 0);
+
+      Act xn = act((int64_t)B * N, C, N);
+      ln_mod(x, (int64_t)B * N, N, fcol(ci + 1 * C), fcol(ci + 0 * C), total, xn);
+      Act cn = act((int64_t)B * T, C, T);
+      if (last) ln_mod(ctx, (int64_t)B * T, T, fcol(cc + 0 * C), fcol(cc + 1 * C), total, cn);
+      else ln_mod(ctx, (int64_t)B * T, T, fcol(cc + 1 * C), fcol(cc + 0 * C), total, cn);
+      Act qx = act((int64_t)B * N, 3 * C, N), qc = act((int64_t)B * T, 3 * C, T);
+      gemm_ex((int64_t)B * N, 3 * C, C, R(xn), qkvw, qkvb, R(qx), SDN_ACT_NONE, Ref(), SDN_OUT_BF16, Ref(), Ref(), 0, 0);
+      gemm_ex((int64_t)B * T, 3 * C, C, R(cn), aqkvw, aqkvb, R(qc), SDN_ACT_NONE, Ref(), SDN_OUT_BF16, Ref(), Ref(), 0, 0);
+      drop(xn); drop(cn);
+      Act ax = act((int64_t)B * N, C, N), ac = act((int64_t)B * T, C, T);
+      {
+        Op o; o.kind = OP_ATTN; o.batch = B; o.heads = c.num_heads; o.nq = N + T; o.nk = N + T; o.hd = c.head_dim;
+        o.a = R(qx); o.k = Ref{SP_WS, qx.off + (int64_t)C * 2}; o.v = Ref{SP_WS, qx.off + (int64_t)2 * C * 2}; o.out = R(ax);
+        o.q2 = R(qc); o.k2 = Ref{SP_WS, qc.off + (int64_t)C * 2}; o.v2 = Ref{SP_WS, qc.off + (int64_t)2 * C * 2}; o.out2 = R(ac);
+        o.n1 = N; o.ldq = o.ldk = o.ldv = 3 * C; o.ldo = C; o.scale = 1.0f / sqrtf((float)c.head_dim);
+        o.flops = 4.0 * (double)B * o.heads * (double)(N + T) * (double)(N + T) * o.hd;
+        o.bytes = 2.0 * (double)B * (N + T) * C * 4.0;
+        snprintf(o.label, sizeof(o.label), "k_attn<%d>", o.hd);
+        plan->ops.push_back(o);
+        plan->flops += o.flops; plan->attn_flops += o.flops;
+      }
+      drop(qx); drop(qc);
+      // image stream: x += gate_msa * to_out(attn);  x += gate_mlp * ff(LNmod(x))
+      Act x2 = act((int64_t)B * N, C, N);
+      gemm_ex((int64_t)B * N, C, C, R(ax), ow, ob, R(x2), SDN_ACT_NONE, R(x), SDN_OUT_BF16, Ref(), fcol(ci + 2 * C), N, total);
+      drop(ax); drop(x);
+      Act xm = act((int64_t)B * N, C, N);
+      ln_mod(x2, (int64_t)B * N, N, fcol(ci + 4 * C), fcol(ci + 3 * C), total, xm);
+      Act hx = act((int64_t)B * N, 4 * C, N);
+      gemm_ex((int64_t)B * N, 4 * C, C, R(xm), f1w, f1b, R(hx), SDN_ACT_GELU_TANH, Ref(), SDN_OUT_BF16, Ref(), Ref(), 0, 0);
+      drop(xm);
+      Act x3 = act((int64_t)B * N, C, N);
+      gemm_ex((int64_t)B * N, C, 4 * C, R(hx), f2w, f2b, R(x3), SDN_ACT_NONE, R(x2), SDN_OUT_BF16, Ref(), fcol(ci + 5 * C), N, total);
+      drop(hx); drop(x2);
+      x = x3;
+      // text stream (skipped in the last block: context_pre_only)
+      if (!last) {
+        Ref aow = param(nm(i, "attn.to_add_out.weight"), SDN_P_MAT, C, C), aob = param(nm(i, "attn.to_add_out.bias"), SDN_P_VEC_F32, C, 0);
+        Ref g1w = param(nm(i, "ff_context.net.0.proj.weight"), SDN_P_MAT, 4 * C, C), g1b = param(nm(i, "ff_context.net.0.proj.bias"), SDN_P_VEC_F32, 4 * C, 0);
+        Ref g2w = param(nm(i, "ff_context.net.2.weight"), SDN_P_MAT, C, 4 * C), g2b = param(nm(i, "ff_context.net.2.bias"), SDN_P_VEC_F32, C, 0);
+        Act c2 = act((int64_t)B * T, C, T);
+        gemm_ex((int64_t)B * T, C, C, R(ac), aow, aob, R(c2), SDN_ACT_NONE, R(ctx), SDN_OUT_BF16, Ref(), fcol(cc + 2 * C), T, total);
+        drop(ctx);
+        Act cm = act((int64_t)B * T, C, T);
+        ln_mod(c2, (int64_t)B * T, T, fcol(cc + 4 * C), fcol(cc + 3 * C), total, cm);
+        Act hc = act((int64_t)B * T, 4 * C, T);
+        gemm_ex((int64_t)B * T, 4 * C, C, R(cm), g1w, g1b, R(hc), SDN_ACT_GELU_TANH, Ref(), SDN_OUT_BF16, Ref(), Ref(), 0, 0);
+        drop(cm);
+        Act c3 = act((int64_t)B * T, C, T);
+        gemm_ex((int64_t)B * T, C, 4 * C, R(hc), g2w, g2b, R(c3), SDN_ACT_NONE, R(c2), SDN_OUT_BF16, Ref(), fcol(cc + 5 * C), T, total);
+        drop(hc); drop(c2);
+        ctx = c3;
+      } else {
+        drop(ctx);
+      }
+      drop(ac);
+    }
+    // ---- norm_out (AdaLayerNormContinuous: scale, shift) + proj_out + unpatchify ----
+    const int col_out = total - 2 * C;
+    Act xo = act((int64_t)B * N, C, N);
+    ln_mod(x, (int64_t)B * N, N, fcol(col_out), fcol(col_out + C), total, xo);
+    drop(x);
+    const int PO = ps * ps * c.out_channels;
+    Ref pw = param("proj_out.weight", SDN_P_MAT, PO, C), pb = param("proj_out.bias", SDN_P_VEC_F32, PO, 0);
+    Act tok = act((int64_t)B * N, PO, N, 0, 4);
+    gemm_ex((int64_t)B * N, PO, C, R(xo), pw, pb, R(tok), SDN_ACT_NONE, Ref(), SDN_OUT_F32, Ref(), Ref(), 0, 0);
+    drop(xo);
+    { Op o; o.kind = OP_UNPATCHIFY; o.batch = B; o.c1 = c.out_channels; o.hw = S; o.patch = ps; o.a = R(tok); o.out = Ref{SP_OUT, 0};
+      o.bytes = (double)B * N * PO * 8.0; snprintf(o.label, sizeof(o.label), "k_unpatchify"); plan->ops.push_back(o); }
+    drop(tok);
+    drop(mods);
+    plan->ws_bytes = arena.peak;
+  }
+
   struct Res { std::string pfx; int cout; };
   // Walk the architecture once to list every resnet (execution order) -> stacked time_emb_proj.
   std::vector<Res> enumerate_resnets() const {
@@ -473,17 +666,19 @@ Plan* get_plan(sdn_unet* u, int batch) {
   p.batch = batch;
   Builder b{u, &p};
   b.B = batch;
-  b.build();
+  if (u->is_mmdit) b.build_mmdit(); else b.build();
   return &p;
 }
 
-inline const char* resolve(const Ref& r, const char* w, const char* ws, const char* lat, const char* text, const char* out) {
+inline const char* resolve(const Ref& r, const char* w, const char* ws, const char* lat, const char* text, const char* out,
+                           const char* pooled) {
   switch (r.space) {
     case SP_W: return w + r.off;
     case SP_WS: return ws + r.off;
     case SP_LATENTS: return lat + r.off;
     case SP_TEXT: return text + r.off;
     case SP_OUT: return out + r.off;
+    case SP_POOLED: return pooled + r.off;
     default: return nullptr;
   }
 }
@@ -517,6 +712,25 @@ int sdn_unet_create(const sdn_unet_config* cfg, sdn_unet** out) {
   return SDN_OK;
 }
 
+int sdn_mmdit_create(const sdn_mmdit_config* cfg, sdn_unet** out) {
+  if (!cfg || !out) return SDN_E_INVALID;
+  const int C = cfg->num_heads * cfg->head_dim;
+  if (cfg->in_channels <= 0 || cfg->out_channels <= 0 || cfg->sample_size <= 0 || cfg->patch_size <= 0 ||
+      cfg->sample_size % cfg->patch_size != 0 || cfg->num_layers <= 0 || cfg->num_heads <= 0 || cfg->head_dim != 64 ||
+      C % 128 != 0 || cfg->joint_dim % 64 != 0 || cfg->pooled_dim % 64 != 0 || cfg->time_dim % 64 != 0 ||
+      (cfg->in_channels * cfg->patch_size * cfg->patch_size) % 64 != 0 ||
+      (cfg->out_channels * cfg->patch_size * cfg->patch_size) % 32 != 0 || cfg->text_len <= 0 || cfg->dtype < 0 ||
+      cfg->dtype > 1 || C > 2048)
+    return SDN_E_INVALID;
+  sdn_unet* u = new sdn_unet();
+  memset(&u->cfg, 0, sizeof(u->cfg));
+  u->mcfg = *cfg;
+  u->is_mmdit = true;
+  get_plan(u, 1);
+  *out = u;
+  return SDN_OK;
+}
+
 void sdn_unet_destroy(sdn_unet* u) { delete u; }
 
 int sdn_unet_param_count(const sdn_unet* u) { return u ? (int)u->params.size() : 0; }
@@ -541,14 +755,31 @@ double sdn_unet_flops(sdn_unet* u, int32_t batch, double* attn) {
   return p->flops;
 }
 
+static int run_plan(sdn_unet* u, const void* weights, const float* latents, float timestep, const void* text,
+                    const void* pooled, float* out, int32_t batch, void* workspace, size_t workspace_bytes, void* stream);
+
 int sdn_unet_forward(sdn_unet* u, const void* weights, const float* latents, float timestep, const void* text,
                      float* out, int32_t batch, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!u || u->is_mmdit) return SDN_E_INVALID;
+  return run_plan(u, weights, latents, timestep, text, nullptr, out, batch, workspace, workspace_bytes, stream);
+}
+
+int sdn_mmdit_forward(sdn_unet* u, const void* weights, const float* latents, float timestep, const void* text,
+                      const void* pooled, float* out, int32_t batch, void* workspace, size_t workspace_bytes,
+                      void* stream) {
+  if (!u || !u->is_mmdit || !pooled) return SDN_E_INVALID;
+  return run_plan(u, weights, latents, timestep, text, pooled, out, batch, workspace, workspace_bytes, stream);
+}
+
+static int run_plan(sdn_unet* u, const void* weights, const float* latents, float timestep, const void* text,
+                    const void* pooled, float* out, int32_t batch, void* workspace, size_t workspace_bytes, void* stream) {
   if (!u || !weights || !latents || !text || !out || !workspace || batch <= 0) return SDN_E_INVALID;
   Plan* p = get_plan(u, batch);
   if (workspace_bytes < (size_t)p->ws_bytes) return SDN_E_WORKSPACE;
   const char* W = (const char*)weights; const char* WS = (const char*)workspace;
   const char* L = (const char*)latents; const char* T = (const char*)text; const char* O = (const char*)out;
-  auto P = [&](const Ref& r) { return resolve(r, W, WS, L, T, O); };
+  const char* PL = (const char*)pooled;
+  auto P = [&](const Ref& r) { return resolve(r, W, WS, L, T, O, PL); };
   const bool prof = u->profile_next;
   if (prof) {                                    // opt-in diagnostics: HIP events around every launch of this forward
     u->profile_next = false;
@@ -556,7 +787,7 @@ int sdn_unet_forward(sdn_unet* u, const void* weights, const float* latents, flo
     u->profiled_batch = batch;
   }
   size_t opi = 0;
-  const bool f16 = u->cfg.dtype == 1;
+  const bool f16 = (u->is_mmdit ? u->mcfg.dtype : u->cfg.dtype) == 1;
   for (const Op& o : p->ops) {
     int rc = SDN_OK;
     if (prof) (void)hipEventRecord(u->ev[2 * opi], (hipStream_t)stream);
@@ -570,17 +801,36 @@ int sdn_unet_forward(sdn_unet* u, const void* weights, const float* latents, flo
         break;
       case OP_GEMM:
         rc = (f16 ? sdn_gemm_f16 : sdn_gemm_bf16)(&o.gd, P(o.a), P(o.a2), P(o.w), (const float*)P(o.bias), (const float*)P(o.rowbias),
-                           P(o.residual), (void*)P(o.out), stream);
+                           (const float*)P(o.rowgate), P(o.residual), (void*)P(o.out), stream);
         break;
       case OP_GN:
         rc = (f16 ? sdn_groupnorm_f16 : sdn_groupnorm_bf16)(P(o.a), P(o.a2), o.batch, o.hw, o.c1, o.c2, o.groups, o.eps, o.silu,
                                 (const float*)P(o.w), (const float*)P(o.bias), (void*)P(o.out), (float*)P(o.aux), stream);
         break;
+      case OP_PATCHIFY:
+        rc = (f16 ? sdn_patchify_f16 : sdn_patchify_bf16)((const float*)P(o.a), o.batch, o.c1, o.hw, o.hw, o.patch,
+                                                          (void*)P(o.out), stream);
+        break;
+      case OP_UNPATCHIFY:
+        rc = sdn_unpatchify_f32((const float*)P(o.a), o.batch, o.c1, o.hw, o.hw, o.patch, (float*)P(o.out), stream);
+        break;
       case OP_LN:
+        if (o.mod) {
+          rc = (f16 ? sdn_layernorm_mod_f16 : sdn_layernorm_mod_bf16)(P(o.a), o.rows, o.c1, o.eps, (const float*)P(o.w),
+                                                                      (const float*)P(o.bias), o.ld_mod, o.hw,
+                                                                      (void*)P(o.out), stream);
+          break;
+        }
         rc = (f16 ? sdn_layernorm_f16 : sdn_layernorm_bf16)(P(o.a), o.rows, o.c1, o.eps, (const float*)P(o.w), (const float*)P(o.bias),
                                 (void*)P(o.out), stream);
         break;
       case OP_ATTN:
+        if (o.n1 > 0) {
+          sdn_attn_segment2 s2{P(o.q2), P(o.k2), P(o.v2), (void*)P(o.out2), o.n1, o.ldq, o.ldk, o.ldv, o.ldo};
+          rc = sdn_joint_attention(f16 ? 1 : 0, P(o.a), P(o.k), P(o.v), (void*)P(o.out), &s2, o.batch, o.heads, o.nq, o.hd,
+                                   o.ldq, o.ldk, o.ldv, o.ldo, o.scale, stream);
+          break;
+        }
         rc = (f16 ? sdn_attention_f16 : sdn_attention_bf16)(P(o.a), P(o.k), P(o.v), (void*)P(o.out), o.batch, o.heads, o.nq, o.nk, o.hd, o.ldq,
                                 o.ldk, o.ldv, o.ldo, o.scale, stream);
         break;

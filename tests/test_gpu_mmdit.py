@@ -1,0 +1,132 @@
+"""SD-v3 MMDiT (row U7): operator-level checks of the new pieces and whole-network parity vs the CPU oracle on a
+small configuration (the full 2 B-parameter model is exercised for shape/finite-ness only: its CPU oracle forward
+would take minutes).  Tolerances: fp16 storage -> rel L2 <= 5e-3 vs the fp16-emulating and the fp32 oracle."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import safe_denoiser_amd as sda
+from oracle.mmdit import OracleMMDiT
+from safe_denoiser_amd import _lib
+from safe_denoiser_amd.mmdit import SD3Transformer2DModel
+from tests_support import ops
+
+pytestmark = pytest.mark.gpu
+H16 = torch.float16
+
+
+def rel_l2(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / b.norm())
+
+
+def test_gemm_rowgate_gelu_tanh_and_broadcast_residual():
+    g = torch.Generator().manual_seed(0)
+    B, rows, K, N = 3, 48, 256, 256
+    a = torch.randn(B * rows, K, generator=g).to(H16); w = (torch.randn(N, K, generator=g) * K ** -0.5).to(H16)
+    bias = torch.randn(N, generator=g); gate = torch.randn(B, 2 * N, generator=g); res = torch.randn(B * rows, N, generator=g).to(H16)
+    base = a.float() @ w.float().T + bias
+    gg = gate.cuda()
+    out = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), rowgate=gg[:, N:], residual=res.cuda(), rows_per_batch=rows)
+    ref = (base.reshape(B, rows, N) * gate[:, None, N:]).reshape(-1, N) + res.float()
+    assert rel_l2(out, ref) <= 5e-4
+    out = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), act=3)
+    assert rel_l2(out, F.gelu(base, approximate="tanh")) <= 5e-4
+    pos = torch.randn(rows, N, generator=g).to(H16)
+    out = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), residual=pos.cuda(), rows_per_batch=rows, residual_bcast=1)
+    assert rel_l2(out, (base.reshape(B, rows, N) + pos.float()[None]).reshape(-1, N)) <= 5e-4
+
+
+def test_layernorm_mod_patchify_unpatchify():
+    g = torch.Generator().manual_seed(1)
+    B, rows, Cc = 2, 37, 1536
+    x = (torch.randn(B * rows, Cc, generator=g) * 2 + 0.3).to(H16)
+    mod = torch.randn(B, 3 * Cc, generator=g) * 0.3
+    out = torch.empty_like(x, device="cuda")
+    mg, xg = mod.cuda(), x.cuda()
+    _lib.check(sda.lib().sdn_layernorm_mod_f16(xg.data_ptr(), B * rows, Cc, 1e-6, mg[:, Cc:].data_ptr(), mg.data_ptr(),
+                                               3 * Cc, rows, out.data_ptr(), _lib.stream_ptr()), "ln_mod")
+    ref = F.layer_norm(x.float(), (Cc,), eps=1e-6).reshape(B, rows, Cc) * (1 + mod[:, None, Cc:2 * Cc]) + mod[:, None, :Cc]
+    assert rel_l2(out, ref.reshape(-1, Cc)) <= 5e-4
+    lat = torch.randn(2, 16, 8, 8, generator=g)
+    pt = torch.empty(2 * 16, 64, dtype=H16, device="cuda")
+    lg = lat.cuda()
+    _lib.check(sda.lib().sdn_patchify_f16(lg.data_ptr(), 2, 16, 8, 8, 2, pt.data_ptr(), _lib.stream_ptr()), "patchify")
+    ref = F.unfold(lat, kernel_size=2, stride=2).transpose(1, 2).reshape(-1, 64)        # column order (c, py, px)
+    assert torch.equal(pt.float().cpu(), ref.half().float())
+    tok = torch.randn(2 * 16, 64, generator=g)
+    o = torch.empty(2, 16, 8, 8, device="cuda")
+    tg = tok.cuda()
+    _lib.check(sda.lib().sdn_unpatchify_f32(tg.data_ptr(), 2, 16, 8, 8, 2, o.data_ptr(), _lib.stream_ptr()), "unpatchify")
+    ref = torch.einsum("nhwpqc->nchpwq", tok.reshape(2, 4, 4, 2, 2, 16)).reshape(2, 16, 8, 8)
+    assert torch.equal(o.cpu(), ref)
+
+
+@pytest.mark.parametrize("n1,n2", [(64, 13), (1024, 333), (96, 32)])
+def test_joint_attention_two_streams(n1, n2):
+    g = torch.Generator().manual_seed(2)
+    B, Hh, d = 2, 4, 64
+    Cc = Hh * d
+    qkv1 = torch.randn(B, n1, 3 * Cc, generator=g).to(H16); qkv2 = torch.randn(B, n2, 3 * Cc, generator=g).to(H16)
+    cat = torch.cat([qkv1, qkv2], 1).float()
+    sp = lambda t: t.reshape(B, n1 + n2, Hh, d).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(sp(cat[..., :Cc]), sp(cat[..., Cc:2 * Cc]), sp(cat[..., 2 * Cc:]))
+    ref = ref.transpose(1, 2).reshape(B, n1 + n2, Cc)
+    g1, g2 = qkv1.cuda(), qkv2.cuda()
+    o1 = torch.empty(B, n1, Cc, dtype=H16, device="cuda"); o2 = torch.empty(B, n2, Cc, dtype=H16, device="cuda")
+    s2 = _lib.AttnSegment2(g2.data_ptr(), g2[..., Cc:].data_ptr(), g2[..., 2 * Cc:].data_ptr(), o2.data_ptr(), n1,
+                           3 * Cc, 3 * Cc, 3 * Cc, Cc)
+    _lib.check(sda.lib().sdn_joint_attention(1, g1.data_ptr(), g1[..., Cc:].data_ptr(), g1[..., 2 * Cc:].data_ptr(),
+                                             o1.data_ptr(), C.byref(s2), B, Hh, n1 + n2, d, 3 * Cc, 3 * Cc, 3 * Cc, Cc,
+                                             d ** -0.5, _lib.stream_ptr()), "joint_attention")
+    assert rel_l2(o1, ref[:, :n1]) <= 1.5e-3 and rel_l2(o2, ref[:, n1:]) <= 1.5e-3
+
+
+SMALL = dict(sample_size=16, num_layers=3, num_attention_heads=4, joint_attention_dim=128, pooled_projection_dim=64,
+             pos_embed_max_size=24)
+SMALL_O = dict(sample_size=16, num_layers=3, num_heads=4, joint_dim=128, pooled_dim=64, pos_embed_max_size=24)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 5e-3), (torch.bfloat16, 4e-2)])
+def test_small_mmdit_matches_oracle(dtype, tol):
+    m = SD3Transformer2DModel(text_len=45, dtype=dtype, **SMALL)
+    sd = m.synthetic_state_dict(5)
+    m.load_state_dict(sd)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 16, 16, 16, generator=g); e = torch.randn(2, 45, 128, generator=g); pl = torch.randn(2, 64, generator=g)
+    y = m(x.cuda(), timestep=torch.tensor([812.0, 812.0]).cuda(), encoder_hidden_states=e.cuda(),
+          pooled_projections=pl.cuda())[0]
+    torch.cuda.synchronize()
+    assert y.shape == (2, 16, 16, 16) and torch.isfinite(y).all()
+    r_em = rel_l2(y, OracleMMDiT(sd, SMALL_O, act_dtype=dtype)(x, 812.0, e, pl))
+    r_32 = rel_l2(y, OracleMMDiT(sd, SMALL_O, act_dtype=None)(x, 812.0, e, pl))
+    print(f"small mmdit {dtype}: rel L2 vs emulating oracle {r_em:.3e}, vs fp32 oracle {r_32:.3e}")
+    assert r_em <= tol and r_32 <= tol
+
+
+def test_full_sd3_medium_plan_runs():
+    """The 2 B-parameter SD3-medium plan at the reference driver's default 512x512 (latent 64): shapes, finiteness,
+    batch-row independence.  (Weights are generated on the GPU to keep the test short.)"""
+    m = SD3Transformer2DModel()
+    buf = torch.zeros(m.weight_bytes, dtype=torch.uint8, device="cuda")
+    gg = torch.Generator(device="cuda").manual_seed(0)
+    for p in m.manifest:
+        n = p["rows_padded"] * max(p["cols"], 1)
+        if p["kind"] == 0:
+            t = (torch.rand(n, generator=gg, device="cuda") - 0.5) * 0.2
+            buf[p["offset"]:p["offset"] + 4 * n] = t.view(torch.uint8)
+        else:
+            scale = (3.0 / max(p["cols"], 1)) ** 0.5 * (0.3 if "norm" in p["name"] else 1.0)
+            t = ((torch.rand(n, generator=gg, device="cuda") * 2 - 1) * scale).half()
+            buf[p["offset"]:p["offset"] + 2 * n] = t.view(torch.uint8)
+    m._weights = buf
+    x = torch.randn(2, 16, 64, 64, device="cuda"); e = torch.randn(2, 333, 4096, device="cuda"); pl = torch.randn(2, 2048, device="cuda")
+    y = m(x, timestep=900.0, encoder_hidden_states=e, pooled_projections=pl)[0]
+    y0 = m(x[:1], timestep=900.0, encoder_hidden_states=e[:1], pooled_projections=pl[:1])[0]
+    torch.cuda.synchronize()
+    assert y.shape == (2, 16, 64, 64) and torch.isfinite(y).all()
+    assert torch.equal(y0, y[:1])
+    total, attn = m.flops(1)
+    assert abs(total / 1e12 - 2.107) < 0.01

@@ -77,3 +77,16 @@ def test_interleave16():
     o = _interleave16(t)
     assert o[:16].tolist() == list(range(16)) and o[16:32].tolist() == list(range(32, 48))
     assert o[32:48].tolist() == list(range(16, 32))
+
+
+def test_mmdit_manifest_matches_sd3_medium_parameter_count():
+    """SD3-medium's transformer has 2,028,328,000 parameters (public figure; pos_embed is a buffer, not a parameter)."""
+    from safe_denoiser_amd.mmdit import SD3Transformer2DModel
+    m = SD3Transformer2DModel()
+    shapes = m.state_dict_shapes()
+    assert sum(math.prod(s) for n, s in shapes.items() if n != "pos_embed.pos_embed") == 2_028_328_000
+    assert shapes["pos_embed.pos_embed"] == (1, 192 * 192, 1536)
+    assert shapes["transformer_blocks.0.norm1.linear.weight"] == (9216, 1536)
+    assert shapes["transformer_blocks.23.norm1_context.linear.weight"] == (3072, 1536)      # context_pre_only
+    assert "transformer_blocks.23.ff_context.net.2.weight" not in shapes
+    assert shapes["proj_out.weight"] == (64, 1536) and shapes["context_embedder.weight"] == (1536, 4096)

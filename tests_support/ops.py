@@ -15,7 +15,7 @@ def _fn(base: str, t: torch.Tensor):
 
 
 def gemm(a, w, *, bias=None, rowbias=None, residual=None, a2=None, conv=None, act=0, out_kind=0, n_valid=0,
-         rows_per_batch=0):
+         rows_per_batch=0, rowgate=None, residual_bcast=0):
     """a [M,K] bf16 (or NHWC map for conv=dict(Hs,Ws,Cin,Ho,Wo,stride,upsample)), w [N,K] bf16."""
     N, K = w.shape
     d = _lib.GemmDesc()
@@ -33,6 +33,9 @@ def gemm(a, w, *, bias=None, rowbias=None, residual=None, a2=None, conv=None, ac
     d.rows_per_batch = rows_per_batch
     if rowbias is not None:
         d.ld_rowbias = rowbias.stride(0)
+    if rowgate is not None:
+        d.ld_rowgate = rowgate.stride(0)
+    d.residual_bcast = residual_bcast
     nv = n_valid or N
     if out_kind == 0:
         out = torch.empty((M, N // 2 if act == 2 else nv), dtype=a.dtype, device=a.device)
@@ -41,7 +44,7 @@ def gemm(a, w, *, bias=None, rowbias=None, residual=None, a2=None, conv=None, ac
     else:
         out = torch.empty((M // rows_per_batch, nv, rows_per_batch), dtype=torch.float32, device=a.device)
     p = lambda t: None if t is None else t.data_ptr()
-    _lib.check(_fn("gemm", a)(C.byref(d), p(a), p(a2), p(w), p(bias), p(rowbias), p(residual), p(out),
+    _lib.check(_fn("gemm", a)(C.byref(d), p(a), p(a2), p(w), p(bias), p(rowbias), p(rowgate), p(residual), p(out),
                                        _lib.stream_ptr()), "sdn_gemm_bf16")
     return out
 
