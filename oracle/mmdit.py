@@ -108,3 +108,42 @@ class OracleMMDiT:
         co = c["out_channels"]
         tok = tok.reshape(b, hp, hp, ps, ps, co)
         return torch.einsum("nhwpqc->nchpwq", tok).reshape(b, co, hp * ps, hp * ps)
+
+
+def sd3_denoise_one(transformer, scheduler, embeds_pair, pooled_pair, p, noise_fn, *, num_inference_steps=50,
+                    guidance_scale=7.0, repel=None, latents_dtype=torch.float16, negation_warmup_start=1000,
+                    negation_warmup_end=780):
+    """The reference's SD-v3 loop for ONE prompt (models/sdv3/safe_denoiser_pipeline.py:1105-1171).
+    embeds_pair [2,T,4096] / pooled_pair [2,2048] = (negative, positive).  repel = dict(proj_refs=..., scale=...) uses
+    the fast_sdv3 kernel_fast projection.  Noise comes from noise_fn(p, shape) in draw order (latents, then one z per
+    window step)."""
+    from . import repellency as orp
+    from . import schedulers as osch
+    cfg = transformer.cfg
+    shape = (1, cfg["in_channels"], cfg["sample_size"], cfg["sample_size"])
+    rq = (lambda x: x) if latents_dtype == torch.float32 else (lambda x: x.to(latents_dtype).float())
+    scheduler.set_timesteps(num_inference_steps)
+    ts = scheduler.timesteps.tolist()
+    lat = rq(noise_fn(p, shape))
+    n_win = 0
+    for i, t in enumerate(ts):
+        out = rq(transformer(torch.cat([lat] * 2), float(t), embeds_pair, pooled_pair))
+        v = out[0:1] + guidance_scale * (out[1:2] - out[0:1])
+        if negation_warmup_end <= t <= negation_warmup_start and repel is not None:
+            n_win += 1
+            sigma = t / 1000.0
+            sigma_next = ts[i + 1] / 1000.0 if i + 1 < len(ts) else 0.0
+            z = noise_fn(p, shape)
+            x0r_fn = lambda x0: orp.kernel_fast_conditioning(rq(x0), repel["proj_refs"], flavour="fast_sdv3",
+                                                             scale=repel["scale"])["x_0_hat"]
+            # x1 is rounded to the latents dtype exactly where the engine does
+            x0 = lat - sigma * v
+            x1 = rq(lat + (1 - sigma) * v)
+            x0r = x0r_fn(x0)
+            noise = math.sqrt(sigma_next) * x1 + math.sqrt(1 - sigma_next) * z
+            lat = x0r + sigma_next * (noise - x0r)
+            scheduler._i += 1
+        else:
+            lat = scheduler.step(v, t, lat)
+        lat = rq(lat)
+    return lat, {"window_steps": n_win}
