@@ -17,6 +17,8 @@
 // no padded copies of the activations exist in HBM.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "sdn_common.h"
 #include "sdn_ops.h"
 
@@ -26,7 +28,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
-constexpr int BM = 128, BK = 64, THREADS = 256;
+constexpr int BK = 64;
 
 struct GemmArgs {
   const __bf16* a;  const __bf16* a2;  const __bf16* w;
@@ -45,10 +47,24 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
   return *reinterpret_cast<unsigned*>(&p);
 }
 __device__ __forceinline__ float silu_f(float v) { return v / (1.f + __expf(-v)); }
-__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below one 16-bit output rounding): one v_exp, one v_rcp and
+// five FMAs instead of libm's branchy erff -- the GEGLU epilogue evaluates it 1280..5120 times per output row.
+__device__ __forceinline__ float erf_as(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+  const float r = fmaf(-p * t, e, 1.0f);
+  return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erf_as(v * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_tanh(float v) {                       // GELU(approximate="tanh"), MMDiT feed-forward
   const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
-  return 0.5f * v * (1.f + tanhf(u));
+  // 0.5 (1 + tanh u) = 1 / (1 + exp(-2u))   (one v_exp + one v_rcp; saturates cleanly for |u| large)
+  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * u));
 }
 
 // byte offset of 16-B chunk c of row r inside a [rows][8 chunks] tile
@@ -69,13 +85,17 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #endif
 
-template <typename T, int NREP>
-__global__ void __launch_bounds__(THREADS, 2)
+// WGM = waves along M (2 -> 128-row tile, 4 waves, 2 blocks/CU;  4 -> 256-row tile, 8 waves, 1 block/CU).
+// The 256 x 320 tile (WGM=4, NREP=10) halves the L2->LDS bytes per MFMA of the 128 x 160 tile: at 2 x 36.9 KB per
+// 1280 MFMA-cycles per CU the small tile needs ~57 B/clk/CU of L2 bandwidth -- ~90 % of what a CU can pull.
+template <typename T, int NREP, int WGM>
+__global__ void __launch_bounds__(128 * WGM, 2)
 k_gemm_dma(const GemmArgs g) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = 64 * WGM, THREADS = 128 * WGM, NWAVES = 2 * WGM;
   constexpr int BN = 32 * NREP;
-  constexpr int A_PIECES = BM / 8 / 4;                       // 1-KiB pieces per wave: 4
-  constexpr int W_PIECES = (BN / 8 + 3) / 4;                 // 5 @160, 4 @128, 2 @64, 1 @32
+  constexpr int A_PIECES = BM / 8 / NWAVES;                  // 1-KiB pieces per wave: 4
+  constexpr int W_PIECES = (BN / 8 + NWAVES - 1) / NWAVES;   // 5 @160/4w or @320/8w, 4 @128/4w, ...
   constexpr int STAGE = (BM + BN) * 128;
   constexpr unsigned OOB = 0x80000000u;                      // > any tensor size handled here
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
@@ -98,15 +118,15 @@ k_gemm_dma(const GemmArgs g) {
   // ---- per-lane source rows (fixed across k).  All per-k-tile address work is strength-reduced to
   //      "lane base + wave-uniform delta" (+ a validity bit test for the conv halo) ----
   unsigned a_base[A_PIECES];        // PLAIN: byte offset of (row, lane chunk) in source 1 (or OOB); CONV: centre pixel
-  unsigned a_base2[A_PIECES];       // PLAIN: same for source 2
-  unsigned a_mask[A_PIECES];        // CONV: bit t = tap t reads inside the (virtual) input map
-  int a_ey[A_PIECES], a_ex[A_PIECES];   // CONV + upsample: parity of the output coordinate
+  unsigned a_aux[A_PIECES];         // PLAIN: the same offset in source 2 (or OOB)
+                                    // CONV: bits 0-8 = tap t reads inside the (virtual) input map, bit 9/10 = parity
+                                    //       of the output row / column (nearest-2x upsample)
   const int ld1 = g.a_mode == 1 ? g.Cin : g.K1, ld2 = g.K - g.K1;
 #pragma unroll
   for (int i = 0; i < A_PIECES; ++i) {
     const int m = m0 + (wid * A_PIECES + i) * 8 + lrow;
     const bool ok = m < g.M;
-    a_base2[i] = OOB; a_mask[i] = 0; a_ey[i] = a_ex[i] = 0;
+    a_aux[i] = OOB;
     if (g.a_mode == 1) {
       const int mm = ok ? m : 0;
       const int hw = g.Ho * g.Wo;
@@ -120,13 +140,12 @@ k_gemm_dma(const GemmArgs g) {
         const int iy = cy + t / 3 - 1, ix = cx + t % 3 - 1;
         if (ok && iy >= 0 && iy < Hi && ix >= 0 && ix < Wi) mask |= 1u << t;
       }
-      a_mask[i] = mask;
-      a_ey[i] = cy & 1; a_ex[i] = cx & 1;
+      a_aux[i] = mask | ((unsigned)(cy & 1) << 9) | ((unsigned)(cx & 1) << 10);
       const int sy = g.upsample ? cy >> 1 : cy, sx = g.upsample ? cx >> 1 : cx;
       a_base[i] = (unsigned)((((bb * g.Hs + sy) * g.Ws + sx) * g.Cin + lchunk * 8) * 2);
     } else {
       a_base[i] = ok ? (unsigned)(((long)m * ld1 + lchunk * 8) * 2) : OOB;
-      if (g.a2) a_base2[i] = ok ? (unsigned)(((long)m * ld2 + lchunk * 8) * 2) : OOB;
+      a_aux[i] = (g.a2 && ok) ? (unsigned)(((long)m * ld2 + lchunk * 8) * 2) : OOB;
     }
   }
   unsigned w_off[W_PIECES];
@@ -153,15 +172,15 @@ k_gemm_dma(const GemmArgs g) {
         const int delta = ((dy * g.Ws + dx) * g.Cin + cur_c0) * 2;                    // wave-uniform
 #pragma unroll
         for (int i = 0; i < A_PIECES; ++i) {
-          const unsigned off = ((a_mask[i] >> tap) & 1u) ? a_base[i] + (unsigned)delta : OOB;
+          const unsigned off = ((a_aux[i] >> tap) & 1u) ? a_base[i] + (unsigned)delta : OOB;
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a1, (lds_ptr_t)(sa + (wid * A_PIECES + i) * 1024), 16, off, 0, 0, 0);
         }
       } else {                                      // nearest-2x: stored row = (y + dy) >> 1 = (y >> 1) + ((y & 1) + dy) >> 1
 #pragma unroll
         for (int i = 0; i < A_PIECES; ++i) {
-          const int sy = (a_ey[i] + dy) >> 1, sx = (a_ex[i] + dx) >> 1;
+          const int sy = ((int)((a_aux[i] >> 9) & 1u) + dy) >> 1, sx = ((int)((a_aux[i] >> 10) & 1u) + dx) >> 1;
           const int delta = ((sy * g.Ws + sx) * g.Cin + cur_c0) * 2;
-          const unsigned off = ((a_mask[i] >> tap) & 1u) ? a_base[i] + (unsigned)delta : OOB;
+          const unsigned off = ((a_aux[i] >> tap) & 1u) ? a_base[i] + (unsigned)delta : OOB;
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a1, (lds_ptr_t)(sa + (wid * A_PIECES + i) * 1024), 16, off, 0, 0, 0);
         }
       }
@@ -172,7 +191,7 @@ k_gemm_dma(const GemmArgs g) {
         const unsigned kb = (unsigned)((cur_k0 - g.K1) * 2);
 #pragma unroll
         for (int i = 0; i < A_PIECES; ++i)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a2, (lds_ptr_t)(sa + (wid * A_PIECES + i) * 1024), 16, a_base2[i] + kb, 0, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a2, (lds_ptr_t)(sa + (wid * A_PIECES + i) * 1024), 16, a_aux[i] + kb, 0, 0, 0);
       } else {
         const unsigned kb = (unsigned)(cur_k0 * 2);
 #pragma unroll
@@ -208,15 +227,23 @@ k_gemm_dma(const GemmArgs g) {
     const unsigned char* sw = smem + buf * STAGE + BM * 128 + (wn * 16 * NREP) * 128;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      typename T::v8 fa[4], fw[NREP];
+      constexpr int JC = NREP > 5 ? NREP / 2 : NREP;         // W fragments live at once (register budget of the big tile)
+      typename T::v8 fa[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const typename T::v8*>(sa + lds_off(i * 16 + fr, ks * 4 + fq));
-#pragma unroll
-      for (int j = 0; j < NREP; ++j) fw[j] = *reinterpret_cast<const typename T::v8*>(sw + lds_off(j * 16 + fr, ks * 4 + fq));
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < NREP; ++j) acc[i][j] = T::mfma16(fw[j], fa[i], acc[i][j]);
+      // (macro, not a lambda: the column-block offset must be a compile-time constant or acc[][] goes to scratch)
+#define SDN_MMA_PART(J0)                                                                                              \
+      {                                                                                                                \
+        typename T::v8 fw[JC];                                                                                         \
+        _Pragma("unroll") for (int j = 0; j < JC; ++j)                                                                 \
+          fw[j] = *reinterpret_cast<const typename T::v8*>(sw + lds_off(((J0) + j) * 16 + fr, ks * 4 + fq));          \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                  \
+          _Pragma("unroll") for (int j = 0; j < JC; ++j)                                                               \
+            acc[i][(J0) + j] = T::mfma16(fw[j], fa[i], acc[i][(J0) + j]);                                              \
+      }
+      SDN_MMA_PART(0)
+      if constexpr (NREP > JC) SDN_MMA_PART(JC)
+#undef SDN_MMA_PART
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -228,103 +255,38 @@ k_gemm_dma(const GemmArgs g) {
   constexpr int CW = (BN + 8) * 2;                           // staged row stride in bytes (+16 B pad)
   const bool staged = g.out_kind == 0 && g.n_valid == g.N;
   const int out_cols = g.act == 2 ? BN / 2 : BN;             // columns this tile contributes to `out`
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int ml = wm * 64 + i * 16 + fr;                    // row inside the tile
-    const int m = m0 + ml;
-    const bool row_ok = m < g.M;
-    const int b = (g.rows_per_batch > 0 && row_ok) ? m / g.rows_per_batch : 0;
-    unsigned short* out16 = reinterpret_cast<unsigned short*>(g.out);
-    if (g.act == 2) {
-#pragma unroll
-      for (int j = 0; j + 1 < NREP; j += 2) {
-        const int np = n0 + wn * 16 * NREP + j * 16 + fq * 4;
-        f32x4 hv = acc[i][j], gv = acc[i][j + 1];
-        if (g.bias) {
-          const float4 bh = *reinterpret_cast<const float4*>(g.bias + np);
-          const float4 bg = *reinterpret_cast<const float4*>(g.bias + np + 16);
-          hv[0] += bh.x; hv[1] += bh.y; hv[2] += bh.z; hv[3] += bh.w;
-          gv[0] += bg.x; gv[1] += bg.y; gv[2] += bg.z; gv[3] += bg.w;
-        }
-        uint2 pk;
-        pk.x = T::pack2(hv[0] * gelu_erf(gv[0]), hv[1] * gelu_erf(gv[1]));
-        pk.y = T::pack2(hv[2] * gelu_erf(gv[2]), hv[3] * gelu_erf(gv[3]));
-        const int nl = ((wn * 16 * NREP + j * 16) >> 1) + fq * 4;        // column inside the (half-width) tile
-        *reinterpret_cast<uint2*>(smem + ml * CW + nl * 2) = pk;
-      }
-      continue;
-    }
-#pragma unroll
-    for (int j = 0; j < NREP; ++j) {
-      const int nl = wn * 16 * NREP + j * 16 + fq * 4;
-      const int n = n0 + nl;
-      f32x4 v = acc[i][j];
-      if (g.bias) {
-        const float4 bb = *reinterpret_cast<const float4*>(g.bias + n);
-        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-      }
-      if (g.rowbias && row_ok) {
-        const float4 rb = *reinterpret_cast<const float4*>(g.rowbias + (long)b * g.ld_rowbias + n);
-        v[0] += rb.x; v[1] += rb.y; v[2] += rb.z; v[3] += rb.w;
-      }
-      if (g.rowgate && row_ok) {                              // adaLN-zero gate: per-sample vector, applied before the residual
-        const float4 gt = *reinterpret_cast<const float4*>(g.rowgate + (long)b * g.ld_rowgate + n);
-        v[0] *= gt.x; v[1] *= gt.y; v[2] *= gt.z; v[3] *= gt.w;
-      }
-      if (g.residual && row_ok) {
-        const long rrow = g.residual_bcast ? (long)(m - b * g.rows_per_batch) : (long)m;     // bcast: same rows for every sample
-        const uint2 rr = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(g.residual) + rrow * g.ldc + n);
-        v[0] += T::to_f(rr.x & 0xffff); v[1] += T::to_f(rr.x >> 16); v[2] += T::to_f(rr.y & 0xffff); v[3] += T::to_f(rr.y >> 16);
-      }
-      if (g.act == 1) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
-      if (g.act == 3) { v[0] = gelu_tanh(v[0]); v[1] = gelu_tanh(v[1]); v[2] = gelu_tanh(v[2]); v[3] = gelu_tanh(v[3]); }
-      if (staged) {
-        uint2 pk; pk.x = T::pack2(v[0], v[1]); pk.y = T::pack2(v[2], v[3]);
-        *reinterpret_cast<uint2*>(smem + ml * CW + nl * 2) = pk;
-      } else if (!row_ok) {
-      } else if (g.out_kind == 0) {
-        for (int e = 0; e < 4; ++e)
-          if (n + e < g.n_valid) out16[(long)m * g.ldc + n + e] = (unsigned short)(T::pack2(v[e], 0.f) & 0xffff);
-      } else if (g.out_kind == 1) {
-        for (int e = 0; e < 4; ++e)
-          if (n + e < g.n_valid) reinterpret_cast<float*>(g.out)[(long)m * g.ldc + n + e] = v[e];
-      } else {
-        const int p = m - b * g.rows_per_batch;
-        for (int e = 0; e < 4; ++e)
-          if (n + e < g.n_valid)
-            reinterpret_cast<float*>(g.out)[((long)b * g.n_valid + n + e) * g.rows_per_batch + p] = v[e];
-      }
-    }
-  }
-  if (staged || g.act == 2) {
-    __syncthreads();
-    const int cpr = out_cols / 8;                            // 16-byte chunks per staged row
-    const int col0 = g.act == 2 ? (n0 >> 1) : n0;
-    unsigned short* out16 = reinterpret_cast<unsigned short*>(g.out);
-    for (int e = tid; e < BM * cpr; e += THREADS) {
-      const int r = e / cpr, c = e - r * cpr;
-      const int m = m0 + r;
-      if (m < g.M && !(g.dbg & 1))
-        *reinterpret_cast<u32x4*>(out16 + (long)m * g.ldc + col0 + c * 8) = *reinterpret_cast<const u32x4*>(smem + r * CW + c * 16);
-    }
+  // the staged tile may exceed the LDS (256 x 320): stage PASSES groups of wave-rows one after the other
+  constexpr int PASSES = (BM * CW + 2 * STAGE - 1) / (2 * STAGE);
+  constexpr int WM_PER_PASS = WGM / PASSES, ROWS_PER_PASS = 64 * WM_PER_PASS;
+  static_assert(WGM % PASSES == 0, "pass split must divide the wave rows");
+  static_assert(PASSES <= 2, "epilogue is written for at most two staging passes");
+#define SDN_PASS 0
+#include "sdn_gemm_epilogue.inc"
+#undef SDN_PASS
+  if constexpr (PASSES > 1) {
+#define SDN_PASS 1
+#include "sdn_gemm_epilogue.inc"
+#undef SDN_PASS
   }
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <typename T, int NREP>
+template <typename T, int NREP, int WGM>
 int launch_dma(const GemmArgs& ga, hipStream_t st) {
   const int grid = ga.tiles_m * ga.tiles_n;
-  hipLaunchKernelGGL((k_gemm_dma<T, NREP>), dim3(grid), dim3(THREADS), 0, st, ga);
+  hipLaunchKernelGGL((k_gemm_dma<T, NREP, WGM>), dim3(grid), dim3(128 * WGM), 0, st, ga);
   return sdn_launch_status();
 }
 
 template <typename T>
 int dispatch_dma(int nrep, const GemmArgs& g, hipStream_t st) {
   switch (nrep) {
-    case 5: return launch_dma<T, 5>(g, st);
-    case 4: return launch_dma<T, 4>(g, st);
-    case 2: return launch_dma<T, 2>(g, st);
-    default: return launch_dma<T, 1>(g, st);
+    case 10: return launch_dma<T, 10, 4>(g, st);
+    case 8: return launch_dma<T, 8, 4>(g, st);
+    case 5: return launch_dma<T, 5, 2>(g, st);
+    case 4: return launch_dma<T, 4, 2>(g, st);
+    case 2: return launch_dma<T, 2, 2>(g, st);
+    default: return launch_dma<T, 1, 2>(g, st);
   }
 }
 
@@ -349,10 +311,21 @@ extern "C" void sdn_debug_set_gemm_variant(int v) { g_gemm_variant = v; }
 
 // Tile choice with the grid in mind: when the widest tile leaves the 256 CUs (x2 resident blocks) underfilled
 // (the 8x8 / 16x16 levels at small batch), fall back to BN = 64 to multiply the number of workgroups.
-static int pick_nrep_for(int M, int N, int act) {
+int sdn_gemm_pick_tile(int M, int N, int K, int act) {
   int nrep = sdn_gemm_pick_nrep(N, act);
-  if (g_gemm_variant == 2) return nrep;                      // debug: heuristic off
-  const int tiles_m = (M + BM - 1) / BM;
+  if (g_gemm_variant == 2) return nrep;                      // debug: heuristics off
+  // big tile (256 rows, 8 waves, 1 block/CU) when it still fills the chip: >= ~3/4 of the 256 CUs get a tile
+  if (g_gemm_variant != 3) {
+    const int big = (N % 320 == 0) ? 10 : ((N % 256 == 0) ? 8 : 0);
+    // ... and only for long k loops: with one block per CU nothing hides a tile's prologue/epilogue, so short-K
+    // projections (K = 320 .. 1280) stay on the 2-blocks-per-CU tile (measured: tools/bench_gemm.py, VARIANTS=0,3)
+    const bool long_k = K >= 2048 || (K >= 1280 && act == SDN_ACT_GEGLU) || (K >= 1536 && act == SDN_ACT_NONE);
+    if (big && long_k) {
+      const long tiles = (long)((M + 255) / 256) * (N / (32 * big));
+      if (tiles >= 192) return big;
+    }
+  }
+  const int tiles_m = (M + 127) / 128;
   if (nrep > 2 && N % 64 == 0 && tiles_m * (N / (32 * nrep)) < 256) nrep = 2;
   return nrep;
 }
@@ -366,7 +339,7 @@ static int sdn_gemm_impl(int dtype, const sdn_gemm_desc* d, const void* a, const
   const int n_valid = d->n_valid > 0 ? d->n_valid : d->N;
   if (n_valid > d->N) return SDN_E_INVALID;
   if (sdn_gemm_pick_nrep(d->N, d->act) == 0) return SDN_E_INVALID;
-  const int nrep = pick_nrep_for(d->M, d->N, d->act);
+  const int nrep = sdn_gemm_pick_tile(d->M, d->N, d->K, d->act);
   if (!al16(a) || !al16(w) || (a2 && !al16(a2)) || (residual && (reinterpret_cast<uintptr_t>(residual) & 7)) ||
       (reinterpret_cast<uintptr_t>(out) & 7) || (bias && !al16(bias)) || (rowbias && !al16(rowbias)))
     return SDN_E_INVALID;
@@ -400,7 +373,8 @@ static int sdn_gemm_impl(int dtype, const sdn_gemm_desc* d, const void* a, const
   g.ldc = d->ldc > 0 ? d->ldc : (d->act == SDN_ACT_GEGLU ? d->N / 2 : n_valid);
   if (d->out_kind == SDN_OUT_BF16 && ((g.ldc & 7) || !al16(out))) return SDN_E_INVALID;
   const int bn = 32 * nrep;
-  g.tiles_m = (d->M + BM - 1) / BM; g.tiles_n = d->N / bn;
+  const int bm = nrep >= 8 ? 256 : 128;
+  g.tiles_m = (d->M + bm - 1) / bm; g.tiles_n = d->N / bn;
   g.dbg = g_gemm_variant >= 16 ? (g_gemm_variant >> 4) : 0;
   hipStream_t st = (hipStream_t)stream;
   // operands must stay below the LDS-DMA out-of-range sentinel (2 GiB per tensor)

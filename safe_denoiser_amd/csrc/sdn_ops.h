@@ -3,3 +3,5 @@
 #include "../../include/sdn.h"
 
 int sdn_gemm_pick_nrep(int n_padded, int act);
+// NREP actually launched for this shape (10 / 8 = the 256-row, 8-wave tile; 5 / 4 / 2 / 1 = the 128-row tile).
+int sdn_gemm_pick_tile(int M, int N, int K, int act);

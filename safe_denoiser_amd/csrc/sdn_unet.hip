@@ -181,7 +181,7 @@ struct Builder {
     o.a = a; o.a2 = a2; o.w = w; o.bias = bias; o.rowbias = rowbias; o.residual = residual; o.out = out;
     o.flops = 2.0 * (double)M * (double)(n_valid > 0 ? n_valid : N) * (double)K;
     o.bytes = 2.0 * ((double)M * K + (double)N * K + (double)M * (act_ == SDN_ACT_GEGLU ? N / 2 : N));
-    snprintf(o.label, sizeof(o.label), "k_gemm<%d>", sdn_gemm_pick_nrep(N, act_));
+    snprintf(o.label, sizeof(o.label), "k_gemm<%d>", sdn_gemm_pick_tile((int)M, N, K, act_));
     plan->ops.push_back(o);
     plan->flops += o.flops;
   }
@@ -197,7 +197,7 @@ struct Builder {
     o.a = R(in); o.w = w; o.bias = bias; o.rowbias = rowbias; o.residual = residual; o.out = out;
     o.flops = 2.0 * (double)o.gd.M * (double)cout * (double)o.gd.K;
     o.bytes = 2.0 * ((double)B * in.side * in.side * in.C + (double)n_pad * o.gd.K + (double)o.gd.M * cout);
-    snprintf(o.label, sizeof(o.label), "k_gemm<%d>", sdn_gemm_pick_nrep(n_pad, SDN_ACT_NONE));
+    snprintf(o.label, sizeof(o.label), "k_gemm<%d>", sdn_gemm_pick_tile(o.gd.M, n_pad, o.gd.K, SDN_ACT_NONE));
     plan->ops.push_back(o);
     plan->flops += o.flops;
   }
@@ -337,7 +337,7 @@ struct Builder {
     o.a = a; o.w = w; o.bias = bias; o.rowbias = rowbias; o.rowgate = rowgate; o.residual = residual; o.out = out;
     o.flops = 2.0 * (double)M * N * K;
     o.bytes = 2.0 * ((double)M * K + (double)N * K + (double)M * N);
-    snprintf(o.label, sizeof(o.label), "k_gemm<%d>", sdn_gemm_pick_nrep(N, act_));
+    snprintf(o.label, sizeof(o.label), "k_gemm<%d>", sdn_gemm_pick_tile((int)M, N, K, act_));
     plan->ops.push_back(o);
     plan->flops += o.flops;
   }

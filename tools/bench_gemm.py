@@ -25,6 +25,8 @@ SHAPES = [  # name, M, N, K, conv(H, Cin) or None, act
     ("ff1 geglu 640 @32", B * 1024, 5120, 640, None, 2),
     ("ff2 640 @32", B * 1024, 640, 2560, None, 0),
     ("ff1 geglu 1280 @16", B * 256, 10240, 1280, None, 2),
+    ("mmdit qkv 1536", B * 1024, 4608, 1536, None, 0),
+    ("mmdit ff1 1536", B * 1024, 6144, 1536, None, 3),
 ]
 VARIANTS = [int(v) for v in os.environ.get("VARIANTS", "0,1").split(",")]
 
