@@ -7,7 +7,8 @@
 One "step" = one batch of P prompts taken through the whole hot path: 50 denoising iterations, each = UNet forward on
 [2P,4,64,64] (CFG) + guidance combine + (t in 780..1000: x0 probe + repellency projection against proj_ref[515] +
 device-side re-noise select) + scheduler step.  Inputs are synthetic (no weights/datasets on the box) and resident in
-HBM before the timed region: SD-v1.4-architecture UNet with random weights (seed 1234), text states randn (seed 7),
+HBM before the timed region: SD-v1.4-architecture UNet with random weights (seed 1234, generated on the GPU), text
+states randn (seed 7),
 proj_ref = channel-normalised randn([515,4,64,64], seed 0), repellency knobs of configs/nudity/safe_denoiser.yaml,
 beta_threshold calibrated by the engine's own row-R5 path.  Prompts shard across ranks (no collective in the loop);
 rank 0 broadcasts proj_ref + threshold once over RCCL.  Prints ONE JSON line on rank 0.
@@ -36,7 +37,7 @@ def build_engine(args, rank, world, dev):
     from safe_denoiser_amd.unet import UNet2DConditionModel
 
     unet = UNet2DConditionModel(dtype=torch.float16 if args.dtype == "f16" else torch.bfloat16)
-    unet.load_state_dict(unet.synthetic_state_dict(1234), device=dev)
+    unet.load_synthetic_on_device(1234, device=dev)
     sched = make_scheduler(args.scheduler)
 
     refs = None
@@ -95,9 +96,9 @@ def cpu_baseline(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--prompts-per-batch", type=int, default=16)
+    ap.add_argument("--prompts-per-batch", type=int, default=32)
     ap.add_argument("--inference-steps", type=int, default=50)
     ap.add_argument("--scheduler", default="ddpm", choices=["ddpm", "ddim"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"], help="16-bit storage type of the UNet")

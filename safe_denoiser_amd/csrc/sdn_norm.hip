@@ -81,20 +81,32 @@ k_gn_stats(const unsigned short* __restrict__ x, const unsigned short* __restric
   }
 }
 
-// GroupNorm pass 1b: reduce the row-tile partials in fixed order -> mean / rstd per (sample, group).
-__global__ void k_gn_finalize(const float* __restrict__ partials, int ntiles, int groups, float n, float eps,
-                              float* __restrict__ stats) {
-  const int b = blockIdx.x, gi = threadIdx.x;
-  if (gi >= groups) return;
-  float s = 0.f, ss = 0.f;
-  for (int t = 0; t < ntiles; ++t) {
-    const float* p = partials + (((long)b * ntiles + t) * groups + gi) * 2;
-    s += p[0]; ss += p[1];
+// GroupNorm pass 1b: reduce the row-tile partials -> mean / rstd per (sample, group).  One workgroup per sample;
+// 8 threads per group each sum a strided share of the tiles (loads in parallel, not a 128-deep dependent chain),
+// then lane 0 of each octet adds the 8 shares in fixed order (deterministic).
+__global__ void __launch_bounds__(512)
+k_gn_finalize(const float* __restrict__ partials, int ntiles, int groups, float n, float eps,
+              float* __restrict__ stats) {
+  __shared__ float sh[64][8][2];
+  const int b = blockIdx.x, gi = threadIdx.x >> 3, part = threadIdx.x & 7;
+  if (gi < groups) {
+    float s = 0.f, ss = 0.f;
+    for (int t = part; t < ntiles; t += 8) {
+      const float* p = partials + (((long)b * ntiles + t) * groups + gi) * 2;
+      s += p[0]; ss += p[1];
+    }
+    sh[gi][part][0] = s; sh[gi][part][1] = ss;
   }
-  const float mean = s / n;
-  const float var = fmaxf(ss / n - mean * mean, 0.f);
-  stats[((long)b * groups + gi) * 2 + 0] = mean;
-  stats[((long)b * groups + gi) * 2 + 1] = rsqrtf(var + eps);
+  __syncthreads();
+  if (gi < groups && part == 0) {
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s += sh[gi][k][0]; ss += sh[gi][k][1]; }
+    const float mean = s / n;
+    const float var = fmaxf(ss / n - mean * mean, 0.f);
+    stats[((long)b * groups + gi) * 2 + 0] = mean;
+    stats[((long)b * groups + gi) * 2 + 1] = rsqrtf(var + eps);
+  }
 }
 
 // GroupNorm pass 2: normalise + affine (+SiLU), write the (concatenated) map.
@@ -196,11 +208,11 @@ template <typename T>
 __global__ void __launch_bounds__(THREADS)
 k_conv_in(const float* __restrict__ lat, const unsigned short* __restrict__ w, const float* __restrict__ bias,
           int B, int cin, int H, int W, int cout, unsigned short* __restrict__ out) {
-  extern __shared__ float wl[];                   // [9*cin][cout] as f32: lanes (consecutive channel chunks) read
-  const int kk = 9 * cin;                         // consecutive addresses -> conflict-free ds_read_b128
+  extern __shared__ float wl[];                   // [9*cin][2 halves][cout/8 chunks][4] as f32: consecutive lanes
+  const int kk = 9 * cin;                         // (channel chunks) read consecutive 16-B slots -> conflict-free b128
   for (int i = threadIdx.x; i < cout * kk; i += THREADS) {
     const int co = i / kk, k = i - co * kk;
-    wl[k * cout + co] = T::to_f(w[i]);
+    wl[((k * 2 + ((co >> 2) & 1)) * (cout / 8) + (co >> 3)) * 4 + (co & 3)] = T::to_f(w[i]);
   }
   __syncthreads();
   const int cchunks = cout / 8;
@@ -212,13 +224,24 @@ k_conv_in(const float* __restrict__ lat, const unsigned short* __restrict__ w, c
     float acc[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[k] = bias[cc * 8 + k];
-    for (int tap = 0; tap < 9; ++tap) {
-      const int iy = yh + tap / 3 - 1, ix = xw + tap % 3 - 1;
-      if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
-      for (int c = 0; c < cin; ++c) {
-        const float v = lat[(((long)b * cin + c) * H + iy) * W + ix];
+    const float* lb = lat + (long)b * cin * H * W;
+    for (int c = 0; c < cin; ++c) {
+      float v[9];                                 // the 3x3 window: clamped (always valid) loads, zeroed by select
 #pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] = fmaf(v, wl[(tap * cin + c) * cout + cc * 8 + k], acc[k]);
+      for (int tap = 0; tap < 9; ++tap) {
+        const int iy = yh + tap / 3 - 1, ix = xw + tap % 3 - 1;
+        const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const float t = lb[((long)c * H + min(max(iy, 0), H - 1)) * W + min(max(ix, 0), W - 1)];
+        v[tap] = ok ? t : 0.f;
+      }
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const float4 w0 = *reinterpret_cast<const float4*>(&wl[(((tap * cin + c) * 2 + 0) * cchunks + cc) * 4]);
+        const float4 w1 = *reinterpret_cast<const float4*>(&wl[(((tap * cin + c) * 2 + 1) * cchunks + cc) * 4]);
+        acc[0] = fmaf(v[tap], w0.x, acc[0]); acc[1] = fmaf(v[tap], w0.y, acc[1]);
+        acc[2] = fmaf(v[tap], w0.z, acc[2]); acc[3] = fmaf(v[tap], w0.w, acc[3]);
+        acc[4] = fmaf(v[tap], w1.x, acc[4]); acc[5] = fmaf(v[tap], w1.y, acc[5]);
+        acc[6] = fmaf(v[tap], w1.z, acc[6]); acc[7] = fmaf(v[tap], w1.w, acc[7]);
       }
     }
     *reinterpret_cast<u32x4*>(out + pix * cout + cc * 8) = pack8<T>(acc);
@@ -269,7 +292,7 @@ int groupnorm_impl(const void* x, const void* x2, int32_t batch, int32_t hw, int
   float* partials = stats_ws + (size_t)batch * groups * 2;          // [B][ntiles][G][2] after the final stats
   hipLaunchKernelGGL((k_gn_stats<T>), dim3(batch, ntiles), dim3(THREADS), lds, st, (const unsigned short*)x,
                      (const unsigned short*)x2, hw, c1, c2, groups, rows_per_tile, ct, nch, partials);
-  hipLaunchKernelGGL(k_gn_finalize, dim3(batch), dim3(64), 0, st, partials, ntiles, groups,
+  hipLaunchKernelGGL(k_gn_finalize, dim3(batch), dim3(512), 0, st, partials, ntiles, groups,
                      (float)hw * (float)(C / groups), eps, stats_ws);
   int rows_per_block = (256 * 8 * 4) / C;     // ~4 chunks per thread
   if (rows_per_block < 1) rows_per_block = 1;

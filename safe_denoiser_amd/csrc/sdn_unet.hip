@@ -844,6 +844,26 @@ static int run_plan(sdn_unet* u, const void* weights, const float* latents, floa
 
 void sdn_unet_profile_next(sdn_unet* u) { if (u) u->profile_next = true; }
 
+// Undeclared debug hook (tools/profile_ops.py): per-launch rows of the profiled forward, in plan order.
+// out[i*6 + {0..5}] = {ms, flops, bytes, M, N, K}; labels[i*24..] = kernel label.  Returns the op count.
+extern "C" int sdn_debug_profile_ops(sdn_unet* u, double* out, char* labels, int max_ops) {
+  if (!u || !out || !labels || u->profiled_batch <= 0) return -1;
+  Plan* p = get_plan(u, u->profiled_batch);
+  int n = 0;
+  for (size_t i = 0; i < p->ops.size() && n < max_ops; ++i, ++n) {
+    if (hipEventSynchronize(u->ev[2 * i + 1]) != hipSuccess) return -2;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, u->ev[2 * i], u->ev[2 * i + 1]) != hipSuccess) return -2;
+    const Op& o = p->ops[i];
+    out[n * 6 + 0] = ms; out[n * 6 + 1] = o.flops; out[n * 6 + 2] = o.bytes;
+    out[n * 6 + 3] = o.kind == OP_GEMM ? o.gd.M : (o.kind == OP_ATTN ? o.nq : o.rows);
+    out[n * 6 + 4] = o.kind == OP_GEMM ? o.gd.N : (o.kind == OP_ATTN ? o.nk : o.c1);
+    out[n * 6 + 5] = o.kind == OP_GEMM ? o.gd.K : (o.kind == OP_ATTN ? o.hd : o.c2);
+    memcpy(labels + n * 24, o.label, 24);
+  }
+  return n;
+}
+
 int sdn_unet_profile_read(sdn_unet* u, sdn_profile_row* rows, int32_t max_rows) {
   if (!u || !rows || max_rows <= 0 || u->profiled_batch <= 0) return SDN_E_INVALID;
   Plan* p = get_plan(u, u->profiled_batch);

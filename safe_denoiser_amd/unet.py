@@ -145,6 +145,27 @@ class UNet2DConditionModel:
         self._weights = self.pack_state_dict(sd).to(device)
         return self
 
+    def load_synthetic_on_device(self, seed: int = 1234, device="cuda"):
+        """Random weights generated DIRECTLY in the packed engine layout on the GPU (benchmarks: no checkpoints exist
+        on the box and the 0.86 G-parameter CPU generate+pack path takes tens of seconds per rank).  Same distributions
+        as synthetic_state_dict(); the values are not the CPU generator's, so parity tests use the state_dict path."""
+        _lib.require_gpu()
+        g = torch.Generator(device=device).manual_seed(seed)
+        buf = torch.zeros(self.weight_bytes, dtype=torch.uint8, device=device)
+        for p in self.manifest:
+            n = p["rows"] * max(p["cols"], 1)
+            if p["kind"] in (P_VEC_F32, P_GEGLU_VEC):
+                is_gain = (".norm" in p["name"] or p["name"].startswith("conv_norm_out")) and p["name"].endswith("weight")
+                is_nb = (".norm" in p["name"] or p["name"].startswith("conv_norm_out")) and p["name"].endswith("bias")
+                amp = 0.1 if (is_gain or is_nb) else 0.2
+                t = (torch.rand(n, generator=g, device=device) - 0.5) * amp + (1.0 if is_gain else 0.0)
+                buf[p["offset"]:p["offset"] + 4 * n] = t.view(torch.uint8)
+            else:
+                t = ((torch.rand(n, generator=g, device=device) * 2 - 1) * (3.0 / max(p["cols"], 1)) ** 0.5).to(self.dtype)
+                buf[p["offset"]:p["offset"] + 2 * n] = t.view(torch.uint8)
+        self._weights = buf
+        return self
+
     # ---- forward --------------------------------------------------------------------------------------
     def flops(self, batch: int):
         a = C.c_double()
