@@ -180,6 +180,15 @@ def main():
     rep_ms = e0.elapsed_time(e1) / 20
     rep_bytes = args.refs * 16384 * 4 + 2 * P * 16384 * 4
 
+    # HBM bytes per launch of the dominant kernel from the PMC passes (tools/pmc_traffic.py; collected in separate
+    # rocprofv3 --pmc runs, which cannot be combined with timing) -- read from profiles/ when present
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, "profiles", "round1_traffic.json")
+    if os.path.exists(tpath):
+        want = dom.replace("k_gemm<", "k_gemm_dma<Sdn" + ("F16" if args.dtype == "f16" else "BF16") + ", ").replace(">", ",")
+        for kname, rec in json.load(open(tpath)).items():
+            if want in kname:
+                traffic, traffic_src = rec["hbm_bytes_per_launch"], "profiles/round1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)"
     n_img = world * P * args.steps
     value = n_img / dt
     line = {
@@ -193,7 +202,8 @@ def main():
                    "prompts_per_batch": P, "images_timed": n_img, "beta_threshold": beta,
                    "renoise_draws_rank0": renoise, "parallelism": f"prompt-shard x{world}"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None, "kernel": dom,
+                     "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                     "algorithmic_bytes_per_launch": d["bytes"] / d["launches"], "kernel": dom,
                      "launches_per_forward": d["launches"] // 3, "avg_launch_us": d["ms"] / d["launches"] * 1e3,
                      "share_of_unet_time": d["ms"] / 3 / unet_ms},
         "attention_roofline": {"achieved": attn_tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",

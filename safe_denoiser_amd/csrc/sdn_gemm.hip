@@ -162,7 +162,7 @@ k_gemm_dma(const GemmArgs g) {
   const __amdgpu_buffer_rsrc_t rs_a2 = make_rsrc(g.a2 ? g.a2 : g.a, (unsigned)(g.a2 ? a_rows * ld2 * 2 : 0));
 
   // k-tile cursor (issue() is always called for consecutive k-tiles)
-  int cur_k0 = 0, cur_c0 = 0, cur_ty = 0, cur_tx = 0;
+  int cur_k0 = 0, cur_c0 = 0, cur_ty = 0, cur_tx = 0, w_k0 = 0;
   auto issue = [&](int buf) {
     unsigned char* sa = smem + buf * STAGE;
     unsigned char* sw = sa + BM * 128;
@@ -184,8 +184,11 @@ k_gemm_dma(const GemmArgs g) {
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a1, (lds_ptr_t)(sa + (wid * A_PIECES + i) * 1024), 16, off, 0, 0, 0);
         }
       }
-      cur_c0 += BK;
-      if (cur_c0 == g.Cin) { cur_c0 = 0; if (++cur_tx == 3) { cur_tx = 0; ++cur_ty; } }
+      // k order = channel-chunk OUTER, tap INNER: the 9 shifted re-reads of one 64-channel slice of the input rows
+      // are consecutive k-tiles, so the slice (49 KB per tile at 64x64) is still in the XCD's L2 when it is re-read;
+      // tap-outer order kept the whole 320..2560-channel halo live (8 MB per XCD > 4 MiB L2) and re-fetched it 9x.
+      w_k0 = (cur_ty * 3 + cur_tx) * g.Cin + cur_c0;
+      if (++cur_tx == 3) { cur_tx = 0; if (++cur_ty == 3) { cur_ty = 0; cur_c0 += BK; } }
     } else {
       if (cur_k0 >= g.K1) {
         const unsigned kb = (unsigned)((cur_k0 - g.K1) * 2);
@@ -203,7 +206,7 @@ k_gemm_dma(const GemmArgs g) {
     for (int i = 0; i < W_PIECES; ++i) {
       if (w_ok[i])
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(sw + (wid * W_PIECES + i) * 1024), 16,
-                                                 w_off[i] + (unsigned)(cur_k0 * 2), 0, 0, 0);
+                                                 w_off[i] + (unsigned)((g.a_mode == 1 ? w_k0 : cur_k0) * 2), 0, 0, 0);
     }
     cur_k0 += BK;
   };
