@@ -179,6 +179,14 @@ def main():
     e1.record(); torch.cuda.synchronize()
     rep_ms = e0.elapsed_time(e1) / 20
     rep_bytes = args.refs * 16384 * 4 + 2 * P * 16384 * 4
+    x1q = torch.randn(1, 4, 64, 64, device=dev)                      # the reference's own shape: one query per call
+    proc.conditioning_device(x1q)
+    e0.record()
+    for _ in range(50):
+        proc.conditioning_device(x1q)
+    e1.record(); torch.cuda.synchronize()
+    rep1_ms = e0.elapsed_time(e1) / 50
+    rep1_bytes = args.refs * 16384 * 4 + 2 * 16384 * 4
 
     # HBM bytes per launch of the dominant kernel from the PMC passes (tools/pmc_traffic.py; collected in separate
     # rocprofv3 --pmc runs, which cannot be combined with timing) -- read from profiles/ when present
@@ -215,7 +223,10 @@ def main():
                  "by_kernel_ms": {k_: v["ms"] / 3 for k_, v in sorted(rows_acc.items(), key=lambda kv: -kv[1]["ms"])}},
         "repellency_roofline": {"bound": "hbm", "achieved": rep_bytes / (rep_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
                                 "unit": "GB/s", "frac": rep_bytes / (rep_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                                "us_per_call": rep_ms * 1e3, "queries": P},
+                                "us_per_call": rep_ms * 1e3, "queries": P,
+                                "single_query": {"us_per_call": rep1_ms * 1e3,
+                                                 "achieved": rep1_bytes / (rep1_ms * 1e-3) / 1e9,
+                                                 "frac": rep1_bytes / (rep1_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}},
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -1,0 +1,78 @@
+"""SAFREE text-side projection: the once-per-prompt preprocessing that produces the
+`rescaled_text_embeddings` and the self-validation-filter step count the denoising loop consumes.
+
+Restates models/textuals_visual/modified_safree_diffusion_pipeline_threshold_time.py:19-99 (f_beta,
+projection_matrix, projection_and_orthogonal, safree_projection) and :458-486 (call order, beta).  It runs ONCE per
+prompt on [<=77, 768] matrices (the reference runs it with torch on the GPU too); it is host orchestration outside the
+step loop, so it is written with torch ops here -- the hot path proper stays in libsdn.  The CLIP encodes it needs
+(`masked_embs` = pooled embedding of the prompt with each token masked in turn, `negspace` = pooled embeddings of the
+negative-concept phrases) come from the text encoder, which is outside this engine: pass them in.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+
+def f_beta(z: float, btype: str = "sigmoid", upperbound_timestep: int = 10, concept_type: str = "nudity") -> int:
+    """Self-validation filter: number of leading steps that use the projected embeddings (:19-36)."""
+    t, k = (5.5, 3.5) if "artists-" in concept_type else (5.333, 2.5)
+    if btype == "tanh":
+        return round(upperbound_timestep / 2.0 * (math.tanh(k * (10 * z - t)) + 1))
+    if btype == "sigmoid":
+        return round(upperbound_timestep * (1.0 / (1.0 + math.exp(-2.0 * k * (10 * z - t)))))
+    raise NotImplementedError("btype is incorrect")
+
+
+def projection_matrix(E: torch.Tensor) -> torch.Tensor:
+    """Projector onto span(columns of E): E (E^T E)^+ E^T (:38-41)."""
+    return E @ torch.pinverse(E.T @ E) @ E.T
+
+
+def safree_projection(input_embeddings: torch.Tensor, p_emb: torch.Tensor, masked_proj: torch.Tensor,
+                      concept_proj: torch.Tensor, alpha: float = 0.0, max_length: int = 77):
+    """Token-wise replacement of trigger tokens by (I - P_c) P_m e (:56-99).
+    input_embeddings [2,77,768] (uncond, text); p_emb [n_t,768]; returns ([2,77,768], n_removed)."""
+    n_t, dim = p_emb.shape
+    eye_m_c = torch.eye(dim, device=p_emb.device, dtype=p_emb.dtype) - concept_proj
+    dist = torch.norm(eye_m_c @ p_emb.T, dim=0)                              # distance of each masked prompt to the concept space
+    loo_mean = (dist.sum() - dist) / (n_t - 1) if n_t > 1 else torch.full_like(dist, float("nan"))
+    keep = (dist < (1.0 + alpha) * loo_mean).float()                         # 1 = safe token, 0 = trigger token
+    mask = torch.ones(max_length, device=p_emb.device, dtype=p_emb.dtype)
+    mask[1:n_t + 1] = keep
+    uncond_e, text_e = input_embeddings.chunk(2)
+    text_e = text_e.squeeze(0)
+    projected = (eye_m_c @ masked_proj @ text_e.T).T
+    merged = torch.where(mask.bool()[:, None], text_e, projected)
+    return torch.cat([uncond_e, merged.unsqueeze(0)]), int(n_t - keep.sum())
+
+
+def projection_and_orthogonal(input_embeddings, masked_proj, concept_proj):
+    """(I - P_c) P_m applied to every token (:44-54)."""
+    dim = masked_proj.shape[0]
+    uncond_e, text_e = input_embeddings.chunk(2)
+    new_text = ((torch.eye(dim, device=text_e.device, dtype=text_e.dtype) - concept_proj) @ masked_proj
+                @ text_e.squeeze(0).T).T[None]
+    return torch.cat([uncond_e, new_text])
+
+
+def prepare(text_embeddings: torch.Tensor, masked_embs: torch.Tensor, negspace: torch.Tensor,
+            attention_mask: torch.Tensor, *, alpha: float = 0.01, svf: bool = True, up_t: int = 10,
+            category: str = "nudity") -> dict:
+    """The reference's call sequence (:458-486).  Returns what SafeDenoiserPipeline takes:
+    rescaled_text_embeddings, beta_adjusted (None when svf is off), plus diagnostics."""
+    P_c = projection_matrix(negspace.T)
+    P_m = projection_matrix(masked_embs.T)
+    rescaled, n_removed = safree_projection(text_embeddings, masked_embs, P_m, P_c, alpha=alpha,
+                                            max_length=text_embeddings.shape[1])
+    out = {"rescaled_text_embeddings": rescaled, "n_removed": n_removed, "beta_adjusted": None, "beta": None}
+    if svf:
+        proj_ort = projection_and_orthogonal(text_embeddings, P_m, P_c)
+        act = attention_mask.reshape(-1) == 1
+        text_e = text_embeddings[1][act]
+        po = proj_ort[1][act]
+        beta = 1.0 - float(torch.nn.functional.cosine_similarity(po, text_e).mean())
+        out["beta"] = beta
+        out["beta_adjusted"] = f_beta(beta, upperbound_timestep=up_t, concept_type=category)
+    return out

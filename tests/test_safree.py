@@ -1,0 +1,37 @@
+"""SAFREE text projection (next-row f1): torch implementation vs an independent numpy restatement; f_beta KATs."""
+import numpy as np
+import torch
+
+from oracle import safree as osf
+from safe_denoiser_amd import safree
+
+
+def test_f_beta_known_values():
+    # sigmoid(2*2.5*(10 z - 5.333)) * 10, rounded
+    assert safree.f_beta(0.0) == 0 and safree.f_beta(1.0) == 10
+    assert safree.f_beta(0.5333) == 5
+    assert safree.f_beta(0.6, btype="tanh") == round(5 * (np.tanh(2.5 * (6 - 5.333)) + 1))
+    assert safree.f_beta(0.55, concept_type="artists-VanGogh") == round(10 / (1 + np.exp(-2 * 3.5 * (5.5 - 5.5))))
+
+
+def test_projection_and_token_replacement_match_numpy():
+    g = torch.Generator().manual_seed(0)
+    dim, n_t, n_neg = 96, 9, 17
+    E = torch.randn(2, 77, dim, generator=g, dtype=torch.float64)
+    neg = torch.randn(n_neg, dim, generator=g, dtype=torch.float64)
+    masked = torch.randn(n_t, dim, generator=g, dtype=torch.float64)
+    masked[3] = neg[:4].mean(0) * 3 + 0.05 * masked[3]                      # token 3 lies near the concept space
+    am = torch.zeros(77); am[:n_t + 2] = 1
+    out = safree.prepare(E, masked, neg, am, alpha=0.01, svf=True, up_t=10)
+    P_c, P_m = osf.proj(neg.numpy().T), osf.proj(masked.numpy().T)
+    # projector properties
+    np.testing.assert_allclose(safree.projection_matrix(neg.T).numpy(), P_c, atol=1e-9)
+    np.testing.assert_allclose(P_c @ P_c, P_c, atol=1e-9)
+    ref, n_removed = osf.safree(E.numpy(), masked.numpy(), 0.01)(P_m, P_c)
+    np.testing.assert_allclose(out["rescaled_text_embeddings"].numpy(), ref, atol=1e-9)
+    assert out["n_removed"] == n_removed >= 1
+    # untouched rows: unconditional branch, BOS token, padding beyond the prompt
+    assert torch.equal(out["rescaled_text_embeddings"][0], E[0])
+    assert torch.equal(out["rescaled_text_embeddings"][1, 0], E[1, 0])
+    assert torch.equal(out["rescaled_text_embeddings"][1, n_t + 1:], E[1, n_t + 1:])
+    assert 0 <= out["beta_adjusted"] <= 10 and 0.0 <= out["beta"] <= 2.0
