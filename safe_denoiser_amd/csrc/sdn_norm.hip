@@ -115,12 +115,17 @@ __global__ void __launch_bounds__(THREADS)
 k_gn_apply(const unsigned short* __restrict__ x, const unsigned short* __restrict__ x2, int hw, int c1, int c2,
            int groups, int rows_per_block, int silu, const float* __restrict__ gamma,
            const float* __restrict__ beta, const float* __restrict__ stats, unsigned short* __restrict__ out) {
-  __shared__ float s_mean[64], s_rstd[64];
+  // per-channel affine of this sample, built once per workgroup: y = x * ca[c] + cb[c]   (ca = rstd_g * gamma_c,
+  // cb = beta_c - mean_g * ca) -- the channel -> group division leaves the per-element loop
+  extern __shared__ float aff[];                 // [2][C]
   const int C = c1 + c2, cpg = C / groups, cchunks = C / 8;
   const int b = blockIdx.x;
-  if (threadIdx.x < groups) {
-    s_mean[threadIdx.x] = stats[((long)b * groups + threadIdx.x) * 2 + 0];
-    s_rstd[threadIdx.x] = stats[((long)b * groups + threadIdx.x) * 2 + 1];
+  float* ca = aff; float* cb = aff + C;
+  for (int c = threadIdx.x; c < C; c += THREADS) {
+    const int gi = c / cpg;
+    const float mean = stats[((long)b * groups + gi) * 2 + 0], rstd = stats[((long)b * groups + gi) * 2 + 1];
+    const float a = rstd * gamma[c];
+    ca[c] = a; cb[c] = beta[c] - mean * a;
   }
   __syncthreads();
   const int r_lo = blockIdx.y * rows_per_block, r_hi = min(hw, r_lo + rows_per_block);
@@ -132,14 +137,13 @@ k_gn_apply(const unsigned short* __restrict__ x, const unsigned short* __restric
     const u32x4 v = *reinterpret_cast<const u32x4*>(src + ((long)b * hw + r) * ld + cc);
     float f[8];
     unpack8<T>(v, f);
-    const float4 g0 = *reinterpret_cast<const float4*>(gamma + ch0), g1 = *reinterpret_cast<const float4*>(gamma + ch0 + 4);
-    const float4 b0 = *reinterpret_cast<const float4*>(beta + ch0), b1 = *reinterpret_cast<const float4*>(beta + ch0 + 4);
-    const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-    const float bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    const float4 a0 = *reinterpret_cast<const float4*>(ca + ch0), a1 = *reinterpret_cast<const float4*>(ca + ch0 + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(cb + ch0), b1 = *reinterpret_cast<const float4*>(cb + ch0 + 4);
+    const float am[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    const float bm[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const int gi = (ch0 + k) / cpg;
-      float y = (f[k] - s_mean[gi]) * s_rstd[gi] * gm[k] + bt[k];
+      const float y = fmaf(f[k], am[k], bm[k]);
       f[k] = silu ? silu_f(y) : y;
     }
     *reinterpret_cast<u32x4*>(out + ((long)b * hw + r) * C + ch0) = pack8<T>(f);
@@ -294,10 +298,10 @@ int groupnorm_impl(const void* x, const void* x2, int32_t batch, int32_t hw, int
                      (const unsigned short*)x2, hw, c1, c2, groups, rows_per_tile, ct, nch, partials);
   hipLaunchKernelGGL(k_gn_finalize, dim3(batch), dim3(512), 0, st, partials, ntiles, groups,
                      (float)hw * (float)(C / groups), eps, stats_ws);
-  int rows_per_block = (256 * 8 * 4) / C;     // ~4 chunks per thread
+  int rows_per_block = (256 * 8 * 16) / C;    // ~16 chunks per thread (amortises the per-workgroup affine table)
   if (rows_per_block < 1) rows_per_block = 1;
   const int nblk = (hw + rows_per_block - 1) / rows_per_block;
-  hipLaunchKernelGGL((k_gn_apply<T>), dim3(batch, nblk), dim3(THREADS), 0, st, (const unsigned short*)x,
+  hipLaunchKernelGGL((k_gn_apply<T>), dim3(batch, nblk), dim3(THREADS), (size_t)2 * C * sizeof(float), st, (const unsigned short*)x,
                      (const unsigned short*)x2, hw, c1, c2, groups, rows_per_block, silu, gamma, beta, stats_ws,
                      (unsigned short*)out);
   return sdn_launch_status();
