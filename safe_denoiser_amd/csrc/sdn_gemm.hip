@@ -22,6 +22,8 @@
 #include "sdn_common.h"
 #include "sdn_ops.h"
 
+static int g_gemm_variant = 0;     // debug A/B switch, see sdn_debug_set_gemm_variant
+
 namespace sdn_gemm_detail {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -101,18 +103,20 @@ k_gemm_dma(const GemmArgs g) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
 
   const int nt = g.tiles_m * g.tiles_n;
-  int tile;
-  {
-    const int bid = blockIdx.x, q = nt >> 3, r = nt & 7, x = bid & 7;
-    tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
-  }
-  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
-
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: LDS-DMA bases go to M0, no waterfall
   const int wm = wid >> 1, wn = wid & 1;
   const int lrow = lane >> 3;                                // row inside a piece
+  // (A persistent tile loop -- one residency of workgroups walking all tiles -- was measured: +-3 %, i.e. workgroup
+  //  dispatch is not what the short-K shapes pay for, and it costs 30 VGPRs; one tile per workgroup is kept.)
+  int tile;
+  {
+    const int vid = blockIdx.x;
+    const int q = nt >> 3, r = nt & 7, x = vid & 7;
+    tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (vid >> 3);
+  }
+  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
   const int lchunk = (lane & 7) ^ lrow;                      // logical 16-B chunk this lane fetches
 
   // ---- per-lane source rows (fixed across k).  All per-k-tile address work is strength-reduced to
@@ -308,7 +312,6 @@ int sdn_gemm_pick_nrep(int n_padded, int act) {
   return 0;
 }
 
-static int g_gemm_variant = 0;
 // Undeclared debug hook for in-process A/B timing (tools/bench_gemm.py): 2 = tile heuristic off, >=16: ablations.
 extern "C" void sdn_debug_set_gemm_variant(int v) { g_gemm_variant = v; }
 
