@@ -108,6 +108,18 @@ int sdn_repel_calibrate(const sdn_repel_params* p_host, const float* queries, co
 int sdn_cfg_combine(const float* model_out, int32_t n_prompt, int32_t n_branch, int64_t d,
                     float guidance_scale, float* eps, void* stream);
 
+/*
+ * Safe-latent-diffusion guidance (SLD eq. 3-8) for the 3-branch model output [P uncond | P text | P safety concept]:
+ *   scale = min(|e_t - e_c| * sld_guidance_scale, 1), zeroed where (e_t - e_c) >= sld_threshold
+ *   gs    = (e_c - e_u) * scale + sld_momentum_scale * momentum ;  momentum <- beta * momentum + (1 - beta) * gs
+ *   eps   = e_u + g * ((e_t - e_u) - (apply_safety ? gs : 0))        apply_safety = (step index >= sld_warmup_steps)
+ * `momentum` [P, D] fp32 is the caller's state (zero before the first step), updated in place.
+ * Replaces models/textuals_visual/modified_sld_pipeline_threshold_time.py:467-503.
+ */
+int sdn_sld_guidance(const float* model_out, int32_t n_prompt, int64_t d, float guidance_scale,
+                     float sld_guidance_scale, float sld_threshold, float sld_momentum_scale, float sld_mom_beta,
+                     int32_t apply_safety, float* momentum, float* eps, void* stream);
+
 /* x0 = (x - sqrt_one_minus_ac * eps) / sqrt_ac, clamped to [-clip, clip] when clip > 0
  *   (epsilon prediction; DDPM/DDIM pred_original_sample).
  * Replaces DDPMScheduler.step(...).pred_original_sample at ...threshold_time.py:554 (diffusers 0.29.0). */

@@ -38,7 +38,7 @@ class TapeGenerator:
 
 def denoise_one(unet, scheduler, text_pair, p, noise_fn, *, num_inference_steps=50, guidance_scale=7.5,
                 repel=None, variant="threshold_time", lra=False, text_safe=None, use_safe_fn=None,
-                negation_warmup_start=None, negation_warmup_end=None):
+                negation_warmup_start=None, negation_warmup_end=None, sld=None):
     """text_pair: [2,77,768] (uncond, text) for prompt p.  repel: dict(flavour=..., proj_refs=..., **params) or None.
     Returns (final latents [1,C,S,S], stats)."""
     kind, lo_d, hi_d, use_beta, use_flag = VARIANTS[variant]
@@ -50,8 +50,9 @@ def denoise_one(unet, scheduler, text_pair, p, noise_fn, *, num_inference_steps=
     cfg = unet.cfg
     shape = (1, cfg["in_channels"], cfg["sample_size"], cfg["sample_size"])
     latents = gen.randn(shape) * scheduler.init_noise_sigma
-    nb = 3 if lra else 2
+    nb = 3 if (lra or sld) else 2
     n_renoise = 0
+    momentum = None            # SLD eq. 8 state (modified_sld_pipeline_threshold_time.py:455,474-503)
     for i, t in enumerate(scheduler.timesteps.tolist()):
         x_in = torch.cat([latents] * nb)
         E = text_safe if (text_safe is not None and use_safe_fn is not None and use_safe_fn(i)) else text_pair
@@ -59,7 +60,18 @@ def denoise_one(unet, scheduler, text_pair, p, noise_fn, *, num_inference_steps=
             E = torch.cat([E, text_pair[1:2]])
         out = unet(x_in, float(t), E)
         e_u, e_t = out[0:1], out[1:2]
-        eps = e_u + guidance_scale * (e_t - e_u)
+        guide = e_t - e_u
+        if sld:                                        # text_pair is then [3,77,768]: uncond, text, safety concept
+            e_c = out[2:3]
+            if momentum is None:
+                momentum = torch.zeros_like(guide)
+            scale = torch.clamp(torch.abs(e_t - e_c) * sld["scale"], max=1.0)
+            scale = torch.where((e_t - e_c) >= sld["thr"], torch.zeros_like(scale), scale)
+            gs = (e_c - e_u) * scale + sld["ms"] * momentum
+            momentum = sld["mb"] * momentum + (1 - sld["mb"]) * gs
+            if i >= sld["warmup"]:
+                guide = guide - gs
+        eps = e_u + guidance_scale * guide
         in_window = (kind is None) or (kind == "t" and lo <= t <= hi) or (kind == "i" and lo <= i <= hi)
         if in_window and repel is not None:
             x0_hat = _step(scheduler, eps, t, latents, gen, is_ddpm).pred_original_sample

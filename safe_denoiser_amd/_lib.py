@@ -76,6 +76,7 @@ SIGNATURES = {
     "sdn_repel_apply": (C.c_int, [C.POINTER(RepelParams), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sdn_repel_calibrate": (C.c_int, [C.POINTER(RepelParams), _vp, _vp, _vp, _vp, _sz, _vp]),
     "sdn_cfg_combine": (C.c_int, [_vp, _i32, _i32, _i64, _f32, _vp, _vp]),
+    "sdn_sld_guidance": (C.c_int, [_vp, _i32, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _vp, _vp]),
     "sdn_pred_x0": (C.c_int, [_vp, _vp, _i64, _f32, _f32, _f32, _vp, _vp]),
     "sdn_sched_step": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp]),
     "sdn_add_noise": (C.c_int, [_vp, _vp, _i64, _f32, _f32, _vp, _vp]),

@@ -22,6 +22,34 @@ k_cfg_combine(const float4* __restrict__ mo, int64_t pd4, float g, float4* __res
   }
 }
 
+// Safe-latent-diffusion guidance (eq. 3-8), one pass: reads the three branches + the momentum state, writes eps and the
+// new momentum.  Elementwise, so the float4 is processed lane-wise.
+__device__ __forceinline__ float sld_one(float u, float t, float c, float& mom, float g, float sg, float thr, float ms,
+                                         float mb, int apply) {
+  float guide = t - u;
+  float scale = fminf(fabsf(t - c) * sg, 1.f);                  // eq. 6
+  scale = (t - c) >= thr ? 0.f : scale;
+  float gs = (c - u) * scale;                                   // eq. 4
+  gs = gs + ms * mom;                                           // eq. 7
+  mom = mb * mom + (1.f - mb) * gs;                             // eq. 8
+  if (apply) guide -= gs;                                       // eq. 3 (after the warm-up)
+  return u + g * guide;
+}
+
+__global__ void __launch_bounds__(kThreads)
+k_sld_guidance(const float4* __restrict__ mo, int64_t pd4, float g, float sg, float thr, float ms, float mb, int apply,
+               float4* __restrict__ mom, float4* __restrict__ eps) {
+  for (int64_t i = blockIdx.x * (int64_t)kThreads + threadIdx.x; i < pd4; i += (int64_t)gridDim.x * kThreads) {
+    const float4 u = mo[i], t = mo[pd4 + i], c = mo[2 * pd4 + i];
+    float4 m = mom[i], o;
+    o.x = sld_one(u.x, t.x, c.x, m.x, g, sg, thr, ms, mb, apply);
+    o.y = sld_one(u.y, t.y, c.y, m.y, g, sg, thr, ms, mb, apply);
+    o.z = sld_one(u.z, t.z, c.z, m.z, g, sg, thr, ms, mb, apply);
+    o.w = sld_one(u.w, t.w, c.w, m.w, g, sg, thr, ms, mb, apply);
+    mom[i] = m; eps[i] = o;
+  }
+}
+
 __device__ __forceinline__ float x0_of(float x, float e, float sa, float s1) { return (x - s1 * e) / sa; }
 __device__ __forceinline__ float clampf(float v, float c) { return c > 0.f ? fminf(fmaxf(v, -c), c) : v; }
 
@@ -115,6 +143,20 @@ int sdn_cfg_combine(const float* model_out, int32_t n_prompt, int32_t n_branch, 
   if (pd4 == 0) return SDN_OK;
   hipLaunchKernelGGL(k_cfg_combine, dim3(grid_for(pd4)), dim3(kThreads), 0, (hipStream_t)stream,
                      (const float4*)model_out, pd4, g, (float4*)eps);
+  return sdn_launch_status();
+}
+
+int sdn_sld_guidance(const float* model_out, int32_t n_prompt, int64_t d, float guidance_scale, float sld_guidance_scale,
+                     float sld_threshold, float sld_momentum_scale, float sld_mom_beta, int32_t apply_safety,
+                     float* momentum, float* eps, void* stream) {
+  if (!model_out || !momentum || !eps || n_prompt < 0 || d < 0 || (d & 3) || !aligned16(model_out) ||
+      !aligned16(momentum) || !aligned16(eps))
+    return SDN_E_INVALID;
+  const int64_t pd4 = (int64_t)n_prompt * d / 4;
+  if (pd4 == 0) return SDN_OK;
+  hipLaunchKernelGGL(k_sld_guidance, dim3(grid_for(pd4)), dim3(kThreads), 0, (hipStream_t)stream,
+                     (const float4*)model_out, pd4, guidance_scale, sld_guidance_scale, sld_threshold, sld_momentum_scale,
+                     sld_mom_beta, apply_safety, (float4*)momentum, (float4*)eps);
   return sdn_launch_status();
 }
 

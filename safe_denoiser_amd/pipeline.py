@@ -64,17 +64,28 @@ class SafeDenoiserPipeline:
         sf = dict(safree=False, svf=False, lra=False, re_attn_t=(-1, -1))
         if safree_dict:
             sf.update(safree_dict)
+        # SLD family (modified_sld_pipeline*.py): third branch = safety concept, guidance eq. 3-8 with momentum state
+        sld = None
+        if kwargs.get("sld_guidance_scale", 0) and kwargs["sld_guidance_scale"] >= 1:
+            sld = dict(scale=float(kwargs["sld_guidance_scale"]), warmup=int(kwargs.get("sld_warmup_steps", 10)),
+                       thr=float(kwargs.get("sld_threshold", 0.01)), ms=float(kwargs.get("sld_momentum_scale", 0.3)),
+                       mb=float(kwargs.get("sld_mom_beta", 0.4)))
         kind, lo_default, hi_default, use_beta, use_flag = VARIANTS[self.variant]
         hi = kwargs.get("negation_warmup_start", hi_default)          # reference: t <= start and t >= end
         lo = kwargs.get("negation_warmup_end", lo_default)
-        nb = 3 if sf["lra"] else 2
+        nb = 3 if (sf["lra"] or sld) else 2
         if guidance_scale <= 1.0:
             raise NotImplementedError("guidance_scale <= 1 (no CFG) is not on the reference's benchmarked path")
         dev = torch.device("cuda", torch.cuda.current_device())
         E = prompt_embeddings.to(dev)
-        if E.shape[0] % 2 != 0:
-            raise _lib.SdnError("prompt_embeddings must be [2P,77,768]: P unconditional rows then P text rows")
-        P = E.shape[0] // 2
+        if sld:
+            if E.shape[0] % 3 != 0:
+                raise _lib.SdnError("SLD: prompt_embeddings must be [3P,77,768]: P uncond | P text | P safety concept")
+            P = E.shape[0] // 3
+        else:
+            if E.shape[0] % 2 != 0:
+                raise _lib.SdnError("prompt_embeddings must be [2P,77,768]: P unconditional rows then P text rows")
+            P = E.shape[0] // 2
         s = self.unet.config.sample_size
         height = height or s * self.vae_scale_factor
         width = width or s * self.vae_scale_factor
@@ -85,7 +96,7 @@ class SafeDenoiserPipeline:
         D = C_ * s * s
 
         # text branches: [uncond | E'(or E) | (text_e when lra)]  (...threshold_time.py:525-540)
-        E_plain = self._branches(E, E, nb)
+        E_plain = E if sld else self._branches(E, E, nb)
         E_safe = self._branches(rescaled_text_embeddings.to(dev), E, nb) if (sf["safree"] and rescaled_text_embeddings
                                                                              is not None) else None
         tb_plain = self.unet.prepare_text(E_plain)
@@ -115,6 +126,7 @@ class SafeDenoiserPipeline:
         is_ddpm = isinstance(sch, DDPMScheduler)
         n_renoise = 0
         n_window = 0
+        momentum = torch.zeros_like(eps) if sld else None
 
         for i, t in enumerate(timesteps):
             x_in.view(nb, P, C_, s, s).copy_(lat)                                   # cat([latents] * nb)
@@ -123,8 +135,13 @@ class SafeDenoiserPipeline:
             else:
                 use_safe = tb_safe is not None and sf["re_attn_t"][0] <= i <= sf["re_attn_t"][1]
             self.unet.forward_into(x_in, float(t), tb_safe if use_safe else tb_plain, model_out)
-            _lib.check(L.sdn_cfg_combine(model_out.data_ptr(), P, nb, D, float(guidance_scale), eps.data_ptr(), st),
-                       "sdn_cfg_combine")
+            if sld:
+                _lib.check(L.sdn_sld_guidance(model_out.data_ptr(), P, D, float(guidance_scale), sld["scale"], sld["thr"],
+                                              sld["ms"], sld["mb"], int(i >= sld["warmup"]), momentum.data_ptr(),
+                                              eps.data_ptr(), st), "sdn_sld_guidance")
+            else:
+                _lib.check(L.sdn_cfg_combine(model_out.data_ptr(), P, nb, D, float(guidance_scale), eps.data_ptr(), st),
+                           "sdn_cfg_combine")
 
             in_window = (kind is None) or (kind == "t" and lo <= t <= hi) or (kind == "i" and lo <= i <= hi)
             if in_window and repellency_processor is not None:

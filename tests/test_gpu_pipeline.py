@@ -156,3 +156,28 @@ def test_fp16_storage_loop_parity(tmp_path):
     errs = [rel_l2(lat[p:p + 1], ref[p:p + 1]) for p in range(P)]
     print(f"fp16 loop: per-prompt rel L2 {['%.2e' % e for e in errs]}")
     assert t_p.cur == t_o.cur and max(errs) <= 1.5e-2
+
+
+def test_sld_family_loop_matches_oracle(world, tmp_path):
+    """SLD pipelines (modified_sld_pipeline_threshold_time.py): 3 branches [uncond | text | safety concept], guidance
+    eq. 3-8 with momentum, then the same repellency window.  fp32 guidance math; bf16 UNet -> 8e-2 bound as above."""
+    u, sd, E, refs, P = world
+    g = torch.Generator().manual_seed(9)
+    concept = torch.randn(P, 77, 768, generator=g)
+    E3 = torch.cat([E, concept])                                   # [3P,77,768]
+    sld = dict(scale=1000.0, warmup=2, thr=0.02, ms=0.3, mb=0.4)
+    shape = (1, 4, 16, 16)
+    params = dict(sigma=3.15, scale=0.33, beta_threshold=1e-6, beta_threshold_margin=1e9)
+    t_o = Tapes(P, shape, 3 * STEPS + 4, seed=13)
+    unet = OracleUNet(sd, SMALL_O, act_dtype=torch.bfloat16)
+    ref = torch.cat([opipe.denoise_one(unet, osch.DDPM(), torch.stack([E3[p], E3[P + p], E3[2 * P + p]]), p, t_o,
+                                       num_inference_steps=STEPS, repel=dict(flavour="threshold", proj_refs=refs, **params),
+                                       sld=sld)[0] for p in range(P)])
+    t_p = Tapes(P, shape, 3 * STEPS + 4, seed=13)
+    pipe = SafeDenoiserPipeline(u, DDPMScheduler(), variant="threshold_time")
+    lat = pipe(prompt_embeddings=E3.cuda(), num_inference_steps=STEPS, repellency_processor=make_proc(thr, refs, tmp_path, **params),
+               noise_fn=t_p, sld_guidance_scale=sld["scale"], sld_warmup_steps=sld["warmup"], sld_threshold=sld["thr"],
+               sld_momentum_scale=sld["ms"], sld_mom_beta=sld["mb"])
+    errs = [rel_l2(lat[p:p + 1], ref[p:p + 1]) for p in range(P)]
+    print(f"sld loop: per-prompt rel L2 {['%.2e' % e for e in errs]}")
+    assert t_p.cur == t_o.cur and max(errs) <= 8e-2

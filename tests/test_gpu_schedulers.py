@@ -108,3 +108,25 @@ def test_flow_kernels():
     _lib.check(L.sdn_flow_renoise(x0r.data_ptr(), x1.data_ptr(), zg.data_ptr(), xg.numel(), sn, out.data_ptr(),
                                   _lib.stream_ptr()), "renoise")
     close(out, exp, rt=1e-5, at=1e-5)
+
+
+def test_sld_guidance_kernel_with_momentum_state():
+    """SLD eq. 3-8 over three steps (momentum carried), warm-up boundary included; fp32 elementwise."""
+    g = torch.Generator().manual_seed(6)
+    P, D = 3, 4 * 64 * 64
+    mom = torch.zeros(P, D); mg = mom.clone().cuda()
+    cfg = dict(scale=2000.0, thr=0.025, ms=0.5, mb=0.7)
+    for step in range(3):
+        mo = torch.randn(3 * P, D, generator=g) * 0.01 + torch.randn(1, D, generator=g)
+        u, t, c = mo[:P], mo[P:2 * P], mo[2 * P:]
+        scale = torch.clamp((t - c).abs() * cfg["scale"], max=1.0)
+        scale = torch.where((t - c) >= cfg["thr"], torch.zeros_like(scale), scale)
+        gs = (c - u) * scale + cfg["ms"] * mom
+        mom = cfg["mb"] * mom + (1 - cfg["mb"]) * gs
+        apply = step >= 1
+        exp = u + 7.5 * ((t - u) - (gs if apply else 0))
+        mog = mo.cuda(); out = torch.empty(P, D, device="cuda")
+        _lib.check(sda.lib().sdn_sld_guidance(mog.data_ptr(), P, D, 7.5, cfg["scale"], cfg["thr"], cfg["ms"], cfg["mb"],
+                                              int(apply), mg.data_ptr(), out.data_ptr(), _lib.stream_ptr()), "sld")
+        close(out, exp, rt=1e-5, at=1e-5)
+        close(mg, mom, rt=1e-5, at=1e-6)
