@@ -56,6 +56,7 @@ k_attn(const AttnArgs a) {
   constexpr int KQ = (HD + 15) / 16;          // 16-deep k-steps of Q K^T
   constexpr int NDB = (HD + 31) / 32;         // 32-row blocks of O^T
   constexpr bool ONES = (HD % 32) != 0;       // a free padding column exists -> row sums via MFMA
+  constexpr bool OFFSET_FREE = T::kDtype == 0; // bf16 has fp32's exponent range: softmax without max subtraction (below)
   constexpr int KSTR = KQ * 32 + 16;          // K tile row stride in bytes (+16 B pad against bank conflicts)
   constexpr int VSTR = NDB * 64 + 16;         // V tile row stride in bytes (multiple of 8 for the tr read)
   constexpr int STAGE = KV * KSTR + KV * VSTR;
@@ -101,6 +102,14 @@ k_attn(const AttnArgs a) {
     u32x4 v = (u32x4){0u, 0u, 0u, 0u};
     if (qvalid && dc < HD)
       v = *reinterpret_cast<const u32x4*>(row_ptr<SEG>(a.q, a.q2, a.ldq, a.ldq2, a.n1, a.nq, b, q0 + r) + head * HD + dc);
+    // fold scale * log2(e) into Q once (re-rounded to the storage type): the MFMA then yields scores already in
+    // log2 units, and the per-score FMA of the softmax disappears (VALU is this kernel's bound for d = 40)
+    if (OFFSET_FREE) {
+      v.x = T::pack2(T::to_f(v.x & 0xffff) * a.c, T::to_f(v.x >> 16) * a.c);
+      v.y = T::pack2(T::to_f(v.y & 0xffff) * a.c, T::to_f(v.y >> 16) * a.c);
+      v.z = T::pack2(T::to_f(v.z & 0xffff) * a.c, T::to_f(v.z >> 16) * a.c);
+      v.w = T::pack2(T::to_f(v.w & 0xffff) * a.c, T::to_f(v.w >> 16) * a.c);
+    }
     qf[s] = *reinterpret_cast<typename T::v8*>(&v);
   }
 
@@ -156,7 +165,8 @@ k_attn(const AttnArgs a) {
   for (int d = 0; d < NDB; ++d)
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[d][i] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
+  float m_run = OFFSET_FREE ? 0.f : -1e30f, l_run = 0.f;   // bf16: per-query exponent offset (0 = none); fp16: running max
+  float m_hi = -1e30f;                                     // bf16: running max of the scores (decides re-centring)
 
   // tr-read lane geometry
   const int gi = lane & 15, gq = gi >> 2, gp = gi & 3, gcol = 16 * ((lane >> 4) & 1);
@@ -203,10 +213,47 @@ k_attn(const AttnArgs a) {
       const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // both halves of the same query
       mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
     }
+    if constexpr (OFFSET_FREE) {
+    // Offset-free softmax: p = 2^(s - off) with a per-query offset that stays 0 while the tile maxima stay inside
+    // +-kGuard (in log2 units; 2^+-64 is comfortably inside the fp32 / bf16 / fp16-scaled range used here), so the
+    // common case needs NO subtraction and NO rescale of O -- softmax is invariant to the offset, the result is exact.
+    // A tile whose maximum leaves the window re-centres that query's offset (O and the row sum are rescaled once).
+    constexpr float kGuard = 64.f;
+    m_hi = fmaxf(m_hi, mx);                                    // running maximum of the scores seen so far
+    const float drift = m_hi - m_run;                          // m_run holds the current offset (0 until re-centred)
+    if (__builtin_amdgcn_ballot_w64(fabsf(drift) > kGuard) != 0) {       // wave-uniform, rare
+      // upward: the old sums shrink by 2^-(>64).  Downward can only happen on the first tile (m_hi never decreases),
+      // when the sums are still zero -- the exponent is clamped so that 0 * alpha stays 0 instead of 0 * inf.
+      const float m_new = fabsf(drift) > kGuard ? m_hi : m_run;
+      const float alpha = __builtin_amdgcn_exp2f(fminf(m_run - m_new, 126.f));
+      if (!ONES) l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
+      m_run = m_new;
+    }
+    if (__builtin_amdgcn_ballot_w64(m_run != 0.f) != 0) {                 // some query of this wave has an offset
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st[kb][i] = __builtin_amdgcn_exp2f(st[kb][i] - m_run);
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st[kb][i] = __builtin_amdgcn_exp2f(st[kb][i]);
+    }
+    if (!ONES) {
+      float ps = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) ps += st[0][i] + st[1][i];
+      l_run += ps;
+    }
+    } else {                                          // fp16: classic running-max form (fp16 P needs p <= 1)
     const float m_new = fmaxf(m_run, mx);
-    const bool moved = m_new != m_run;
     const float mc = m_new * a.c;
-    if (__builtin_amdgcn_ballot_w64(moved) != 0) {                       // wave-uniform: rescale only when needed
+    if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {              // wave-uniform: rescale only when needed
       const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * a.c);
       if (!ONES) l_run *= alpha;
 #pragma unroll
@@ -224,6 +271,7 @@ k_attn(const AttnArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) ps += st[0][i] + st[1][i];
       l_run += ps;
+    }
     }
 
     // ---- O^T += V^T P^T ----

@@ -185,6 +185,35 @@ def test_attention_fused_qkv_views_and_sharp_softmax():
     assert rel_l2(out, ref) <= 6e-3
 
 
+@pytest.mark.parametrize("kind", ["spike_up_late", "all_far_down", "up_then_down"])
+def test_attention_offset_recentering_branches(kind):
+    """bf16 attention runs the softmax WITHOUT max subtraction while every tile maximum stays within 2^+-64 of the
+    per-query offset; these inputs force the rare re-centring branch (guide rule 26: a data-dependent branch needs an
+    input that takes it): logits far above the window in a late tile, far below it everywhere, and both in turn."""
+    B, H, N, d = 1, 8, 512, 40
+    C_ = H * d
+    g = torch.Generator().manual_seed(35)
+    q = torch.randn(B, N, C_, generator=g) * 0.5
+    k = torch.randn(B, N, C_, generator=g) * 0.5
+    v = torch.randn(B, N, C_, generator=g)
+    if kind in ("spike_up_late", "up_then_down"):
+        q[0, 7, :d] = 6.0; k[0, 450, :d] = 6.0                       # head 0, query 7 x key 450: logit = 36*40/sqrt(40) = 228 nats
+    if kind in ("all_far_down", "up_then_down"):
+        q[0, 9, d:2 * d] = 8.0; k[0, :, d:2 * d] = -3.0 + 0.05 * torch.randn(N, d, generator=g)   # head 1, query 9: all ~ -150 nats
+    if kind == "up_then_down":
+        k[0, 100, :d] = 4.0                                            # an earlier, smaller spike for query 7 (two re-centres)
+    q, k, v = q.to(BF), k.to(BF), v.to(BF)
+    sp = lambda t: t.float().reshape(B, N, H, d).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(sp(q), sp(k), sp(v)).transpose(1, 2).reshape(B, N, C_)
+    out = ops.attention(q.cuda(), k.cuda(), v.cuda(), H)
+    assert torch.isfinite(out).all()
+    assert rel_l2(out, ref) <= 8e-3, rel_l2(out, ref)
+    # the forced rows themselves
+    for row, hd in ((7, 0), (9, 1)):
+        sl = slice(hd * d, (hd + 1) * d)
+        assert rel_l2(out[0, row, sl], ref[0, row, sl]) <= 2e-2
+
+
 # ------------------------------------------------------------------------------------------ conv_in / temb
 def test_conv_in_and_timestep_embedding():
     B, H = 2, 64
