@@ -119,6 +119,9 @@ struct sdn_unet {
   int64_t weight_bytes = 0;
   std::map<int, Plan> plans;
   int tproj_total = 0;
+  int64_t subbatch_bytes = 0;            // >0: run transformer blocks on batch slices of at most this many bytes per
+                                         // activation.  Measured at B = 64 (tools/profile_ops.py, SUBBATCH=...): 48 MB
+                                         // -> +5 %, 24 MB -> +10 % forward time, i.e. no cache-residency win -> OFF.
   bool profile_next = false;
   std::vector<hipEvent_t> ev;          // 2 per op of the profiled forward
   int profiled_batch = 0;
@@ -262,7 +265,27 @@ struct Builder {
   }
 
   // Transformer2DModel (continuous) with one BasicTransformerBlock.
+  // Optional sub-batching of the transformer blocks (every op of a block is per-sample independent; results are
+  // bit-identical).  It was built to test whether slicing the 168 MB activations of the 64x64 level keeps the chain of
+  // short-K projections Infinity-Cache resident; it does not pay (see subbatch_bytes), so it is off by default.
   Act transformer(const std::string& pfx, Act& x) {
+    const int64_t bytes_full = (int64_t)B * x.hw * x.C * 2;
+    int nsub = 1;
+    if (u->subbatch_bytes > 0)
+      while (nsub < B && bytes_full / nsub > u->subbatch_bytes && B % (nsub * 2) == 0) nsub *= 2;
+    Act out = act((int64_t)B * x.hw, x.C, x.hw, x.side);
+    const int Bfull = B, Bs = B / nsub;
+    for (int sb = 0; sb < nsub; ++sb) {
+      B = Bs;
+      Act xs = x, os = out;                                   // views: never dropped
+      xs.off += (int64_t)sb * Bs * x.hw * x.C * 2; os.off += (int64_t)sb * Bs * x.hw * x.C * 2;
+      transformer_body(pfx, xs, os, (int64_t)sb * Bs * u->cfg.text_len * u->cfg.cross_dim * 2);
+    }
+    B = Bfull;
+    return out;
+  }
+
+  void transformer_body(const std::string& pfx, Act& x, const Act& out, int64_t text_off) {
     const int C = x.C, hw = x.hw, T = u->cfg.text_len, X = u->cfg.cross_dim;
     const int64_t rows = (int64_t)B * hw;
     const std::string tb = pfx + ".transformer_blocks.0";
@@ -302,7 +325,7 @@ struct Builder {
     Act qb = act(rows, C, hw, x.side);
     gemm(rows, C, C, R(ln), q2w, Ref(), R(qb));
     Act kvb = act((int64_t)B * T, 2 * C);
-    gemm((int64_t)B * T, 2 * C, X, Ref{SP_TEXT, 0}, kv2, Ref(), R(kvb));
+    gemm((int64_t)B * T, 2 * C, X, Ref{SP_TEXT, text_off}, kv2, Ref(), R(kvb));
     attention(R(qb), R(kvb), Ref{SP_WS, kvb.off + (int64_t)C * 2}, R(at), hw, T, C, C, 2 * C, 2 * C);
     drop(qb); drop(kvb);
     Act h3 = act(rows, C, hw, x.side);
@@ -316,10 +339,8 @@ struct Builder {
     Act h4 = act(rows, C, hw, x.side);
     gemm(rows, C, 4 * C, R(ff), f2w, f2b, R(h4), SDN_ACT_NONE, R(h3));
     drop(ff); drop(h3);
-    Act out = act(rows, C, hw, x.side);
     gemm(rows, C, C, R(h4), pow_, pob, R(out), SDN_ACT_NONE, R(x));
     drop(h4);
-    return out;
   }
 
 
@@ -843,6 +864,13 @@ static int run_plan(sdn_unet* u, const void* weights, const float* latents, floa
 }
 
 void sdn_unet_profile_next(sdn_unet* u) { if (u) u->profile_next = true; }
+
+// Undeclared tuning hook (tools/): size threshold of the transformer sub-batching; rebuilds the plans.
+extern "C" void sdn_debug_set_subbatch_bytes(sdn_unet* u, long long bytes) {
+  if (!u || u->is_mmdit) return;
+  u->subbatch_bytes = bytes;
+  u->plans.clear();
+}
 
 // Undeclared debug hook (tools/profile_ops.py): per-launch rows of the profiled forward, in plan order.
 // out[i*6 + {0..5}] = {ms, flops, bytes, M, N, K}; labels[i*24..] = kernel label.  Returns the op count.

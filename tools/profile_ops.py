@@ -24,6 +24,8 @@ for p in u.manifest:
         t = ((torch.rand(n, generator=g, device="cuda") * 2 - 1) * (3.0 / max(p["cols"], 1)) ** 0.5).bfloat16()
         buf[p["offset"]:p["offset"] + 2 * n] = t.view(torch.uint8)
 u._weights = buf
+if os.environ.get("SUBBATCH") is not None:
+    sda.lib().sdn_debug_set_subbatch_bytes(u._h, C.c_longlong(int(os.environ["SUBBATCH"])))
 x = torch.randn(B, 4, 64, 64, device="cuda")
 e = u.prepare_text(torch.randn(B, 77, 768, device="cuda"))
 y = torch.empty_like(x)
@@ -35,9 +37,9 @@ lib.sdn_debug_profile_ops.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_in
 for _ in range(3):
     u.profile_next()
     u.forward_into(x, 981.0, e, y)
-    out = (C.c_double * (6 * 1024))()
-    lab = C.create_string_buffer(24 * 1024)
-    n = lib.sdn_debug_profile_ops(u._h, out, lab, 1024)
+    out = (C.c_double * (6 * 32768))()
+    lab = C.create_string_buffer(24 * 32768)
+    n = lib.sdn_debug_profile_ops(u._h, out, lab, 32768)
     for i in range(n):
         name = lab.raw[i * 24:(i + 1) * 24].split(b"\0")[0].decode()
         key = (name, int(out[i * 6 + 3]), int(out[i * 6 + 4]), int(out[i * 6 + 5]))
