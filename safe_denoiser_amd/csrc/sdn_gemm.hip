@@ -23,6 +23,7 @@
 #include "sdn_ops.h"
 
 static int g_gemm_variant = 0;     // debug A/B switch, see sdn_debug_set_gemm_variant
+static unsigned long long* g_gemm_stamps = nullptr;   // diagnostics buffer (4 x grid), see sdn_debug_set_gemm_stamps
 
 namespace sdn_gemm_detail {
 
@@ -39,6 +40,9 @@ struct GemmArgs {
   int a_mode, Hs, Ws, Cin, Ho, Wo, stride, upsample;
   int act, out_kind, rows_per_batch, ld_rowbias, ld_rowgate, residual_bcast, n_valid, ldc;
   int tiles_m, tiles_n;
+  int res_lds;               // residual goes through the LDS staging slab (16-bit staged output, offsets fit 31 bits)
+  unsigned res_bytes;        // buffer size of the residual for the DMA's bounds check
+  unsigned long long* stamps; // diagnostics: 4 s_memtime stamps per workgroup (tools/gemm_stamps.py); nullptr in production
   int dbg;                   // timing-only ablations (tools/bench_gemm.py): 1 = no global stores, 2 = DMA only for k-tile 0
 };
 
@@ -90,10 +94,18 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // WGM = waves along M (2 -> 128-row tile, 4 waves, 2 blocks/CU;  4 -> 256-row tile, 8 waves, 1 block/CU).
 // The 256 x 320 tile (WGM=4, NREP=10) halves the L2->LDS bytes per MFMA of the 128 x 160 tile: at 2 x 36.9 KB per
 // 1280 MFMA-cycles per CU the small tile needs ~57 B/clk/CU of L2 bandwidth -- ~90 % of what a CU can pull.
+#define SDN_STAMP(IDX)                                                                                   \
+  if (g.stamps && threadIdx.x == 0) {                                                                    \
+    unsigned long long t_;                                                                               \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                          \
+    g.stamps[(long)blockIdx.x * 4 + (IDX)] = t_;                                                         \
+  }
+
 template <typename T, int NREP, int WGM>
 __global__ void __launch_bounds__(128 * WGM, 2)
 k_gemm_dma(const GemmArgs g) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  SDN_STAMP(0)
   constexpr int BM = 64 * WGM, THREADS = 128 * WGM, NWAVES = 2 * WGM;
   constexpr int BN = 32 * NREP;
   constexpr int A_PIECES = BM / 8 / NWAVES;                  // 1-KiB pieces per wave: 4
@@ -215,18 +227,42 @@ k_gemm_dma(const GemmArgs g) {
     cur_k0 += BK;
   };
 
+  const int fr = lane & 15, fq = lane >> 4;
+  // Accumulators start at bias (+ the per-sample row bias): the loads overlap the first k-tile's DMA instead of sitting,
+  // one L2 round trip per fragment, in the epilogue (in-kernel stamps: the epilogue was 26-61 % of a workgroup's life).
+  // acc[i][j][e] <-> row m0 + wm*64 + i*16 + fr, column n0 + wn*16*NREP + j*16 + fq*4 + e.
   f32x4 acc[4][NREP];
+  if (g.bias) {
+    f32x4 bv[NREP];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < NREP; ++j) bv[j] = *reinterpret_cast<const f32x4*>(g.bias + n0 + wn * 16 * NREP + j * 16 + fq * 4);
 #pragma unroll
-    for (int j = 0; j < NREP; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NREP; ++j) acc[i][j] = bv[j];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NREP; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  if (g.rowbias) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wm * 64 + i * 16 + fr;
+      const int b = m < g.M ? m / g.rows_per_batch : 0;
+      const float* rbp = g.rowbias + (long)b * g.ld_rowbias + n0 + wn * 16 * NREP + fq * 4;
+#pragma unroll
+      for (int j = 0; j < NREP; ++j) acc[i][j] += *reinterpret_cast<const f32x4*>(rbp + j * 16);
+    }
+  }
 
   const int nk = g.K / BK;
   issue(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  SDN_STAMP(1)
 
-  const int fr = lane & 15, fq = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk && !(g.dbg & 2)) issue(buf ^ 1);
@@ -256,14 +292,21 @@ k_gemm_dma(const GemmArgs g) {
     __syncthreads();
   }
 
+  SDN_STAMP(2)
   // ---- epilogue ----
   // 16-bit outputs are staged through LDS (free after the k loop) so that HBM sees whole 16-byte-per-lane, row-
   // contiguous stores instead of 8-byte fragments at a row stride (guide T21: "widen the epilogue stores").
-  constexpr int CW = (BN + 8) * 2;                           // staged row stride in bytes (+16 B pad)
+  constexpr int CW_PAD = (BN + 8) * 2;                       // staged row stride in bytes (+16 B pad)
   const bool staged = g.out_kind == 0 && g.n_valid == g.N;
   const int out_cols = g.act == 2 ? BN / 2 : BN;             // columns this tile contributes to `out`
+  // Residual: its tile is DMA'd into the staging slab first (whole rows, 16 B per lane, every load in flight at once);
+  // each lane then adds its own 8-byte slot in fp32 and writes the packed sum back in place.  The DMA image is linear,
+  // so that layout has no row pad.  (Per-fragment global loads here cost one serialized L2/HBM round trip each.)
+  const bool res_lds = staged && g.res_lds;
+  const int CW = res_lds ? BN * 2 : CW_PAD;
+  const __amdgpu_buffer_rsrc_t rs_res = make_rsrc(g.residual ? g.residual : g.a, g.res_bytes);
   // the staged tile may exceed the LDS (256 x 320): stage PASSES groups of wave-rows one after the other
-  constexpr int PASSES = (BM * CW + 2 * STAGE - 1) / (2 * STAGE);
+  constexpr int PASSES = (BM * CW_PAD + 2 * STAGE - 1) / (2 * STAGE);
   constexpr int WM_PER_PASS = WGM / PASSES, ROWS_PER_PASS = 64 * WM_PER_PASS;
   static_assert(WGM % PASSES == 0, "pass split must divide the wave rows");
   static_assert(PASSES <= 2, "epilogue is written for at most two staging passes");
@@ -275,6 +318,7 @@ k_gemm_dma(const GemmArgs g) {
 #include "sdn_gemm_epilogue.inc"
 #undef SDN_PASS
   }
+  SDN_STAMP(3)
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
@@ -314,6 +358,7 @@ int sdn_gemm_pick_nrep(int n_padded, int act) {
 
 // Undeclared debug hook for in-process A/B timing (tools/bench_gemm.py): 2 = tile heuristic off, >=16: ablations.
 extern "C" void sdn_debug_set_gemm_variant(int v) { g_gemm_variant = v; }
+extern "C" void sdn_debug_set_gemm_stamps(void* p) { g_gemm_stamps = (unsigned long long*)p; }
 
 // Tile choice with the grid in mind: when the widest tile leaves the 256 CUs (x2 resident blocks) underfilled
 // (the 8x8 / 16x16 levels at small batch), fall back to BN = 64 to multiply the number of workgroups.
@@ -381,7 +426,14 @@ static int sdn_gemm_impl(int dtype, const sdn_gemm_desc* d, const void* a, const
   const int bn = 32 * nrep;
   const int bm = nrep >= 8 ? 256 : 128;
   g.tiles_m = (d->M + bm - 1) / bm; g.tiles_n = d->N / bn;
+  {
+    const long res_rows = d->residual_bcast ? (long)d->rows_per_batch : (long)d->M;
+    const long res_bytes = res_rows * g.ldc * 2;
+    g.res_lds = residual != nullptr && al16(residual) && res_bytes < (1L << 31) && g_gemm_variant != 4;   // variant 4: per-fragment loads (A/B)
+    g.res_bytes = g.res_lds ? (unsigned)res_bytes : 0u;
+  }
   g.dbg = g_gemm_variant >= 16 ? (g_gemm_variant >> 4) : 0;
+  g.stamps = g_gemm_stamps;
   hipStream_t st = (hipStream_t)stream;
   // operands must stay below the LDS-DMA out-of-range sentinel (2 GiB per tensor)
   const long a_rows = d->a_mode == SDN_A_CONV3X3 ? (long)(d->M / (d->Ho * d->Wo)) * d->Hs * d->Ws : (long)d->M;
