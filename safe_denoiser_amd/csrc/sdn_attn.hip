@@ -26,6 +26,13 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
+#if defined(__HIP_DEVICE_COMPILE__)     // buffer-resource builtins exist only in the device pass
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+#endif
+
 constexpr int THREADS = 256;
 constexpr int KV = 64;       // keys per tile
 constexpr int QB = 128;      // queries per workgroup (32 per wave)
@@ -57,14 +64,32 @@ k_attn(const AttnArgs a) {
   constexpr int NDB = (HD + 31) / 32;         // 32-row blocks of O^T
   constexpr bool ONES = (HD % 32) != 0;       // a free padding column exists -> row sums via MFMA
   constexpr bool OFFSET_FREE = T::kDtype == 0; // bf16 has fp32's exponent range: softmax without max subtraction (below)
-  constexpr int KSTR = KQ * 32 + 16;          // K tile row stride in bytes (+16 B pad against bank conflicts)
-  constexpr int VSTR = NDB * 64 + 16;         // V tile row stride in bytes (multiple of 8 for the tr read)
-  constexpr int STAGE = KV * KSTR + KV * VSTR;
   constexpr int CH = HD / 8;                  // valid 16-B chunks per K / V row
-  constexpr int NLOAD = (2 * KV * CH + THREADS - 1) / THREADS;   // staged chunks per thread per tile
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+  // Single-buffer inputs (DMA): K/V tiles arrive by LDS-DMA (buffer_load ... lds, 16 B per lane, one linear 1-KiB
+  // piece per wave-instruction): no staging registers, no ds_write pass.  A DMA piece cannot skip bytes, so the tiles
+  // hold ONLY the HD data columns; the zero padding of the head dim and the ones column live once in a 32-byte static
+  // block that the padding lanes of the fragment reads point at instead (their contents do not depend on the key).
+  // Two-segment inputs (SEG, MMDiT) keep register staging: the two streams have different base pointers.
+  constexpr bool DMA = !SEG;
+#ifndef SDN_ATTN_VCH40
+#define SDN_ATTN_VCH40 5
+#endif
+  constexpr int KCH = HD == 40 ? 5 : CH + 1;  // 16-B chunks per K row in LDS; strides 20/36/44/84 words: b128 reads conflict-free
+  constexpr int VCH = HD == 40 ? SDN_ATTN_VCH40 : (HD == 160 ? 20 : 12);   // V rows 16 or 48 banks apart (tr reads conflict-free)
+  // K tile row stride in bytes (register staging: zero-padded to KQ*16 columns + 16 B against bank conflicts)
+  constexpr int KSTR = DMA ? KCH * 16 : KQ * 32 + 16;
+  // V tile row stride in bytes.  ds_read_b64_tr_b16 is banked like ds_read_b64 (64 banks, lanes 0-31 / 32-63 are the
+  // two groups): one group reads 4 consecutive keys x 64 contiguous bytes, so the rows must sit 16 or 48 banks apart
+  // for the 4 x 16 words to tile all 64 banks.
+  constexpr int VSTR_PAD = (NDB * 16) % 64 == 16 || (NDB * 16) % 64 == 48 ? NDB * 64 : NDB * 64 + 64;
+  constexpr int VSTR = DMA ? VCH * 16 : VSTR_PAD;
+  constexpr int STAGE = KV * KSTR + KV * VSTR;
+  constexpr int ZOFF = 2 * STAGE;             // static block: [1,0,0,0 | 0,0,0,0 | 0 x 8] (16-bit), DMA mode only
+  constexpr int NLOAD = (2 * KV * CH + THREADS - 1) / THREADS;   // staged chunks per thread per tile (register staging)
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE + 32];
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: LDS-DMA bases go to M0
   const int r = lane & 31, h = lane >> 5;
   // XCD-aware mapping (1-D grid): workgroups are dealt round-robin over the 8 XCDs, so id % 8 labels the XCD.
   // All q-blocks of one (batch, head) pair go to ONE XCD: its K/V (N*d*4 B = 655 KB at N=4096, d=40) is then fetched
@@ -84,7 +109,9 @@ k_attn(const AttnArgs a) {
   const bool qvalid = q0 + r < a.nq;             // per lane: the query tail (nq % 32 != 0) is clamped, not stored
 
   // ---- one-time LDS init: zero the padding columns, plant the ones column (both stages) ----
-  {
+  if constexpr (DMA) {
+    if (tid < 8) *reinterpret_cast<unsigned*>(smem + ZOFF + tid * 4) = tid == 0 ? (T::pack2(1.0f, 0.0f) & 0xffffu) : 0u;
+  } else {
     const unsigned one16 = T::pack2(1.0f, 0.0f) & 0xffffu;
     for (int e = tid; e < 2 * KV; e += THREADS) {
       unsigned char* sK = smem + (e / KV) * STAGE + (e % KV) * KSTR;
@@ -160,6 +187,42 @@ k_attn(const AttnArgs a) {
     }
   };
 
+  // ---- LDS-DMA tile loads (DMA mode).  Piece p of a tile = chunks [64p, 64p+64) of the K image (p < KCH) or of the V
+  // image; lane l fetches chunk 64p + l -> (row, chunk-in-row).  The per-lane source offset is FIXED for the whole
+  // kernel: each tile moves the descriptor's base (scalar work) and shrinks its record count, so rows past nk and the
+  // bank-pad chunks (offset 2^31) fail the range check and are written as zeros.
+  constexpr int NPIECE = (KCH + VCH + 3) / 4;                  // pieces per wave per tile (4 waves)
+  unsigned dma_off[NPIECE];
+  const long kv_bytes_k = ((long)(a.nk - 1) * a.ldk + a.heads * HD) * 2, kv_bytes_v = ((long)(a.nk - 1) * a.ldv + a.heads * HD) * 2;
+  if constexpr (DMA) {
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) {
+      const int p = wid + 4 * i;                               // wave-uniform
+      const bool isv = p >= KCH;
+      const int e = (isv ? p - KCH : p) * 64 + lane;
+      const int rowc = isv ? VCH : KCH;
+      const int row = e / rowc, ch = e - row * rowc;
+      dma_off[i] = ch < CH ? (unsigned)(((long)row * (isv ? a.ldv : a.ldk) + head * HD + ch * 8) * 2) : 0x80000000u;
+    }
+  }
+  auto dma_issue = [&](int buf, int t) {
+    const long k0 = (long)t * KV;
+    const unsigned short* kb_ = a.k + ((long)b * a.nk + k0) * a.ldk;
+    const unsigned short* vb_ = a.v + ((long)b * a.nk + k0) * a.ldv;
+    const long rk = kv_bytes_k - k0 * a.ldk * 2, rv = kv_bytes_v - k0 * a.ldv * 2;
+    const __amdgpu_buffer_rsrc_t rs_k = make_rsrc(kb_, (unsigned)(rk > 0 ? rk : 0));
+    const __amdgpu_buffer_rsrc_t rs_v = make_rsrc(vb_, (unsigned)(rv > 0 ? rv : 0));
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) {
+      const int p = wid + 4 * i;
+      if (p < KCH)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lds_ptr_t)(smem + buf * STAGE + p * 1024), 16, dma_off[i], 0, 0, 0);
+      else if (p < KCH + VCH)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lds_ptr_t)(smem + buf * STAGE + KV * KSTR + (p - KCH) * 1024), 16,
+                                                 dma_off[i], 0, 0, 0);
+    }
+  };
+
   f32x16 o[NDB];
 #pragma unroll
   for (int d = 0; d < NDB; ++d)
@@ -172,15 +235,23 @@ k_attn(const AttnArgs a) {
   const int gi = lane & 15, gq = gi >> 2, gp = gi & 3, gcol = 16 * ((lane >> 4) & 1);
 
   const int ntiles = (a.nk + KV - 1) / KV;
-  g_load(0);
-  s_store(0, 0);
+  if constexpr (DMA) {
+    dma_issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    g_load(0);
+    s_store(0, 0);
+  }
   __syncthreads();
 
   for (int t = 0; t < ntiles; ++t) {
     const int buf = t & 1;
     const unsigned char* sK = smem + buf * STAGE;
     const unsigned char* sV = sK + KV * KSTR;
-    if (t + 1 < ntiles) g_load(t + 1);            // in flight during this tile's MFMAs / softmax (uniform branch)
+    if (t + 1 < ntiles) {                         // in flight during this tile's MFMAs / softmax (uniform branch)
+      if constexpr (DMA) dma_issue(buf ^ 1, t + 1);   // the other stage: last read before the previous barrier
+      else g_load(t + 1);
+    }
 
     // ---- S^T = K Q^T : two 32-key blocks ----
     f32x16 st[2];
@@ -190,7 +261,9 @@ k_attn(const AttnArgs a) {
       for (int i = 0; i < 16; ++i) st[kb][i] = 0.f;
 #pragma unroll
       for (int s = 0; s < KQ; ++s) {
-        const typename T::v8 kf = *reinterpret_cast<const typename T::v8*>(sK + (32 * kb + r) * KSTR + (16 * s + 8 * h) * 2);
+        const unsigned char* kp = sK + (32 * kb + r) * KSTR + (16 * s + 8 * h) * 2;
+        if (DMA && 16 * s + 16 > HD) { if (16 * s + 8 * h >= HD) kp = smem + ZOFF + 16; }   // zero padding of d
+        const typename T::v8 kf = *reinterpret_cast<const typename T::v8*>(kp);
         st[kb] = T::mfma32(kf, qf[s], st[kb]);
       }
     }
@@ -289,14 +362,23 @@ k_attn(const AttnArgs a) {
 #pragma unroll
         for (int d = 0; d < NDB; ++d) {
           const unsigned char* pa = sV + keyb * VSTR + (32 * d + gcol + 4 * gp) * 2;
+          const unsigned char* pb = pa + 8 * VSTR;
+          if (DMA && 32 * d + 32 > HD) {               // columns past HD: the ones column, then zeros
+            const int col = 32 * d + gcol + 4 * gp;
+            if (col >= HD) pa = pb = smem + ZOFF + (ONES && col == HD ? 0 : 8);
+          }
           union { s16x4 hlf[2]; typename T::v8 full; } vf;
           vf.hlf[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pa));
-          vf.hlf[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pa + 8 * VSTR));
+          vf.hlf[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pb));
           o[d] = T::mfma32(vf.full, pf, o[d]);
         }
       }
 
-    if (t + 1 < ntiles) s_store(buf ^ 1, t + 1);  // the other stage: nobody reads it during this iteration
+    if constexpr (DMA) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // next tile landed; the barrier publishes it
+    } else {
+      if (t + 1 < ntiles) s_store(buf ^ 1, t + 1);  // the other stage: nobody reads it during this iteration
+    }
     __syncthreads();
   }
 
