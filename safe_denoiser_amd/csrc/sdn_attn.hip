@@ -33,6 +33,26 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #endif
 
+// Diagnostics build (-DSDN_ATTN_STAMPS, tools/attn_stamps.py): per-wave cycle sums of the main loop's phases.
+#ifdef SDN_ATTN_STAMPS
+#define SDN_ATS_DECL unsigned long long ats_prev = 0, ats_sum[5] = {0, 0, 0, 0, 0};
+#define SDN_ATS_MARK(I)                                                                         \
+  {                                                                                             \
+    unsigned long long t_;                                                                      \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
+    if ((I) >= 0) ats_sum[(I) < 0 ? 0 : (I)] += t_ - ats_prev;                                  \
+    ats_prev = t_;                                                                              \
+  }
+#define SDN_ATS_FLUSH                                                                           \
+  if (g_attn_stamps && lane == 0)                                                               \
+    for (int i_ = 0; i_ < 5; ++i_) g_attn_stamps[((long)blockIdx.x * 4 + wid) * 5 + i_] = ats_sum[i_];
+__device__ unsigned long long* g_attn_stamps = nullptr;
+#else
+#define SDN_ATS_DECL
+#define SDN_ATS_MARK(I)
+#define SDN_ATS_FLUSH
+#endif
+
 constexpr int THREADS = 256;
 constexpr int KV = 64;       // keys per tile
 constexpr int QB = 128;      // queries per workgroup (32 per wave)
@@ -244,6 +264,8 @@ k_attn(const AttnArgs a) {
   }
   __syncthreads();
 
+  SDN_ATS_DECL
+  SDN_ATS_MARK(-1)
   for (int t = 0; t < ntiles; ++t) {
     const int buf = t & 1;
     const unsigned char* sK = smem + buf * STAGE;
@@ -278,6 +300,7 @@ k_attn(const AttnArgs a) {
         }
     }
     // ---- online softmax: the query is on the lane, its 32 keys of this tile are in st[0], st[1] ----
+    SDN_ATS_MARK(0)                               // DMA issue + K reads + S MFMAs issued
     float mx = fmaxf(st[0][0], st[1][0]);
 #pragma unroll
     for (int i = 1; i < 16; ++i) mx = fmaxf(fmaxf(mx, st[0][i]), st[1][i]);
@@ -347,6 +370,7 @@ k_attn(const AttnArgs a) {
     }
     }
 
+    SDN_ATS_MARK(1)                               // max, exp (waits for the S MFMAs)
     // ---- O^T += V^T P^T ----
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -374,13 +398,17 @@ k_attn(const AttnArgs a) {
         }
       }
 
+    SDN_ATS_MARK(2)                               // pack, V tr reads, PV MFMAs issued
     if constexpr (DMA) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // next tile landed; the barrier publishes it
     } else {
       if (t + 1 < ntiles) s_store(buf ^ 1, t + 1);  // the other stage: nobody reads it during this iteration
     }
+    SDN_ATS_MARK(3)                               // wait for the next tile's DMA
     __syncthreads();
+    SDN_ATS_MARK(4)                               // barrier
   }
+  SDN_ATS_FLUSH
 
   // ---- epilogue: normalise by the row sum ----
   float l_tot;
@@ -452,6 +480,11 @@ int run(const void* q, const void* k, const void* v, void* out, int32_t batch, i
 
 }  // namespace sdn_attn_detail
 
+#ifdef SDN_ATTN_STAMPS
+extern "C" int sdn_debug_set_attn_stamps(void* p) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(sdn_attn_detail::g_attn_stamps), &p, sizeof(p));
+}
+#endif
 extern "C" int sdn_attention_bf16(const void* q, const void* k, const void* v, void* out, int32_t batch,
                                   int32_t heads, int32_t nq, int32_t nk, int32_t head_dim, int32_t ldq,
                                   int32_t ldk, int32_t ldv, int32_t ldo, float scale, void* stream) {

@@ -42,7 +42,7 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   int res_lds;               // residual goes through the LDS staging slab (16-bit staged output, offsets fit 31 bits)
   unsigned res_bytes;        // buffer size of the residual for the DMA's bounds check
-  unsigned long long* stamps; // diagnostics: 4 s_memtime stamps per workgroup (tools/gemm_stamps.py); nullptr in production
+  unsigned long long* stamps; // diagnostics: 8 s_memtime stamp slots per workgroup (tools/gemm_stamps.py); nullptr in production
   int dbg;                   // timing-only ablations (tools/bench_gemm.py): 1 = no global stores, 2 = DMA only for k-tile 0
 };
 
@@ -98,7 +98,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
   if (g.stamps && threadIdx.x == 0) {                                                                    \
     unsigned long long t_;                                                                               \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                          \
-    g.stamps[(long)blockIdx.x * 4 + (IDX)] = t_;                                                         \
+    g.stamps[(long)blockIdx.x * 8 + (IDX)] = t_;                                                         \
   }
 
 template <typename T, int NREP, int WGM>
@@ -304,6 +304,9 @@ k_gemm_dma(const GemmArgs g) {
   // so that layout has no row pad.  (Per-fragment global loads here cost one serialized L2/HBM round trip each.)
   const bool res_lds = staged && g.res_lds;
   const int CW = res_lds ? BN * 2 : CW_PAD;
+  const bool lean = staged && !g.rowgate && g.act == 0 && (res_lds || !g.residual);
+  const bool lean_gelu = staged && !g.rowgate && g.act == 3 && !g.residual;
+  const bool lean_gate = staged && g.rowgate && g.act == 0 && res_lds;
   const __amdgpu_buffer_rsrc_t rs_res = make_rsrc(g.residual ? g.residual : g.a, g.res_bytes);
   // the staged tile may exceed the LDS (256 x 320): stage PASSES groups of wave-rows one after the other
   constexpr int PASSES = (BM * CW_PAD + 2 * STAGE - 1) / (2 * STAGE);

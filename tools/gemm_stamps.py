@@ -25,15 +25,19 @@ for name, M, N, K, conv, res in [("proj 320", B * 4096, 320, 320, None, True), (
         a = torch.randn(M, K, device="cuda").bfloat16(); kw = {}
     r = torch.randn(M, N, device="cuda").bfloat16() if res else None
     ops.gemm(a, w, bias=bias, residual=r, **kw)
-    st = torch.zeros(4 * 8192, dtype=torch.int64, device="cuda")
+    st = torch.zeros(8 * 8192, dtype=torch.int64, device="cuda")
     lib.sdn_debug_set_gemm_stamps(st.data_ptr())
     ops.gemm(a, w, bias=bias, residual=r, **kw)
     torch.cuda.synchronize()
     lib.sdn_debug_set_gemm_stamps(None)
-    s = st.cpu().reshape(-1, 4)
+    s8 = st.cpu().reshape(-1, 8)
+    s8 = s8[s8[:, 3] > 0]
+    s = s8[:, :4]
     s = s[s[:, 3] > 0]
     d = (s[:, 1:] - s[:, :-1]).double()
     tot = (s[:, 3] - s[:, 0]).double()
-    span = float(s[:, 3].max() - s[:, 0].min())
     print(f"{name:16s} blocks {len(s):5d}  prologue+first DMA {d[:,0].median():8.0f}  k-loop {d[:,1].median():8.0f}  epilogue {d[:,2].median():8.0f}"
-          f"  block total {tot.median():8.0f}   kernel span {span:9.0f}  (s_memtime ticks = shader cycles)")
+          f"  block total {tot.median():8.0f}")
+    e = s8.double()
+    print(f"{'':16s} epilogue pass 0: acc->LDS {(e[:,4]-e[:,2]).median():7.0f}  barrier {(e[:,5]-e[:,4]).median():7.0f}  store loop {(e[:,6]-e[:,5]).median():7.0f}"
+          f"  rest (pass 1 / tail) {(e[:,3]-e[:,6]).median():7.0f}   [s_memtime ticks]")
