@@ -98,7 +98,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--prompts-per-batch", type=int, default=32)
+    ap.add_argument("--prompts-per-batch", type=int, default=64)
     ap.add_argument("--inference-steps", type=int, default=50)
     ap.add_argument("--scheduler", default="ddpm", choices=["ddpm", "ddim"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"], help="16-bit storage type of the UNet")

@@ -101,7 +101,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
     g.stamps[(long)blockIdx.x * 8 + (IDX)] = t_;                                                         \
   }
 
-template <typename T, int NREP, int WGM>
+template <typename T, int NREP, int WGM, int NSTAGE>
 __global__ void __launch_bounds__(128 * WGM, 2)
 k_gemm_dma(const GemmArgs g) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -112,7 +112,12 @@ k_gemm_dma(const GemmArgs g) {
   constexpr int W_PIECES = (BN / 8 + NWAVES - 1) / NWAVES;   // 5 @160/4w or @320/8w, 4 @128/4w, ...
   constexpr int STAGE = (BM + BN) * 128;
   constexpr unsigned OOB = 0x80000000u;                      // > any tensor size handled here
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+  // NSTAGE = 2: one k-tile of prefetch, 2 workgroups per CU cover each other's waits.  NSTAGE = 4 (grids of at most one
+  // workgroup per CU, e.g. the 8x8-level convs, M = 4096): the lone workgroup owns the LDS, so it keeps 3 k-tiles in
+  // flight behind counted vmcnt waits and raw barriers instead.
+  constexpr int LPI = A_PIECES + W_PIECES;                   // DMA instructions per wave per k-tile (every wave issues all)
+  static_assert(NSTAGE == 2 || (BN / 8) % NWAVES == 0, "counted waits need the same number of loads in every wave");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NSTAGE * STAGE];
 
   const int nt = g.tiles_m * g.tiles_n;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -258,14 +263,21 @@ k_gemm_dma(const GemmArgs g) {
   }
 
   const int nk = g.K / BK;
-  issue(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  if constexpr (NSTAGE == 2) {
+    issue(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  } else {                                                   // host guarantees nk >= NSTAGE
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s) issue(s);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * LPI) : "memory");
+    __builtin_amdgcn_s_barrier();
+  }
   SDN_STAMP(1)
 
   for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk && !(g.dbg & 2)) issue(buf ^ 1);
+    const int buf = kt & (NSTAGE - 1);
+    if (kt + NSTAGE - 1 < nk && !(g.dbg & 2)) issue((kt + NSTAGE - 1) & (NSTAGE - 1));
     const unsigned char* sa = smem + buf * STAGE + (wm * 64) * 128;
     const unsigned char* sw = smem + buf * STAGE + BM * 128 + (wn * 16 * NREP) * 128;
 #pragma unroll
@@ -288,8 +300,18 @@ k_gemm_dma(const GemmArgs g) {
       if constexpr (NREP > JC) SDN_MMA_PART(JC)
 #undef SDN_MMA_PART
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if constexpr (NSTAGE == 2) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    } else {
+      // tile kt+1 must have landed; the tiles issued after it may stay in flight
+      const int later = nk - kt - 2;                         // k-tiles issued after tile kt+1 (capped by the ring depth)
+      if (later >= NSTAGE - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * LPI) : "memory");
+      else if (later == 1 && NSTAGE > 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPI) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this tile's fragment reads are done before its buffer is refilled
+      __builtin_amdgcn_s_barrier();
+    }
   }
 
   SDN_STAMP(2)
@@ -325,10 +347,10 @@ k_gemm_dma(const GemmArgs g) {
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <typename T, int NREP, int WGM>
+template <typename T, int NREP, int WGM, int NSTAGE = 2>
 int launch_dma(const GemmArgs& ga, hipStream_t st) {
   const int grid = ga.tiles_m * ga.tiles_n;
-  hipLaunchKernelGGL((k_gemm_dma<T, NREP, WGM>), dim3(grid), dim3(128 * WGM), 0, st, ga);
+  hipLaunchKernelGGL((k_gemm_dma<T, NREP, WGM, NSTAGE>), dim3(grid), dim3(128 * WGM), 0, st, ga);
   return sdn_launch_status();
 }
 
@@ -337,7 +359,10 @@ int dispatch_dma(int nrep, const GemmArgs& g, hipStream_t st) {
   switch (nrep) {
     case 10: return launch_dma<T, 10, 4>(g, st);
     case 8: return launch_dma<T, 8, 4>(g, st);
-    case 5: return launch_dma<T, 5, 2>(g, st);
+    case 5:
+      // at most one workgroup per CU and a long k loop: the deep ring (see NSTAGE) instead of a second resident workgroup
+      if (g.tiles_m * g.tiles_n <= 256 && g.K >= 8 * BK && g_gemm_variant != 5) return launch_dma<T, 5, 2, 4>(g, st);
+      return launch_dma<T, 5, 2>(g, st);
     case 4: return launch_dma<T, 4, 2>(g, st);
     case 2: return launch_dma<T, 2, 2>(g, st);
     default: return launch_dma<T, 1, 2>(g, st);

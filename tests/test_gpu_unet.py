@@ -65,6 +65,23 @@ def test_full_sd14_unet_matches_oracle():
     assert r1 <= 2.5e-2
 
 
+@pytest.mark.parametrize("batch", [64, 128])
+def test_full_sd14_unet_bench_batch_rows_equal_small_batch_rows(batch):
+    """Size-independent property at the bench's batch sizes (32 / 64 prompts x 2 CFG branches): every sample of a
+    B-sample forward is bit-identical to the same sample run at B = 2 (which the test above pins to the oracle).
+    Covers the 32-bit byte offsets, tile choices and workspace layout that only the large batch exercises."""
+    u = UNet2DConditionModel()
+    u.load_synthetic_on_device(1234)
+    g = torch.Generator().manual_seed(batch)
+    x = torch.randn(batch, 4, 64, 64, generator=g).cuda()
+    e = torch.randn(batch, 77, 768, generator=g).cuda()
+    y = u(x, 981.0, encoder_hidden_states=e).sample
+    assert torch.isfinite(y).all()
+    for lo in (0, batch // 2 - 1, batch - 2):
+        y2 = u(x[lo:lo + 2].contiguous(), 981.0, encoder_hidden_states=e[lo:lo + 2].contiguous()).sample
+        torch.testing.assert_close(y2, y[lo:lo + 2], rtol=0, atol=0)
+
+
 def test_small_unet_fp16_storage_meets_fp16_tolerance():
     """fp16 storage (the reference's SD-v3 dtype; north-star "within fp16 tolerance"): rel L2 <= 4e-3 vs the fp32
     oracle and vs the fp16-emulating oracle (the oracle itself: fp16 emulation vs fp32 = 1.4e-3)."""

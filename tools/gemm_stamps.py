@@ -15,7 +15,9 @@ lib = sda.lib()
 lib.sdn_debug_set_gemm_stamps.argtypes = [ctypes.c_void_p]          # undeclared debug hook: 64-bit pointer, not int
 lib.sdn_debug_set_gemm_stamps.restype = None
 for name, M, N, K, conv, res in [("proj 320", B * 4096, 320, 320, None, True), ("proj 320 nores", B * 4096, 320, 320, None, False),
-                                 ("ff2 320", B * 4096, 320, 1280, None, True), ("conv 320", B * 4096, 320, 2880, (64, 320), False)]:
+                                 ("ff2 320", B * 4096, 320, 1280, None, True), ("conv 320", B * 4096, 320, 2880, (64, 320), False),
+                                 ("qkv 320", B * 4096, 960, 320, None, False), ("ff1 geglu 320", B * 4096, 2560, 320, None, "geglu"),
+                                 ("ff1 geglu 640", B * 1024, 5120, 640, None, "geglu")]:
     w = (torch.randn(N, K, device="cuda") * K ** -0.5).bfloat16()
     bias = torch.randn(N, device="cuda")
     if conv:
@@ -23,9 +25,12 @@ for name, M, N, K, conv, res in [("proj 320", B * 4096, 320, 320, None, True), (
         a = torch.randn(M // (H * H), H, H, Cin, device="cuda").bfloat16(); kw = dict(conv=dict(Hs=H, Ws=H, Cin=Cin, Ho=H, Wo=H))
     else:
         a = torch.randn(M, K, device="cuda").bfloat16(); kw = {}
+    if res == "geglu":
+        kw["act"] = 2
+        res = False
     r = torch.randn(M, N, device="cuda").bfloat16() if res else None
     ops.gemm(a, w, bias=bias, residual=r, **kw)
-    st = torch.zeros(8 * 8192, dtype=torch.int64, device="cuda")
+    st = torch.zeros(8 * 32768, dtype=torch.int64, device="cuda")
     lib.sdn_debug_set_gemm_stamps(st.data_ptr())
     ops.gemm(a, w, bias=bias, residual=r, **kw)
     torch.cuda.synchronize()
