@@ -342,6 +342,42 @@ int sdn_mmdit_forward(sdn_unet* m, const void* weights, const float* latents, fl
                       const void* pooled, float* out, int32_t batch, void* workspace, size_t workspace_bytes,
                       void* stream);
 
+/* ---- AutoencoderKL decoder (the "next" row after the denoising loop) ------------------------------
+ * Replaces `self.vae.decode(latents / scaling_factor)` inside StableDiffusionPipeline.decode_latents, called at
+ * models/textuals_visual/modified_safree_diffusion_pipeline_threshold_time.py:589 (and :539-545 of the SLD
+ * pipeline).  The handle is an sdn_unet: manifest, weight and workspace queries are the sdn_unet_* ones; the
+ * manifest uses the diffusers AutoencoderKL keys `post_quant_conv.*` and `decoder.*` (attention: to_q/to_k/to_v/
+ * to_out.0).  The encoder half (proj_ref builder) is not part of this row yet. */
+typedef struct sdn_vae_config {
+  int32_t latent_channels, out_channels; /* 4, 3                                                       */
+  int32_t sample_size;                   /* LATENT side: 64 -> 512 x 512 images                        */
+  int32_t n_levels;                      /* 4                                                          */
+  int32_t block_out_channels[4];         /* 128, 256, 512, 512 (multiples of 64)                       */
+  int32_t layers_per_block;              /* 2 (the decoder's up blocks run layers_per_block + 1 resnets) */
+  int32_t norm_groups;                   /* 32                                                         */
+  int32_t dtype;                         /* 0 = bf16, 1 = fp16 activations / weights                   */
+} sdn_vae_config;
+int sdn_vae_decoder_create(const sdn_vae_config* cfg_host, sdn_unet** out_host);
+/* image [B, out_channels, 8S.., 8S..] fp32 NCHW (the decoder's raw output, nominally in [-1, 1]) =
+ * decoder(post_quant_conv(latent_scale * latents [B, latent_channels, S, S] fp32)).  latent_scale = 1 / scaling_factor
+ * folds the first line of decode_latents.  The batch is bounded by 32-bit byte offsets inside one activation
+ * (15 images at 512 x 512): larger batches return SDN_E_INVALID -- decode in chunks. */
+int sdn_vae_decode(sdn_unet* vae, const void* weights, const float* latents, float latent_scale, float* image,
+                   int32_t batch, void* workspace, size_t workspace_bytes, void* stream);
+/* decode_latents' tail + numpy_to_pil: v = clamp(x / 2 + 0.5, 0, 1); out_nhwc01 [B,H,W,C] fp32 = v (nullable);
+ * out_nhwc_u8 [B,H,W,C] = round_half_even(255 v) (nullable; at least one output). */
+int sdn_image_postprocess(const float* image_nchw, int32_t batch, int32_t channels, int32_t height, int32_t width,
+                          float* out_nhwc01, uint8_t* out_nhwc_u8, void* stream);
+/* building blocks of the decoder's single-head d = 512 attention (also usable alone):
+ * out[b, co, p] = bias[co] + sum_ci w[co, ci] * in_scale * z[b, ci, p]   (1x1 conv on an fp32 NCHW map, C <= 16) */
+int sdn_latent_mix(const float* z, const float* w, const float* bias, int32_t batch, int32_t channels, int32_t hw,
+                   float in_scale, float* out, void* stream);
+/* out[r, :] = softmax(scale * scores[r, :n]) as 16-bit (dtype 0 bf16 / 1 fp16); n % 4 == 0, n <= 4096 */
+int sdn_softmax_rows(int32_t dtype, const float* scores, int64_t ld_scores, int64_t rows, int32_t n, float scale,
+                     void* out, int64_t ld_out, void* stream);
+/* out[c, r] = in[r, c] for a 16-bit [rows, cols] matrix */
+int sdn_transpose16(const void* in, int32_t rows, int32_t cols, int64_t ld_in, void* out, int64_t ld_out, void* stream);
+
 /* ---- opt-in measurement: HIP events around every launch of ONE forward, on the forward's own stream ---- */
 typedef struct sdn_profile_row {
   char    kernel[24];     /* kernel symbol, e.g. "k_gemm<5>", "k_attn<40>"                              */

@@ -56,6 +56,12 @@ class MmditConfig(C.Structure):
                                          "dtype")]
 
 
+class VaeConfig(C.Structure):
+    _fields_ = [("latent_channels", C.c_int32), ("out_channels", C.c_int32), ("sample_size", C.c_int32),
+                ("n_levels", C.c_int32), ("block_out_channels", C.c_int32 * 4), ("layers_per_block", C.c_int32),
+                ("norm_groups", C.c_int32), ("dtype", C.c_int32)]
+
+
 class AttnSegment2(C.Structure):
     _fields_ = [("q2", C.c_void_p), ("k2", C.c_void_p), ("v2", C.c_void_p), ("out2", C.c_void_p), ("n1", C.c_int32),
                 ("ldq2", C.c_int32), ("ldk2", C.c_int32), ("ldv2", C.c_int32), ("ldo2", C.c_int32)]
@@ -115,6 +121,12 @@ SIGNATURES = {
     "sdn_patchify_bf16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "sdn_patchify_f16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "sdn_unpatchify_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "sdn_vae_decoder_create": (C.c_int, [C.POINTER(VaeConfig), C.POINTER(_vp)]),
+    "sdn_vae_decode": (C.c_int, [_vp, _vp, _vp, _f32, _vp, _i32, _vp, _sz, _vp]),
+    "sdn_image_postprocess": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "sdn_latent_mix": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp]),
+    "sdn_softmax_rows": (C.c_int, [_i32, _vp, _i64, _i64, _i32, _f32, _vp, _i64, _vp]),
+    "sdn_transpose16": (C.c_int, [_vp, _i32, _i32, _i64, _vp, _i64, _vp]),
     "sdn_unet_profile_next": (None, [_vp]),
     "sdn_unet_profile_read": (C.c_int, [_vp, C.POINTER(ProfileRow), _i32]),
 }

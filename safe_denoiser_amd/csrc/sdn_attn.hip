@@ -54,7 +54,7 @@ __device__ unsigned long long* g_attn_stamps = nullptr;
 #endif
 
 constexpr int THREADS = 256;
-constexpr int KV = 64;       // keys per tile
+[[maybe_unused]] constexpr int KV = 64;       // keys per tile
 constexpr int QB = 128;      // queries per workgroup (32 per wave)
 
 struct AttnArgs {

@@ -4,7 +4,7 @@
 
 extern "C" {
 
-int sdn_abi_version(void) { return 2; }
+int sdn_abi_version(void) { return 3; }
 
 const char* sdn_device_arch_host(void) {
   static char name[64];

@@ -102,7 +102,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
   }
 
 template <typename T, int NREP, int WGM, int NSTAGE>
-__global__ void __launch_bounds__(128 * WGM, 2)
+__global__ void __launch_bounds__(128 * WGM, NSTAGE > 2 ? 1 : 2)
 k_gemm_dma(const GemmArgs g) {
 #if defined(__HIP_DEVICE_COMPILE__)
   SDN_STAMP(0)

@@ -397,7 +397,15 @@ int conv_in_impl(const float* lat, const void* w, const float* bias, int32_t bat
     return SDN_E_INVALID;
   if (batch == 0) return SDN_OK;
   const size_t lds = (size_t)cout * 9 * cin * sizeof(float);
-  if (lds > 64 * 1024) return SDN_E_INVALID;
+  if (lds > 160 * 1024) return SDN_E_INVALID;
+  if (lds > 64 * 1024) {                      // VAE decoder conv_in (4 -> 512): 72 KB of weights; opt in to > 64 KB once
+    static bool raised = false;
+    if (!raised) {
+      if (hipFuncSetAttribute((const void*)k_conv_in<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        return SDN_E_LAUNCH;
+      raised = true;
+    }
+  }
   const long total = (long)batch * h * wd * (cout / 8);
   long grid = (total + THREADS - 1) / THREADS;
   if (grid > 2048) grid = 2048;

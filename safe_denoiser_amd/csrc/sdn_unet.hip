@@ -35,7 +35,8 @@ namespace {
 enum Space { SP_NONE = 0, SP_W = 1, SP_WS = 2, SP_LATENTS = 3, SP_TEXT = 4, SP_OUT = 5, SP_POOLED = 6 };
 struct Ref { int space = SP_NONE; int64_t off = 0; };
 
-enum OpKind { OP_TEMB, OP_CONV_IN, OP_GEMM, OP_GN, OP_LN, OP_ATTN, OP_PATCHIFY, OP_UNPATCHIFY };
+enum OpKind { OP_TEMB, OP_CONV_IN, OP_GEMM, OP_GN, OP_LN, OP_ATTN, OP_PATCHIFY, OP_UNPATCHIFY, OP_LATENT_MIX, OP_SOFTMAX,
+              OP_TRANSPOSE };
 
 struct Op {
   int kind;
@@ -113,7 +114,9 @@ struct Plan {
 struct sdn_unet {
   sdn_unet_config cfg;
   sdn_mmdit_config mcfg;
+  sdn_vae_config vcfg;
   bool is_mmdit = false;
+  bool is_vae = false;
   std::vector<sdn_param_info> params;
   std::map<std::string, int> param_index;
   int64_t weight_bytes = 0;
@@ -678,6 +681,144 @@ struct Builder {
     drop(g);
     plan->ws_bytes = arena.peak;
   }
+
+  // =================================================================================================
+  // AutoencoderKL decoder: vae.decode(latents / scaling_factor) of
+  // StableDiffusionPipeline.decode_latents (...threshold_time.py:589).  diffusers-0.29.0 definitions (third party,
+  // restated): Decoder = conv_in -> UNetMidBlock2D(resnet, 1-head attention, resnet) -> UpDecoderBlock2D x n
+  // (layers_per_block + 1 resnets, nearest-2x + conv except the last) -> GroupNorm -> SiLU -> conv_out; resnets have no
+  // time embedding, every norm uses eps 1e-6.
+  // =================================================================================================
+  Act vae_resnet(const std::string& pfx, Act& x, int cout) {
+    const int cin = x.C;
+    Ref n1g = param(pfx + ".norm1.weight", SDN_P_VEC_F32, cin, 0), n1b = param(pfx + ".norm1.bias", SDN_P_VEC_F32, cin, 0);
+    Ref c1w = param(pfx + ".conv1.weight", SDN_P_CONV3X3, cout, 9 * cin), c1b = param(pfx + ".conv1.bias", SDN_P_VEC_F32, cout, 0);
+    Ref n2g = param(pfx + ".norm2.weight", SDN_P_VEC_F32, cout, 0), n2b = param(pfx + ".norm2.bias", SDN_P_VEC_F32, cout, 0);
+    Ref c2w = param(pfx + ".conv2.weight", SDN_P_CONV3X3, cout, 9 * cout), c2b = param(pfx + ".conv2.bias", SDN_P_VEC_F32, cout, 0);
+    const int64_t rows = (int64_t)B * x.hw;
+    Act g1 = act(rows, cin, x.hw, x.side);
+    groupnorm(x, nullptr, 1e-6f, 1, n1g, n1b, g1);
+    Act h = act(rows, cout, x.hw, x.side);
+    conv3x3(g1, cout, cout, c1w, c1b, R(h), 1, 0, Ref(), Ref(), 0);
+    drop(g1);
+    Act g2 = act(rows, cout, x.hw, x.side);
+    groupnorm(h, nullptr, 1e-6f, 1, n2g, n2b, g2);
+    drop(h);
+    Act out = act(rows, cout, x.hw, x.side);
+    if (cin != cout) {
+      Ref scw = param(pfx + ".conv_shortcut.weight", SDN_P_MAT, cout, cin), scb = param(pfx + ".conv_shortcut.bias", SDN_P_VEC_F32, cout, 0);
+      Act sc = act(rows, cout, x.hw, x.side);
+      gemm(rows, cout, cin, R(x), scw, scb, R(sc));
+      conv3x3(g2, cout, cout, c2w, c2b, R(out), 1, 0, R(sc), Ref(), 0);
+      drop(sc);
+    } else {
+      conv3x3(g2, cout, cout, c2w, c2b, R(out), 1, 0, R(x), Ref(), 0);
+    }
+    drop(g2);
+    return out;
+  }
+
+  // Attention(C, heads = 1, dim_head = C) with GroupNorm, biased q/k/v/out linears and a residual connection.
+  // d = C = 512 does not fit the flash kernel: per image  S = Q K^T (fp32) -> row softmax -> P V.
+  Act vae_attention(const std::string& pfx, Act& x) {
+    const int C = x.C, hw = x.hw;
+    const int64_t rows = (int64_t)B * hw;
+    Ref gg = param(pfx + ".group_norm.weight", SDN_P_VEC_F32, C, 0), gb = param(pfx + ".group_norm.bias", SDN_P_VEC_F32, C, 0);
+    Ref qw = param(pfx + ".to_q.weight", SDN_P_MAT, C, C), qb = param(pfx + ".to_q.bias", SDN_P_VEC_F32, C, 0);
+    Ref kw = param(pfx + ".to_k.weight", SDN_P_MAT, C, C), kb = param(pfx + ".to_k.bias", SDN_P_VEC_F32, C, 0);
+    Ref vw = param(pfx + ".to_v.weight", SDN_P_MAT, C, C), vb = param(pfx + ".to_v.bias", SDN_P_VEC_F32, C, 0);
+    Ref ow = param(pfx + ".to_out.0.weight", SDN_P_MAT, C, C), ob = param(pfx + ".to_out.0.bias", SDN_P_VEC_F32, C, 0);
+    Act gn = act(rows, C, hw, x.side);
+    groupnorm(x, nullptr, 1e-6f, 0, gg, gb, gn);
+    // three dense projections (not one stacked GEMM): the per-image Q K^T / P V GEMMs below take dense operands
+    Act q = act(rows, C, hw, x.side), k = act(rows, C, hw, x.side), v = act(rows, C, hw, x.side);
+    gemm(rows, C, C, R(gn), qw, qb, R(q));
+    gemm(rows, C, C, R(gn), kw, kb, R(k));
+    gemm(rows, C, C, R(gn), vw, vb, R(v));
+    drop(gn);
+    Act at = act(rows, C, hw, x.side);
+    Act sc = act(hw, hw, 0, 0, 4);                 // fp32 scores of ONE image, reused image after image (stream order)
+    Act pr = act(hw, hw);
+    Act vt = act(C, hw);
+    const float scale = 1.0f / sqrtf((float)C);
+    for (int b = 0; b < B; ++b) {
+      const int64_t img = (int64_t)b * hw * C * 2;
+      { // S = Q K^T : A = Q rows of this image, "weight" operand = its K rows
+        Op o; o.kind = OP_GEMM; memset(&o.gd, 0, sizeof(o.gd));
+        o.gd.M = hw; o.gd.N = hw; o.gd.K = C; o.gd.a_mode = SDN_A_PLAIN; o.gd.out_kind = SDN_OUT_F32;
+        o.a = Ref{SP_WS, q.off + img}; o.w = Ref{SP_WS, k.off + img}; o.out = R(sc);
+        o.flops = 2.0 * hw * (double)hw * C; o.bytes = 2.0 * 2.0 * hw * C + 4.0 * hw * (double)hw;
+        snprintf(o.label, sizeof(o.label), "k_gemm<%d>", sdn_gemm_pick_tile(hw, hw, C, SDN_ACT_NONE));
+        plan->ops.push_back(o); plan->flops += o.flops; plan->attn_flops += o.flops;
+      }
+      { Op o; o.kind = OP_SOFTMAX; o.a = R(sc); o.out = R(pr); o.rows = hw; o.c1 = hw; o.scale = scale;
+        o.bytes = 6.0 * hw * (double)hw; snprintf(o.label, sizeof(o.label), "k_softmax_rows"); plan->ops.push_back(o); }
+      { Op o; o.kind = OP_TRANSPOSE; o.a = Ref{SP_WS, v.off + img}; o.out = R(vt); o.rows = hw; o.c1 = C; o.ldq = C;
+        o.ldo = hw; o.bytes = 4.0 * hw * C; snprintf(o.label, sizeof(o.label), "k_transpose16"); plan->ops.push_back(o); }
+      { // O = P V : A = P [hw, hw], "weight" = V^T [C, hw]
+        Op o; o.kind = OP_GEMM; memset(&o.gd, 0, sizeof(o.gd));
+        o.gd.M = hw; o.gd.N = C; o.gd.K = hw; o.gd.a_mode = SDN_A_PLAIN; o.gd.out_kind = SDN_OUT_BF16;
+        o.a = R(pr); o.w = R(vt); o.out = Ref{SP_WS, at.off + (int64_t)b * hw * C * 2};
+        o.flops = 2.0 * hw * (double)hw * C; o.bytes = 2.0 * (hw * (double)hw + 2.0 * hw * C);
+        snprintf(o.label, sizeof(o.label), "k_gemm<%d>", sdn_gemm_pick_tile(hw, C, hw, SDN_ACT_NONE));
+        plan->ops.push_back(o); plan->flops += o.flops; plan->attn_flops += o.flops;
+      }
+    }
+    drop(sc); drop(pr); drop(vt); drop(q); drop(k); drop(v);
+    Act out = act(rows, C, hw, x.side);
+    gemm(rows, C, C, R(at), ow, ob, R(out), SDN_ACT_NONE, R(x));
+    drop(at);
+    return out;
+  }
+
+  void build_vae() {
+    const sdn_vae_config& c = u->vcfg;
+    const int S = c.sample_size, L = c.latent_channels, n = c.n_levels;
+    const int ctop = c.block_out_channels[n - 1];
+    char buf[96];
+    gn_stats = Ref{SP_WS, arena.alloc((int64_t)B * 129 * 64 * 2 * 4)};
+    Ref pqw = param("post_quant_conv.weight", SDN_P_VEC_F32, L * L, 0), pqb = param("post_quant_conv.bias", SDN_P_VEC_F32, L, 0);
+    Act z = act((int64_t)B * L, S * S, 0, 0, 4);                    // fp32 NCHW
+    { Op o; o.kind = OP_LATENT_MIX; o.batch = B; o.c1 = L; o.hw = S * S; o.a = Ref{SP_LATENTS, 0}; o.w = pqw; o.bias = pqb; o.out = R(z);
+      o.flops = 2.0 * B * S * S * (double)L * L; o.bytes = 8.0 * B * S * S * L; snprintf(o.label, sizeof(o.label), "k_latent_mix");
+      plan->ops.push_back(o); plan->flops += o.flops; }
+    Ref ciw = param("decoder.conv_in.weight", SDN_P_CONV3X3, ctop, 9 * L), cib = param("decoder.conv_in.bias", SDN_P_VEC_F32, ctop, 0);
+    Act cur = act((int64_t)B * S * S, ctop, S * S, S);
+    { Op o; o.kind = OP_CONV_IN; o.batch = B; o.c1 = L; o.c2 = ctop; o.hw = S; o.a = R(z); o.w = ciw; o.bias = cib; o.out = R(cur);
+      o.flops = 2.0 * B * S * S * (double)ctop * 9 * L; o.bytes = (double)B * S * S * (4.0 * L + 2.0 * ctop);
+      snprintf(o.label, sizeof(o.label), "k_conv_in"); plan->ops.push_back(o); plan->flops += o.flops; }
+    drop(z);
+    { Act r = vae_resnet("decoder.mid_block.resnets.0", cur, ctop); drop(cur); cur = r; }
+    { Act r = vae_attention("decoder.mid_block.attentions.0", cur); drop(cur); cur = r; }
+    { Act r = vae_resnet("decoder.mid_block.resnets.1", cur, ctop); drop(cur); cur = r; }
+    for (int i = 0; i < n; ++i) {
+      const int cout = c.block_out_channels[n - 1 - i];
+      for (int j = 0; j <= c.layers_per_block; ++j) {
+        snprintf(buf, sizeof(buf), "decoder.up_blocks.%d.resnets.%d", i, j);
+        Act r = vae_resnet(buf, cur, cout);
+        drop(cur); cur = r;
+      }
+      if (i + 1 < n) {
+        snprintf(buf, sizeof(buf), "decoder.up_blocks.%d.upsamplers.0.conv", i);
+        Ref w = param(std::string(buf) + ".weight", SDN_P_CONV3X3, cout, 9 * cout), bb = param(std::string(buf) + ".bias", SDN_P_VEC_F32, cout, 0);
+        const int s2 = cur.side * 2;
+        Act up = act((int64_t)B * s2 * s2, cout, s2 * s2, s2);
+        conv3x3(cur, cout, cout, w, bb, R(up), 1, 1, Ref(), Ref(), 0);
+        drop(cur); cur = up;
+      }
+    }
+    const int c0 = c.block_out_channels[0];
+    Ref og = param("decoder.conv_norm_out.weight", SDN_P_VEC_F32, c0, 0), ob = param("decoder.conv_norm_out.bias", SDN_P_VEC_F32, c0, 0);
+    const int npad = 32;
+    Ref cow = param("decoder.conv_out.weight", SDN_P_CONV3X3, c.out_channels, 9 * c0, npad);
+    Ref cob = param("decoder.conv_out.bias", SDN_P_VEC_F32, c.out_channels, 0, npad);
+    Act g = act((int64_t)B * cur.hw, c0, cur.hw, cur.side);
+    groupnorm(cur, nullptr, 1e-6f, 1, og, ob, g);
+    drop(cur);
+    conv3x3(g, c.out_channels, npad, cow, cob, Ref{SP_OUT, 0}, 1, 0, Ref(), Ref(), 0, SDN_OUT_F32_NCHW, c.out_channels);
+    drop(g);
+    plan->ws_bytes = arena.peak;
+  }
 };
 
 Plan* get_plan(sdn_unet* u, int batch) {
@@ -687,7 +828,7 @@ Plan* get_plan(sdn_unet* u, int batch) {
   p.batch = batch;
   Builder b{u, &p};
   b.B = batch;
-  if (u->is_mmdit) b.build_mmdit(); else b.build();
+  if (u->is_vae) b.build_vae(); else if (u->is_mmdit) b.build_mmdit(); else b.build();
   return &p;
 }
 
@@ -752,6 +893,29 @@ int sdn_mmdit_create(const sdn_mmdit_config* cfg, sdn_unet** out) {
   return SDN_OK;
 }
 
+int sdn_vae_decoder_create(const sdn_vae_config* cfg, sdn_unet** out) {
+  if (!cfg || !out) return SDN_E_INVALID;
+  if (cfg->n_levels < 1 || cfg->n_levels > 4 || cfg->layers_per_block < 1 || cfg->latent_channels <= 0 ||
+      cfg->latent_channels > 16 || cfg->out_channels <= 0 || cfg->out_channels > 32 || cfg->sample_size <= 0 ||
+      cfg->norm_groups <= 0 || cfg->norm_groups > 64 || cfg->dtype < 0 || cfg->dtype > 1)
+    return SDN_E_INVALID;
+  for (int i = 0; i < cfg->n_levels; ++i) {
+    const int c = cfg->block_out_channels[i];
+    if (c <= 0 || c % 64 != 0 || c % cfg->norm_groups != 0 || sdn_gemm_pick_nrep(c, SDN_ACT_NONE) == 0) return SDN_E_INVALID;
+  }
+  const int hw = cfg->sample_size * cfg->sample_size;         // tokens of the mid-block attention
+  if (hw % 64 != 0 || hw > 4096 || sdn_gemm_pick_nrep(hw, SDN_ACT_NONE) == 0) return SDN_E_INVALID;
+  sdn_unet* u = new sdn_unet();
+  memset(&u->cfg, 0, sizeof(u->cfg));
+  u->cfg.norm_groups = cfg->norm_groups;
+  u->cfg.dtype = cfg->dtype;
+  u->vcfg = *cfg;
+  u->is_vae = true;
+  get_plan(u, 1);
+  *out = u;
+  return SDN_OK;
+}
+
 void sdn_unet_destroy(sdn_unet* u) { delete u; }
 
 int sdn_unet_param_count(const sdn_unet* u) { return u ? (int)u->params.size() : 0; }
@@ -779,16 +943,29 @@ double sdn_unet_flops(sdn_unet* u, int32_t batch, double* attn) {
 static int run_plan(sdn_unet* u, const void* weights, const float* latents, float timestep, const void* text,
                     const void* pooled, float* out, int32_t batch, void* workspace, size_t workspace_bytes, void* stream);
 
+int sdn_vae_decode(sdn_unet* v, const void* weights, const float* latents, float latent_scale, float* image, int32_t batch,
+                   void* workspace, size_t workspace_bytes, void* stream) {
+  if (!v || !v->is_vae) return SDN_E_INVALID;
+  // byte offsets inside one activation are 32-bit in the GEMM's DMA descriptors: bound the batch by the largest tensor
+  const sdn_vae_config& c = v->vcfg;
+  const int64_t side = (int64_t)c.sample_size << (c.n_levels - 1);
+  int64_t cmax = 0;
+  for (int i = 0; i < c.n_levels; ++i) if (c.block_out_channels[i] > cmax) cmax = c.block_out_channels[i];
+  if (batch > 0 && (int64_t)batch * side * side * cmax * 2 >= ((int64_t)1 << 32)) return SDN_E_INVALID;
+  return run_plan(v, weights, latents, latent_scale, weights /* no text operand */, nullptr, image, batch, workspace,
+                  workspace_bytes, stream);
+}
+
 int sdn_unet_forward(sdn_unet* u, const void* weights, const float* latents, float timestep, const void* text,
                      float* out, int32_t batch, void* workspace, size_t workspace_bytes, void* stream) {
-  if (!u || u->is_mmdit) return SDN_E_INVALID;
+  if (!u || u->is_mmdit || u->is_vae) return SDN_E_INVALID;
   return run_plan(u, weights, latents, timestep, text, nullptr, out, batch, workspace, workspace_bytes, stream);
 }
 
 int sdn_mmdit_forward(sdn_unet* u, const void* weights, const float* latents, float timestep, const void* text,
                       const void* pooled, float* out, int32_t batch, void* workspace, size_t workspace_bytes,
                       void* stream) {
-  if (!u || !u->is_mmdit || !pooled) return SDN_E_INVALID;
+  if (!u || !u->is_mmdit || u->is_vae || !pooled) return SDN_E_INVALID;
   return run_plan(u, weights, latents, timestep, text, pooled, out, batch, workspace, workspace_bytes, stream);
 }
 
@@ -827,6 +1004,16 @@ static int run_plan(sdn_unet* u, const void* weights, const float* latents, floa
       case OP_GN:
         rc = (f16 ? sdn_groupnorm_f16 : sdn_groupnorm_bf16)(P(o.a), P(o.a2), o.batch, o.hw, o.c1, o.c2, o.groups, o.eps, o.silu,
                                 (const float*)P(o.w), (const float*)P(o.bias), (void*)P(o.out), (float*)P(o.aux), stream);
+        break;
+      case OP_LATENT_MIX:
+        rc = sdn_latent_mix((const float*)P(o.a), (const float*)P(o.w), (const float*)P(o.bias), o.batch, o.c1, o.hw, timestep,
+                            (float*)P(o.out), stream);
+        break;
+      case OP_SOFTMAX:
+        rc = sdn_softmax_rows(f16 ? 1 : 0, (const float*)P(o.a), o.c1, o.rows, o.c1, o.scale, (void*)P(o.out), o.c1, stream);
+        break;
+      case OP_TRANSPOSE:
+        rc = sdn_transpose16(P(o.a), (int)o.rows, o.c1, o.ldq, (void*)P(o.out), o.ldo, stream);
         break;
       case OP_PATCHIFY:
         rc = (f16 ? sdn_patchify_f16 : sdn_patchify_bf16)((const float*)P(o.a), o.batch, o.c1, o.hw, o.hw, o.patch,

@@ -98,6 +98,10 @@ class UNet2DConditionModel:
         del cin
         return out
 
+    @staticmethod
+    def _is_norm_param(name: str) -> bool:
+        return ".norm" in name or name.startswith("conv_norm_out")
+
     def synthetic_state_dict(self, seed: int = 1234) -> dict:
         """Random weights of this architecture (there are no checkpoints on the box): variance-preserving
         uniform U(-sqrt(3/fan_in), sqrt(3/fan_in)) for matrices, small uniform biases, norm gains near 1."""
@@ -105,7 +109,7 @@ class UNet2DConditionModel:
         sd = {}
         for name, shape in self.state_dict_shapes().items():
             if len(shape) == 1:
-                if ".norm" in name or name.startswith("conv_norm_out"):
+                if self._is_norm_param(name):
                     base = 1.0 if name.endswith("weight") else 0.0
                     sd[name] = base + 0.1 * (torch.rand(shape, generator=g) - 0.5)
                 else:
@@ -155,8 +159,8 @@ class UNet2DConditionModel:
         for p in self.manifest:
             n = p["rows"] * max(p["cols"], 1)
             if p["kind"] in (P_VEC_F32, P_GEGLU_VEC):
-                is_gain = (".norm" in p["name"] or p["name"].startswith("conv_norm_out")) and p["name"].endswith("weight")
-                is_nb = (".norm" in p["name"] or p["name"].startswith("conv_norm_out")) and p["name"].endswith("bias")
+                is_gain = self._is_norm_param(p["name"]) and p["name"].endswith("weight")
+                is_nb = self._is_norm_param(p["name"]) and p["name"].endswith("bias")
                 amp = 0.1 if (is_gain or is_nb) else 0.2
                 t = (torch.rand(n, generator=g, device=device) - 0.5) * amp + (1.0 if is_gain else 0.0)
                 buf[p["offset"]:p["offset"] + 4 * n] = t.view(torch.uint8)

@@ -1,0 +1,115 @@
+"""VAE decoder row on the GPU: libsdn's decoder plan and its helper kernels vs the CPU oracle.
+
+Tolerances: the helper kernels are fp32 (<= 1e-5) or one 16-bit rounding of the output; the whole decoder follows the
+UNet's reasoning (tests/test_gpu_unet.py): 16-bit STORAGE of ~45 normalised layers decorrelates rounding, so the bf16
+engine is compared with the bf16-emulating oracle at rel L2 <= 2.5e-2 and the fp16 engine at <= 3e-3; the uint8 image
+may differ by one code value on a small fraction of pixels.
+"""
+import pytest
+import torch
+
+from oracle.vae import OracleVAEDecoder
+from safe_denoiser_amd import _lib
+from safe_denoiser_amd.vae import AutoencoderKL
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / b.norm())
+
+
+def test_latent_mix_softmax_transpose_postprocess_match_torch():
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(0)
+    # 1x1 conv on an fp32 NCHW latent with the input scale folded in
+    z = torch.randn(3, 4, 8, 8, generator=g)
+    w, b = torch.randn(4, 4, generator=g), torch.randn(4, generator=g)
+    zd, wd, bd = z.cuda(), w.cuda(), b.cuda()
+    out = torch.empty_like(zd)
+    _lib.check(lib.sdn_latent_mix(zd.data_ptr(), wd.data_ptr(), bd.data_ptr(), 3, 4, 64, 5.49, out.data_ptr(), _lib.stream_ptr()), "mix")
+    ref = torch.nn.functional.conv2d(z * 5.49, w[:, :, None, None], b)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=1e-5)
+    # row softmax, fp32 -> 16 bit, ragged row count, full 4096 width and a narrow one
+    for n, rows in ((4096, 5), (64, 64)):
+        s = (torch.randn(rows, n, generator=g) * 30).cuda()
+        for dt, code, tol in ((torch.bfloat16, 0, 4e-3), (torch.float16, 1, 5e-4)):
+            p = torch.empty(rows, n, dtype=dt, device="cuda")
+            _lib.check(lib.sdn_softmax_rows(code, s.data_ptr(), n, rows, n, 0.0442, p.data_ptr(), n, _lib.stream_ptr()), "softmax")
+            ref = torch.softmax(s.cpu() * 0.0442, dim=-1)
+            assert rel_l2(p, ref) <= tol
+            torch.testing.assert_close(p.float().sum(-1).cpu(), torch.ones(rows), rtol=0, atol=2e-2)
+    # transpose of a strided view
+    m = torch.randn(100, 3 * 72, generator=g).bfloat16().cuda()
+    t = torch.empty(72, 100, dtype=torch.bfloat16, device="cuda")
+    view = m[:, 72:144]
+    _lib.check(lib.sdn_transpose16(view.data_ptr(), 100, 72, 3 * 72, t.data_ptr(), 100, _lib.stream_ptr()), "transpose")
+    torch.testing.assert_close(t.cpu(), view.cpu().t().contiguous(), rtol=0, atol=0)
+    # image post-processing: exact, including the half-to-even rounding and the clamp
+    img = torch.randn(2, 3, 16, 24, generator=g) * 1.5
+    img[0, 0, 0, :5] = torch.tensor([-1.0, 1.0, 2.0 * (0.5 / 255) - 1.0, 2.0 * (1.5 / 255) - 1.0, float("inf")])
+    v = AutoencoderKL.__new__(AutoencoderKL)
+    f = AutoencoderKL.postprocess(v, img.cuda()).cpu()
+    u = AutoencoderKL.postprocess(v, img.cuda(), uint8=True).cpu()
+    ref01 = (img / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).contiguous()
+    torch.testing.assert_close(f, ref01, rtol=0, atol=1e-7)
+    assert int((u.int() - (ref01 * 255).round().int()).abs().max()) == 0
+
+
+SMALL = dict(block_out_channels=(64, 128), layers_per_block=1, sample_size=16)
+SMALL_O = dict(block_out_channels=(64, 128), layers_per_block=1)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 2.5e-2), (torch.float16, 3e-3)])
+def test_small_decoder_matches_oracle(dtype, tol):
+    v = AutoencoderKL(dtype=dtype, **SMALL)
+    sd = v.synthetic_state_dict(3)
+    v.load_state_dict(sd)
+    g = torch.Generator().manual_seed(1)
+    z = torch.randn(3, 4, 8, 8, generator=g)
+    img = v.decode(z.cuda(), latent_scale=1.0 / 0.18215).sample
+    assert img.shape == (3, 3, 16, 16) and torch.isfinite(img).all()
+    ref_q = OracleVAEDecoder(sd, SMALL_O, act_dtype=dtype).decode(z, 1.0 / 0.18215)
+    ref_32 = OracleVAEDecoder(sd, SMALL_O, act_dtype=None).decode(z, 1.0 / 0.18215)
+    r1, r2 = rel_l2(img, ref_q), rel_l2(img, ref_32)
+    print(f"small VAE decoder {dtype}: rel L2 vs emulating oracle {r1:.3e}, vs fp32 oracle {r2:.3e}")
+    assert r1 <= tol and r2 <= tol
+    # batch rows are independent
+    torch.testing.assert_close(v.decode(z[1:2].cuda(), latent_scale=1.0 / 0.18215).sample, img[1:2], rtol=0, atol=0)
+
+
+def test_full_sd14_decoder_matches_oracle_and_pipeline_tail():
+    v = AutoencoderKL()
+    sd = v.synthetic_state_dict(11)
+    v.load_state_dict(sd)
+    g = torch.Generator().manual_seed(5)
+    lat = torch.randn(1, 4, 64, 64, generator=g) * 0.18215 * 3.0          # decode_latents divides by the scaling factor
+    img = v.decode(lat.cuda(), latent_scale=1.0 / 0.18215).sample
+    assert img.shape == (1, 3, 512, 512) and torch.isfinite(img).all()
+    o = OracleVAEDecoder(sd, None, act_dtype=torch.bfloat16)
+    ref = o.decode(lat, 1.0 / 0.18215)
+    r = rel_l2(img, ref)
+    print(f"full SD-v1.4 VAE decoder: rel L2 vs bf16-emulating oracle {r:.3e}; |y| rms {float(ref.pow(2).mean().sqrt()):.3f}")
+    assert r <= 2.5e-2
+    # the pipelines' tail: decode_latents (NHWC fp32 numpy in [0,1]) and numpy_to_pil's uint8
+    im01 = v.decode_latents(lat.cuda())
+    assert im01.shape == (1, 512, 512, 3) and im01.dtype.name == "float32"
+    ref01 = (ref / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1)
+    assert float((torch.from_numpy(im01) - ref01).abs().mean()) <= 5e-3
+    u8 = v.decode_latents_uint8(lat.cuda()).cpu()
+    d = (u8.int() - o.to_uint8(ref01).int()).abs()
+    print(f"uint8 image: {float((d > 0).float().mean()) * 100:.1f} % of values differ, max {int(d.max())} code values")
+    assert float(d.float().mean()) <= 1.5
+
+
+def test_decode_chunks_large_batches_and_rejects_bad_shapes():
+    v = AutoencoderKL(**SMALL)
+    v.load_state_dict(v.synthetic_state_dict(3))
+    z = torch.randn(19, 4, 8, 8).cuda()                       # > MAX_CHUNK: three plan invocations
+    img = v.decode(z).sample
+    torch.testing.assert_close(v.decode(z[17:18]).sample, img[17:18], rtol=0, atol=0)
+    with pytest.raises(_lib.SdnError):
+        v.decode(torch.randn(1, 4, 16, 16).cuda())
+    with pytest.raises(_lib.SdnUnavailable):
+        v.decode(torch.randn(1, 4, 8, 8))                      # host tensor: no CPU fallback
