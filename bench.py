@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--refs", type=int, default=515)
     ap.add_argument("--total-prompts", type=int, default=515)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vae", action="store_true", help="skip the (untimed) VAE decoder measurement")
     args = ap.parse_args()
 
     from safe_denoiser_amd import dist as sdist
@@ -188,6 +189,27 @@ def main():
     rep1_ms = e0.elapsed_time(e1) / 50
     rep1_bytes = args.refs * 16384 * 4 + 2 * 16384 * 4
 
+    # VAE decoder, measured OUTSIDE the timed region: `value` stays the latent-level metric of section
+    # 8d; the block below says what ending every image with decode_latents + uint8 would cost on top of it.
+    vae_block = None
+    if rank == 0 and not args.no_vae:
+        from safe_denoiser_amd.vae import AutoencoderKL
+        vae = AutoencoderKL(dtype=torch.float16 if args.dtype == "f16" else torch.bfloat16)
+        vae.load_synthetic_on_device(4321, device=dev)
+        zl = torch.randn(16, 4, 64, 64, device=dev) * 0.18215
+        vae.decode_latents_uint8(zl)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            vae.decode_latents_uint8(zl)
+        e1.record(); torch.cuda.synchronize()
+        vae_ms = e0.elapsed_time(e1) / 3 / 16
+        vae_fl, _ = vae.flops(1)
+        vae_block = {"ms_per_image": vae_ms, "tflop_per_image": vae_fl / 1e12, "tflops": vae_fl / (vae_ms * 1e-3) / 1e12,
+                     "images_per_sec_with_decode_1gpu": 1.0 / (dt / (P * args.steps) + vae_ms * 1e-3),
+                     "note": "decode_latents + uint8 conversion of 16 images in chunks of 8, outside the timed region"}
+        del vae, zl
+
     # HBM bytes per launch of the dominant kernel from the PMC passes (tools/pmc_traffic.py; collected in separate
     # rocprofv3 --pmc runs, which cannot be combined with timing) -- read from profiles/ when present
     traffic, traffic_src = None, None
@@ -228,6 +250,8 @@ def main():
                                                  "achieved": rep1_bytes / (rep1_ms * 1e-3) / 1e9,
                                                  "frac": rep1_bytes / (rep1_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}},
     }
+    if vae_block is not None:
+        line["vae_decode"] = vae_block
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)

@@ -3,9 +3,12 @@
 Call surface: the reference's `ModifiedSafreeDiffusionPipeline_Rep.__call__`
 (models/textuals_visual/modified_safree_diffusion_pipeline_threshold_time.py:352-375,598) restricted to the hot path:
 the tensor-level inputs the loop consumes (`prompt_embeddings`, `generator`, `latents`, `repellency_processor`,
-`safree_dict`, `negation_warmup_start/end`, `return_latents`).  The text encoder, SAFREE text projection and the VAE
-decoder sit either side of the loop and are not part of this engine: pass CLIP hidden states
-as `prompt_embeddings` ([2P,77,768] = chunk(2) -> [P uncond | P text], or [3P,...] with `lra`), get latents back.
+`safree_dict`, `negation_warmup_start/end`, `return_latents`, `output_type`).  The text encoder sits before the loop
+ and is not part of this engine: pass CLIP hidden states as `prompt_embeddings`
+([2P,77,768] = chunk(2) -> [P uncond | P text], or [3P,...] with `lra`).  With a `vae` (safe_denoiser_amd.vae.
+AutoencoderKL, section 8f row 2) and `return_latents=False` the call ends like the reference's (:588-596):
+`decode_latents` -> NHWC float numpy in [0,1] (`output_type="np"`), PIL images ("pil", needs Pillow) or the uint8
+NHWC tensor numpy_to_pil would build, left on the device ("uint8"); otherwise latents come back.
 
 What differs from the reference by design (results per sample are the same):
   * P prompts are denoised together (the reference is hard-wired to batch 1); every prompt keeps its OWN
@@ -35,10 +38,10 @@ VARIANTS = {
 
 
 class SafeDenoiserPipeline:
-    def __init__(self, unet, scheduler, variant: str = "threshold_time"):
+    def __init__(self, unet, scheduler, variant: str = "threshold_time", vae=None):
         if variant not in VARIANTS:
             raise KeyError(f"unknown variant {variant}; have {sorted(VARIANTS)}")
-        self.unet, self.scheduler, self.variant = unet, scheduler, variant
+        self.unet, self.scheduler, self.variant, self.vae = unet, scheduler, variant, vae
         self.vae_scale_factor = 8
         self.last_stats = {}
 
@@ -53,14 +56,17 @@ class SafeDenoiserPipeline:
                  num_inference_steps: int = 50, guidance_scale: float = 7.5, generator=None, latents=None,
                  prompt_embeddings: Optional[torch.Tensor] = None, repellency_processor=None, safree_dict=None,
                  rescaled_text_embeddings: Optional[torch.Tensor] = None, beta_adjusted: Optional[int] = None,
-                 return_latents: bool = True, noise_fn: Optional[Callable] = None, **kwargs):
+                 return_latents: bool = True, noise_fn: Optional[Callable] = None, output_type: str = "pil", **kwargs):
         _lib.require_gpu()
         if prompt_embeddings is None:
             raise NotImplementedError("the CLIP text encoder is outside the hot path (SURVEY.md section 8f row 4): pass "
                                       "`prompt_embeddings` ([2P,77,768]) instead of `prompt` strings")
         if not return_latents:
-            raise NotImplementedError("the VAE decoder is outside the hot path (SURVEY.md section 8f row 2): use "
-                                      "return_latents=True (the reference's parity tap, ...threshold_time.py:585-586)")
+            if self.vae is None:
+                raise NotImplementedError("no VAE decoder attached: construct the pipeline with vae=AutoencoderKL(...) or "
+                                          "use return_latents=True (the reference's parity tap, ...threshold_time.py:585-586)")
+            if output_type not in ("pil", "np", "uint8"):
+                raise _lib.SdnError("output_type must be 'pil', 'np' or 'uint8'")
         sf = dict(safree=False, svf=False, lra=False, re_attn_t=(-1, -1))
         if safree_dict:
             sf.update(safree_dict)
@@ -181,7 +187,19 @@ class SafeDenoiserPipeline:
             lat, nxt = nxt, lat
 
         self.last_stats = {"renoise_draws": n_renoise, "window_steps": n_window, "prompts": P, "branches": nb}
-        return lat
+        if return_latents:
+            return lat
+        return self.decode_latents(lat, output_type)
+
+    def decode_latents(self, latents: torch.Tensor, output_type: str = "np"):
+        """Steps 8-10 of the reference's __call__ (...threshold_time.py:588-596)."""
+        if output_type == "uint8":
+            return self.vae.decode_latents_uint8(latents)
+        image = self.vae.decode_latents(latents)                      # NHWC float32 numpy in [0, 1]
+        if output_type == "pil":
+            from PIL import Image                                     # numpy_to_pil
+            return [Image.fromarray(im) for im in (image * 255).round().astype("uint8")]
+        return image
 
     # ------------------------------------------------------------------------------------------------
     @staticmethod

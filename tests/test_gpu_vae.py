@@ -113,3 +113,34 @@ def test_decode_chunks_large_batches_and_rejects_bad_shapes():
         v.decode(torch.randn(1, 4, 16, 16).cuda())
     with pytest.raises(_lib.SdnUnavailable):
         v.decode(torch.randn(1, 4, 8, 8))                      # host tensor: no CPU fallback
+
+
+def test_pipeline_ends_like_the_reference_with_images():
+    """Steps 8-10 of the reference's __call__ (...threshold_time.py:588-596) behind the same loop: with a VAE attached,
+    return_latents=False yields decode_latents' NHWC [0,1] array / numpy_to_pil's images of the SAME latents."""
+    from safe_denoiser_amd.pipeline import SafeDenoiserPipeline
+    from safe_denoiser_amd.schedulers import DDPMScheduler
+    from safe_denoiser_amd.unet import UNet2DConditionModel
+    u = UNet2DConditionModel(text_len=77, block_out_channels=(320, 640),
+                             down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"), layers_per_block=1,
+                             attention_head_dim=8, cross_attention_dim=768, sample_size=16)
+    u.load_state_dict(u.synthetic_state_dict(11))
+    v = AutoencoderKL(block_out_channels=(64, 128), layers_per_block=1, sample_size=32)     # latent side 16
+    sd = v.synthetic_state_dict(4)
+    v.load_state_dict(sd)
+    E = torch.randn(4, 77, 768, generator=torch.Generator().manual_seed(2)).cuda()
+    gens = lambda: [torch.Generator(device="cuda").manual_seed(7 + i) for i in range(2)]
+    pipe = SafeDenoiserPipeline(u, DDPMScheduler(), variant="threshold_time", vae=v)
+    lat = pipe(prompt_embeddings=E, num_inference_steps=4, generator=gens())
+    im_np = pipe(prompt_embeddings=E, num_inference_steps=4, generator=gens(), return_latents=False, output_type="np")
+    im_u8 = pipe(prompt_embeddings=E, num_inference_steps=4, generator=gens(), return_latents=False, output_type="uint8")
+    im_pil = pipe(prompt_embeddings=E, num_inference_steps=4, generator=gens(), return_latents=False)
+    assert im_np.shape == (2, 32, 32, 3) and im_np.dtype.name == "float32"
+    import numpy as np
+    assert np.array_equal(im_np, v.decode_latents(lat))                              # same latents, same decoder
+    assert np.array_equal(im_u8.cpu().numpy(), (im_np * 255).round().astype("uint8"))
+    assert len(im_pil) == 2 and im_pil[0].size == (32, 32) and np.array_equal(np.asarray(im_pil[1]), im_u8[1].cpu().numpy())
+    ref = OracleVAEDecoder(sd, dict(block_out_channels=(64, 128), layers_per_block=1), act_dtype=torch.bfloat16).decode_latents(lat.cpu())
+    assert float((torch.from_numpy(im_np) - ref).abs().mean()) <= 5e-3
+    with pytest.raises(NotImplementedError):
+        SafeDenoiserPipeline(u, DDPMScheduler())(prompt_embeddings=E, num_inference_steps=2, return_latents=False)
