@@ -192,6 +192,8 @@ typedef struct sdn_gemm_desc {
   int32_t residual_bcast;   /* 1 = residual is [rows_per_batch, N], shared by every sample     */
   int32_t n_valid;          /* columns actually stored (0 = N); W is zero-padded to N rows     */
   int32_t ldc;              /* leading dimension of out/residual (0 = natural)                 */
+  int32_t asym_pad;         /* CONV3X3, stride 2 only: 1 = zero padding (0,1,0,1) (right/bottom only: the VAE encoder's
+                               Downsample2D(padding=0) + F.pad) instead of 1 on every side             */
 } sdn_gemm_desc;
 
 /* out = act((A.W^T + bias[n] + rowbias[b(m), n]) * rowgate[b(m), n] + residual[m, n])   (rowgate NULL = 1).
@@ -364,6 +366,17 @@ int sdn_vae_decoder_create(const sdn_vae_config* cfg_host, sdn_unet** out_host);
  * (15 images at 512 x 512): larger batches return SDN_E_INVALID -- decode in chunks. */
 int sdn_vae_decode(sdn_unet* vae, const void* weights, const float* latents, float latent_scale, float* image,
                    int32_t batch, void* workspace, size_t workspace_bytes, void* stream);
+/* Encoder half: the embed_fn of the proj_ref builder, `pipe.vae.encode(x).latent_dist.sample() * scaling_factor`
+ * (run_nudity.py:308, consumed by RepellencyMethod.project, repellency/repellency_methods_threshold.py:54-72).
+ * Same config struct (out_channels = image channels); manifest keys `encoder.*`, `quant_conv.*`.
+ * moments [B, 2*latent_channels, S, S] fp32 NCHW = quant_conv(encoder(image [B, 3, H, W] fp32 NCHW)) = (mean | logvar). */
+int sdn_vae_encoder_create(const sdn_vae_config* cfg_host, sdn_unet** out_host);
+int sdn_vae_encode(sdn_unet* vae_encoder, const void* weights, const float* image, float* moments, int32_t batch,
+                   void* workspace, size_t workspace_bytes, void* stream);
+/* DiagonalGaussianDistribution: out [B, L, hw] = scale * (mean + exp(0.5 * clamp(logvar, -30, 20)) * noise);
+ * noise == NULL gives scale * mean (`.mode()`). */
+int sdn_gaussian_sample(const float* moments, const float* noise, int32_t batch, int32_t latent_channels, int32_t hw,
+                        float scale, float* out, void* stream);
 /* decode_latents' tail + numpy_to_pil: v = clamp(x / 2 + 0.5, 0, 1); out_nhwc01 [B,H,W,C] fp32 = v (nullable);
  * out_nhwc_u8 [B,H,W,C] = round_half_even(255 v) (nullable; at least one output). */
 int sdn_image_postprocess(const float* image_nchw, int32_t batch, int32_t channels, int32_t height, int32_t width,

@@ -69,6 +69,46 @@ def decoder_state_dict_shapes(cfg: dict | None = None) -> dict:
     return out
 
 
+def encoder_state_dict_shapes(cfg: dict | None = None) -> dict:
+    """diffusers key -> shape of the encoder half (+ quant_conv).  Encoder (diffusers-0.29.0): conv_in Conv2d(3, 128, 3, pad 1)
+    -> 4 x DownEncoderBlock2D (layers_per_block resnets; Downsample2D(padding=0): F.pad (0,1,0,1) + conv3x3 stride 2 on all
+    but the last) -> UNetMidBlock2D -> GroupNorm(32, 512, 1e-6) -> SiLU -> conv_out Conv2d(512, 2L, 3, pad 1); quant_conv
+    Conv2d(2L, 2L, 1)."""
+    c = dict(SD14_VAE)
+    if cfg:
+        c.update(cfg)
+    boc, L = list(c["block_out_channels"]), c["latent_channels"]
+    out = {"quant_conv.weight": (2 * L, 2 * L, 1, 1), "quant_conv.bias": (2 * L,),
+           "encoder.conv_in.weight": (boc[0], c["out_channels"], 3, 3), "encoder.conv_in.bias": (boc[0],)}
+
+    def resnet(pfx, cin, cout):
+        out[pfx + ".norm1.weight"] = (cin,); out[pfx + ".norm1.bias"] = (cin,)
+        out[pfx + ".conv1.weight"] = (cout, cin, 3, 3); out[pfx + ".conv1.bias"] = (cout,)
+        out[pfx + ".norm2.weight"] = (cout,); out[pfx + ".norm2.bias"] = (cout,)
+        out[pfx + ".conv2.weight"] = (cout, cout, 3, 3); out[pfx + ".conv2.bias"] = (cout,)
+        if cin != cout:
+            out[pfx + ".conv_shortcut.weight"] = (cout, cin, 1, 1); out[pfx + ".conv_shortcut.bias"] = (cout,)
+
+    cur = boc[0]
+    for i, cout in enumerate(boc):
+        for j in range(c["layers_per_block"]):
+            resnet(f"encoder.down_blocks.{i}.resnets.{j}", cur, cout)
+            cur = cout
+        if i + 1 < len(boc):
+            out[f"encoder.down_blocks.{i}.downsamplers.0.conv.weight"] = (cout, cout, 3, 3)
+            out[f"encoder.down_blocks.{i}.downsamplers.0.conv.bias"] = (cout,)
+    top = boc[-1]
+    resnet("encoder.mid_block.resnets.0", top, top)
+    a = "encoder.mid_block.attentions.0"
+    out[a + ".group_norm.weight"] = (top,); out[a + ".group_norm.bias"] = (top,)
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        out[f"{a}.{n}.weight"] = (top, top); out[f"{a}.{n}.bias"] = (top,)
+    resnet("encoder.mid_block.resnets.1", top, top)
+    out["encoder.conv_norm_out.weight"] = (top,); out["encoder.conv_norm_out.bias"] = (top,)
+    out["encoder.conv_out.weight"] = (2 * L, top, 3, 3); out["encoder.conv_out.bias"] = (2 * L,)
+    return out
+
+
 class OracleVAEDecoder:
     def __init__(self, state_dict: dict, config: dict | None = None, act_dtype=None):
         self.cfg = dict(SD14_VAE)
@@ -79,7 +119,7 @@ class OracleVAEDecoder:
         for k, v in state_dict.items():
             v = v.detach().float()
             # matrices are stored 16-bit by the engine; vectors and the tiny post_quant_conv stay f32
-            if act_dtype is not None and v.dim() > 1 and not k.startswith("post_quant_conv"):
+            if act_dtype is not None and v.dim() > 1 and "quant_conv" not in k:
                 v = v.to(act_dtype).float()
             self.sd[k] = v
 
@@ -142,3 +182,32 @@ class OracleVAEDecoder:
     def to_uint8(images01: torch.Tensor) -> torch.Tensor:
         """numpy_to_pil's conversion: (images * 255).round().astype(uint8) (numpy rounds half to even, as torch.round)."""
         return (images01 * 255).round().to(torch.uint8)
+
+
+class OracleVAEEncoder(OracleVAEDecoder):
+    """encode(x) -> moments [B, 2L, S, S] (mean | logvar); embed(x, noise) = the reference's embed_fn (run_nudity.py:308)."""
+
+    def encode(self, x: torch.Tensor) -> torch.Tensor:
+        c = self.cfg
+        h = self.q(F.conv2d(x.float(), self.P("encoder.conv_in.weight"), self.P("encoder.conv_in.bias"), padding=1))
+        n = len(c["block_out_channels"])
+        for i in range(n):
+            for j in range(c["layers_per_block"]):
+                h = self.resnet(f"encoder.down_blocks.{i}.resnets.{j}", h)
+            if i + 1 < n:
+                h = F.pad(h, (0, 1, 0, 1))
+                h = self.q(F.conv2d(h, self.P(f"encoder.down_blocks.{i}.downsamplers.0.conv.weight"),
+                                    self.P(f"encoder.down_blocks.{i}.downsamplers.0.conv.bias"), stride=2))
+        h = self.resnet("encoder.mid_block.resnets.0", h)
+        h = self.attention("encoder.mid_block.attentions.0", h)
+        h = self.resnet("encoder.mid_block.resnets.1", h)
+        h = self.q(F.silu(F.group_norm(h, c["norm_groups"], self.P("encoder.conv_norm_out.weight"),
+                                       self.P("encoder.conv_norm_out.bias"), eps=1e-6)))
+        m = F.conv2d(h, self.P("encoder.conv_out.weight"), self.P("encoder.conv_out.bias"), padding=1)
+        return F.conv2d(m, self.P("quant_conv.weight"), self.P("quant_conv.bias"))
+
+    def embed(self, x: torch.Tensor, noise: torch.Tensor | None) -> torch.Tensor:
+        """DiagonalGaussianDistribution.sample() * scaling_factor (noise None -> mode)."""
+        mean, logvar = self.encode(x).chunk(2, dim=1)
+        z = mean if noise is None else mean + torch.exp(0.5 * logvar.clamp(-30.0, 20.0)) * noise
+        return z * self.cfg["scaling_factor"]

@@ -35,7 +35,7 @@ class RepelParams(C.Structure):
 class GemmDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("M", "N", "K", "a_mode", "K1", "Hs", "Ws", "Cin", "Ho", "Wo", "stride",
                                          "upsample", "act", "out_kind", "rows_per_batch", "ld_rowbias", "ld_rowgate",
-                                         "residual_bcast", "n_valid", "ldc")]
+                                         "residual_bcast", "n_valid", "ldc", "asym_pad")]
 
 
 class UnetConfig(C.Structure):
@@ -123,6 +123,9 @@ SIGNATURES = {
     "sdn_unpatchify_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "sdn_vae_decoder_create": (C.c_int, [C.POINTER(VaeConfig), C.POINTER(_vp)]),
     "sdn_vae_decode": (C.c_int, [_vp, _vp, _vp, _f32, _vp, _i32, _vp, _sz, _vp]),
+    "sdn_vae_encoder_create": (C.c_int, [C.POINTER(VaeConfig), C.POINTER(_vp)]),
+    "sdn_vae_encode": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _sz, _vp]),
+    "sdn_gaussian_sample": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp]),
     "sdn_image_postprocess": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "sdn_latent_mix": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp]),
     "sdn_softmax_rows": (C.c_int, [_i32, _vp, _i64, _i64, _i32, _f32, _vp, _i64, _vp]),

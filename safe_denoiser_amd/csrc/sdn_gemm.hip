@@ -37,7 +37,7 @@ struct GemmArgs {
   const __bf16* a;  const __bf16* a2;  const __bf16* w;
   const float* bias;  const float* rowbias;  const float* rowgate;  const __bf16* residual;  void* out;
   int M, N, K, K1;
-  int a_mode, Hs, Ws, Cin, Ho, Wo, stride, upsample;
+  int a_mode, Hs, Ws, Cin, Ho, Wo, stride, upsample, conv_off;
   int act, out_kind, rows_per_batch, ld_rowbias, ld_rowgate, residual_bcast, n_valid, ldc;
   int tiles_m, tiles_n;
   int res_lds;               // residual goes through the LDS staging slab (16-bit staged output, offsets fit 31 bits)
@@ -154,7 +154,8 @@ k_gemm_dma(const GemmArgs g) {
       const int bb = mm / hw, p = mm - bb * hw;
       const int oy = p / g.Wo, ox = p - oy * g.Wo;
       const int Hi = g.upsample ? g.Hs * 2 : g.Hs, Wi = g.upsample ? g.Ws * 2 : g.Ws;
-      const int cy = oy * g.stride, cx = ox * g.stride;          // centre in the virtual (upsampled) input
+      const int cy = oy * g.stride + g.conv_off, cx = ox * g.stride + g.conv_off;   // centre in the virtual (upsampled) input
+                                                                 // (conv_off = 1: padding (0,1,0,1), taps start at 2*o)
       unsigned mask = 0;
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
@@ -435,9 +436,11 @@ static int sdn_gemm_impl(int dtype, const sdn_gemm_desc* d, const void* a, const
         d->Wo <= 0 || (d->stride != 1 && d->stride != 2) || d->M % (d->Ho * d->Wo) != 0)
       return SDN_E_INVALID;
     const int Hi = d->upsample ? 2 * d->Hs : d->Hs, Wi = d->upsample ? 2 * d->Ws : d->Ws;
-    if ((Hi + 2 - 3) / d->stride + 1 != d->Ho || (Wi + 2 - 3) / d->stride + 1 != d->Wo) return SDN_E_INVALID;
+    if (d->asym_pad != 0 && (d->asym_pad != 1 || d->stride != 2 || d->upsample)) return SDN_E_INVALID;
+    const int pad2 = d->asym_pad ? 1 : 2;                     // total zero padding per axis
+    if ((Hi + pad2 - 3) / d->stride + 1 != d->Ho || (Wi + pad2 - 3) / d->stride + 1 != d->Wo) return SDN_E_INVALID;
     g.K1 = d->K; g.Hs = d->Hs; g.Ws = d->Ws; g.Cin = d->Cin; g.Ho = d->Ho; g.Wo = d->Wo; g.stride = d->stride;
-    g.upsample = d->upsample;
+    g.upsample = d->upsample; g.conv_off = d->asym_pad ? 1 : 0;
   } else {
     return SDN_E_INVALID;
   }

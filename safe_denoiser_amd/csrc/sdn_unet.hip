@@ -36,7 +36,7 @@ enum Space { SP_NONE = 0, SP_W = 1, SP_WS = 2, SP_LATENTS = 3, SP_TEXT = 4, SP_O
 struct Ref { int space = SP_NONE; int64_t off = 0; };
 
 enum OpKind { OP_TEMB, OP_CONV_IN, OP_GEMM, OP_GN, OP_LN, OP_ATTN, OP_PATCHIFY, OP_UNPATCHIFY, OP_LATENT_MIX, OP_SOFTMAX,
-              OP_TRANSPOSE };
+              OP_TRANSPOSE, OP_GAUSS };
 
 struct Op {
   int kind;
@@ -117,6 +117,7 @@ struct sdn_unet {
   sdn_vae_config vcfg;
   bool is_mmdit = false;
   bool is_vae = false;
+  bool is_vae_encoder = false;
   std::vector<sdn_param_info> params;
   std::map<std::string, int> param_index;
   int64_t weight_bytes = 0;
@@ -192,13 +193,13 @@ struct Builder {
     plan->flops += o.flops;
   }
   void conv3x3(const Act& in, int cout, int n_pad, Ref w, Ref bias, Ref out, int stride, int upsample, Ref residual,
-               Ref rowbias, int ld_rowbias, int out_kind = SDN_OUT_BF16, int n_valid = 0) {
+               Ref rowbias, int ld_rowbias, int out_kind = SDN_OUT_BF16, int n_valid = 0, int asym_pad = 0) {
     const int Hi = upsample ? in.side * 2 : in.side;
-    const int Ho = (Hi + 2 - 3) / stride + 1;
+    const int Ho = (Hi + (asym_pad ? 1 : 2) - 3) / stride + 1;
     Op o; o.kind = OP_GEMM; memset(&o.gd, 0, sizeof(o.gd));
     o.gd.M = B * Ho * Ho; o.gd.N = n_pad; o.gd.K = 9 * in.C; o.gd.a_mode = SDN_A_CONV3X3;
     o.gd.Hs = in.side; o.gd.Ws = in.side; o.gd.Cin = in.C; o.gd.Ho = Ho; o.gd.Wo = Ho; o.gd.stride = stride;
-    o.gd.upsample = upsample; o.gd.out_kind = out_kind; o.gd.n_valid = n_valid; o.gd.rows_per_batch = Ho * Ho;
+    o.gd.upsample = upsample; o.gd.asym_pad = asym_pad; o.gd.out_kind = out_kind; o.gd.n_valid = n_valid; o.gd.rows_per_batch = Ho * Ho;
     o.gd.ld_rowbias = ld_rowbias;
     o.a = R(in); o.w = w; o.bias = bias; o.rowbias = rowbias; o.residual = residual; o.out = out;
     o.flops = 2.0 * (double)o.gd.M * (double)cout * (double)o.gd.K;
@@ -819,6 +820,61 @@ struct Builder {
     drop(g);
     plan->ws_bytes = arena.peak;
   }
+  // AutoencoderKL encoder (the proj_ref builder's embed_fn, run_nudity.py:308): conv_in -> DownEncoderBlock2D x n
+  // (layers_per_block resnets; Downsample2D(padding=0) = F.pad (0,1,0,1) + conv3x3 stride 2 on all but the last) ->
+  // UNetMidBlock2D -> GroupNorm -> SiLU -> conv_out (2L moments) -> quant_conv 1x1.  Output: fp32 NCHW moments
+  // [B, 2L, S, S] (mean | logvar); sampling is sdn_gaussian_sample.
+  void build_vae_encoder() {
+    const sdn_vae_config& c = u->vcfg;
+    const int n = c.n_levels, L = c.latent_channels;
+    const int S0 = c.sample_size << (n - 1);                         // image side
+    char buf[96];
+    gn_stats = Ref{SP_WS, arena.alloc((int64_t)B * 129 * 64 * 2 * 4)};
+    const int c0 = c.block_out_channels[0];
+    Ref ciw = param("encoder.conv_in.weight", SDN_P_CONV3X3, c0, 9 * c.out_channels), cib = param("encoder.conv_in.bias", SDN_P_VEC_F32, c0, 0);
+    Act cur = act((int64_t)B * S0 * S0, c0, S0 * S0, S0);
+    { Op o; o.kind = OP_CONV_IN; o.batch = B; o.c1 = c.out_channels; o.c2 = c0; o.hw = S0; o.a = Ref{SP_LATENTS, 0}; o.w = ciw; o.bias = cib; o.out = R(cur);
+      o.flops = 2.0 * B * S0 * S0 * (double)c0 * 9 * c.out_channels; o.bytes = (double)B * S0 * S0 * (4.0 * c.out_channels + 2.0 * c0);
+      snprintf(o.label, sizeof(o.label), "k_conv_in"); plan->ops.push_back(o); plan->flops += o.flops; }
+    for (int i = 0; i < n; ++i) {
+      const int cout = c.block_out_channels[i];
+      for (int j = 0; j < c.layers_per_block; ++j) {
+        snprintf(buf, sizeof(buf), "encoder.down_blocks.%d.resnets.%d", i, j);
+        Act r = vae_resnet(buf, cur, cout);
+        drop(cur); cur = r;
+      }
+      if (i + 1 < n) {
+        snprintf(buf, sizeof(buf), "encoder.down_blocks.%d.downsamplers.0.conv", i);
+        Ref w = param(std::string(buf) + ".weight", SDN_P_CONV3X3, cout, 9 * cout), bb = param(std::string(buf) + ".bias", SDN_P_VEC_F32, cout, 0);
+        const int s2 = cur.side / 2;
+        Act d = act((int64_t)B * s2 * s2, cout, s2 * s2, s2);
+        conv3x3(cur, cout, cout, w, bb, R(d), 2, 0, Ref(), Ref(), 0, SDN_OUT_BF16, 0, 1);
+        drop(cur); cur = d;
+      }
+    }
+    const int ctop = c.block_out_channels[n - 1];
+    { Act r = vae_resnet("encoder.mid_block.resnets.0", cur, ctop); drop(cur); cur = r; }
+    { Act r = vae_attention("encoder.mid_block.attentions.0", cur); drop(cur); cur = r; }
+    { Act r = vae_resnet("encoder.mid_block.resnets.1", cur, ctop); drop(cur); cur = r; }
+    Ref og = param("encoder.conv_norm_out.weight", SDN_P_VEC_F32, ctop, 0), ob = param("encoder.conv_norm_out.bias", SDN_P_VEC_F32, ctop, 0);
+    const int npad = 32, M2 = 2 * L;
+    Ref cow = param("encoder.conv_out.weight", SDN_P_CONV3X3, M2, 9 * ctop, npad);
+    Ref cob = param("encoder.conv_out.bias", SDN_P_VEC_F32, M2, 0, npad);
+    Ref qw = param("quant_conv.weight", SDN_P_VEC_F32, M2 * M2, 0), qb = param("quant_conv.bias", SDN_P_VEC_F32, M2, 0);
+    Act g = act((int64_t)B * cur.hw, ctop, cur.hw, cur.side);
+    groupnorm(cur, nullptr, 1e-6f, 1, og, ob, g);
+    const int hw = cur.hw;
+    drop(cur);
+    Act mom = act((int64_t)B * M2, hw, 0, 0, 4);                     // fp32 NCHW moments before quant_conv
+    conv3x3(g, M2, npad, cow, cob, R(mom), 1, 0, Ref(), Ref(), 0, SDN_OUT_F32_NCHW, M2);
+    drop(g);
+    { Op o; o.kind = OP_LATENT_MIX; o.batch = B; o.c1 = M2; o.hw = hw; o.a = R(mom); o.w = qw; o.bias = qb; o.out = Ref{SP_OUT, 0};
+      o.mod = 1; o.scale = 1.0f;
+      o.flops = 2.0 * B * hw * (double)M2 * M2; o.bytes = 8.0 * B * hw * M2; snprintf(o.label, sizeof(o.label), "k_latent_mix");
+      plan->ops.push_back(o); plan->flops += o.flops; }
+    drop(mom);
+    plan->ws_bytes = arena.peak;
+  }
 };
 
 Plan* get_plan(sdn_unet* u, int batch) {
@@ -828,7 +884,7 @@ Plan* get_plan(sdn_unet* u, int batch) {
   p.batch = batch;
   Builder b{u, &p};
   b.B = batch;
-  if (u->is_vae) b.build_vae(); else if (u->is_mmdit) b.build_mmdit(); else b.build();
+  if (u->is_vae_encoder) b.build_vae_encoder(); else if (u->is_vae) b.build_vae(); else if (u->is_mmdit) b.build_mmdit(); else b.build();
   return &p;
 }
 
@@ -916,6 +972,19 @@ int sdn_vae_decoder_create(const sdn_vae_config* cfg, sdn_unet** out) {
   return SDN_OK;
 }
 
+int sdn_vae_encoder_create(const sdn_vae_config* cfg, sdn_unet** out) {
+  if (!cfg || !out) return SDN_E_INVALID;
+  sdn_unet* u = nullptr;
+  const int rc = sdn_vae_decoder_create(cfg, &u);              // same config checks; the plan is rebuilt as an encoder
+  if (rc != SDN_OK) return rc;
+  if (2 * cfg->latent_channels > 16) { delete u; return SDN_E_INVALID; }
+  u->is_vae_encoder = true;
+  u->plans.clear(); u->params.clear(); u->param_index.clear(); u->weight_bytes = 0;
+  get_plan(u, 1);
+  *out = u;
+  return SDN_OK;
+}
+
 void sdn_unet_destroy(sdn_unet* u) { delete u; }
 
 int sdn_unet_param_count(const sdn_unet* u) { return u ? (int)u->params.size() : 0; }
@@ -945,7 +1014,7 @@ static int run_plan(sdn_unet* u, const void* weights, const float* latents, floa
 
 int sdn_vae_decode(sdn_unet* v, const void* weights, const float* latents, float latent_scale, float* image, int32_t batch,
                    void* workspace, size_t workspace_bytes, void* stream) {
-  if (!v || !v->is_vae) return SDN_E_INVALID;
+  if (!v || !v->is_vae || v->is_vae_encoder) return SDN_E_INVALID;
   // byte offsets inside one activation are 32-bit in the GEMM's DMA descriptors: bound the batch by the largest tensor
   const sdn_vae_config& c = v->vcfg;
   const int64_t side = (int64_t)c.sample_size << (c.n_levels - 1);
@@ -954,6 +1023,18 @@ int sdn_vae_decode(sdn_unet* v, const void* weights, const float* latents, float
   if (batch > 0 && (int64_t)batch * side * side * cmax * 2 >= ((int64_t)1 << 32)) return SDN_E_INVALID;
   return run_plan(v, weights, latents, latent_scale, weights /* no text operand */, nullptr, image, batch, workspace,
                   workspace_bytes, stream);
+}
+
+int sdn_vae_encode(sdn_unet* v, const void* weights, const float* image, float* moments, int32_t batch, void* workspace,
+                   size_t workspace_bytes, void* stream) {
+  if (!v || !v->is_vae || !v->is_vae_encoder) return SDN_E_INVALID;
+  const sdn_vae_config& c = v->vcfg;
+  const int64_t side = (int64_t)c.sample_size << (c.n_levels - 1);
+  int64_t cmax = 0;
+  for (int i = 0; i < c.n_levels; ++i) if (c.block_out_channels[i] > cmax) cmax = c.block_out_channels[i];
+  if (batch > 0 && (int64_t)batch * side * side * cmax * 2 >= ((int64_t)1 << 32)) return SDN_E_INVALID;
+  return run_plan(v, weights, image, 1.0f, weights /* no text operand */, nullptr, moments, batch, workspace, workspace_bytes,
+                  stream);
 }
 
 int sdn_unet_forward(sdn_unet* u, const void* weights, const float* latents, float timestep, const void* text,
@@ -1006,7 +1087,8 @@ static int run_plan(sdn_unet* u, const void* weights, const float* latents, floa
                                 (const float*)P(o.w), (const float*)P(o.bias), (void*)P(o.out), (float*)P(o.aux), stream);
         break;
       case OP_LATENT_MIX:
-        rc = sdn_latent_mix((const float*)P(o.a), (const float*)P(o.w), (const float*)P(o.bias), o.batch, o.c1, o.hw, timestep,
+        rc = sdn_latent_mix((const float*)P(o.a), (const float*)P(o.w), (const float*)P(o.bias), o.batch, o.c1, o.hw,
+                            o.mod ? o.scale : timestep /* decoder: the caller's latent_scale */,
                             (float*)P(o.out), stream);
         break;
       case OP_SOFTMAX:

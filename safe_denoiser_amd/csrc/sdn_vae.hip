@@ -108,6 +108,23 @@ k_image_post(const float* __restrict__ x, int B, int C, int hw, float* __restric
   }
 }
 
+// DiagonalGaussianDistribution.sample() * scale: moments [B, 2L, hw] = (mean | logvar), logvar clamped to [-30, 20].
+__global__ void __launch_bounds__(THREADS)
+k_gauss_sample(const float* __restrict__ mom, const float* __restrict__ noise, int B, int L, int hw, float scale,
+               float* __restrict__ out) {
+  const long total = (long)B * L * hw;
+  for (long e = (long)blockIdx.x * THREADS + threadIdx.x; e < total; e += (long)gridDim.x * THREADS) {
+    const long b = e / ((long)L * hw), r = e - b * (long)L * hw;
+    const float mean = mom[b * 2 * L * hw + r];
+    float v = mean;
+    if (noise) {
+      const float lv = fminf(fmaxf(mom[b * 2 * L * hw + (long)L * hw + r], -30.f), 20.f);
+      v = fmaf(expf(0.5f * lv), noise[e], mean);
+    }
+    out[e] = v * scale;
+  }
+}
+
 inline unsigned grid_for(long total) {
   long g = (total + THREADS - 1) / THREADS;
   return (unsigned)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
@@ -157,5 +174,14 @@ extern "C" int sdn_image_postprocess(const float* image_nchw, int32_t batch, int
   const int hw = height * width;
   hipLaunchKernelGGL(k_image_post, dim3(grid_for((long)batch * hw)), dim3(THREADS), 0, (hipStream_t)stream, image_nchw,
                      batch, channels, hw, out_nhwc01, out_nhwc_u8);
+  return sdn_launch_status();
+}
+
+extern "C" int sdn_gaussian_sample(const float* moments, const float* noise, int32_t batch, int32_t latent_channels,
+                                   int32_t hw, float scale, float* out, void* stream) {
+  if (!moments || !out || batch < 0 || latent_channels <= 0 || hw <= 0) return SDN_E_INVALID;
+  if (batch == 0) return SDN_OK;
+  hipLaunchKernelGGL(k_gauss_sample, dim3(grid_for((long)batch * latent_channels * hw)), dim3(THREADS), 0, (hipStream_t)stream,
+                     moments, noise, batch, latent_channels, hw, scale, out);
   return sdn_launch_status();
 }

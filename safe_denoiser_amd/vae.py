@@ -1,10 +1,14 @@
-"""AutoencoderKL (decoder half) front-end: `vae.decode(z).sample`, `vae.config.scaling_factor` and the pipelines'
+"""AutoencoderKL front-end: `vae.decode(z).sample`, `vae.config.scaling_factor` and the pipelines'
 `decode_latents` / `numpy_to_pil` tail (StableDiffusionPipeline.decode_latents as called at
 models/textuals_visual/modified_safree_diffusion_pipeline_threshold_time.py:589-596), executed by libsdn's static launch
 plan (sdn_vae_decoder_create / sdn_vae_decode).  SURVEY section 8f row 2.
 
-Weights: the `post_quant_conv.*` and `decoder.*` entries of a diffusers AutoencoderKL state_dict (SD-v1.4 `vae/`), packed
-once into the engine layout exactly like the UNet's.  The deprecated attention names of the on-disk checkpoint
+The encoder half serves the proj_ref builder's embed_fn, `vae.encode(x).latent_dist.sample() * scaling_factor`
+(run_nudity.py:308 -> RepellencyMethod.project, repellency_methods_threshold.py:54-72): sdn_vae_encoder_create /
+sdn_vae_encode / sdn_gaussian_sample.
+
+Weights: the `post_quant_conv.*` + `decoder.*` (and, when present, `quant_conv.*` + `encoder.*`) entries of a diffusers
+AutoencoderKL state_dict (SD-v1.4 `vae/`), packed once into the engine layout exactly like the UNet's.  The deprecated attention names of the on-disk checkpoint
 (`query/key/value/proj_attn`) are accepted as aliases of `to_q/to_k/to_v/to_out.0`.
 """
 from __future__ import annotations
@@ -30,13 +34,53 @@ class DecoderOutput:
         self.sample = sample
 
 
+class DiagonalGaussianDistribution:
+    """`latent_dist` of AutoencoderKLOutput: moments [B, 2L, S, S] = (mean | logvar), logvar clamped to [-30, 20]."""
+
+    def __init__(self, moments: torch.Tensor):
+        self.parameters = moments
+        self.mean, lv = moments.chunk(2, dim=1)
+        self.logvar = lv.clamp(-30.0, 20.0)
+
+    @property
+    def std(self):
+        return torch.exp(0.5 * self.logvar)
+
+    def _draw(self, noise, scale):
+        m = self.parameters
+        b, c2, h, w = m.shape
+        out = torch.empty((b, c2 // 2, h, w), dtype=torch.float32, device=m.device)
+        _lib.check(_lib.lib().sdn_gaussian_sample(_lib.dptr(m, torch.float32), None if noise is None else _lib.dptr(noise, torch.float32),
+                                                  b, c2 // 2, h * w, float(scale), _lib.dptr(out, torch.float32), _lib.stream_ptr()),
+                   "sdn_gaussian_sample")
+        return out
+
+    def sample(self, generator=None, scale: float = 1.0) -> torch.Tensor:
+        """mean + std * randn (diffusers draws with randn_tensor(mean.shape, generator) on the parameters' device)."""
+        m = self.parameters
+        noise = torch.randn((m.shape[0], m.shape[1] // 2) + tuple(m.shape[2:]), generator=generator, device=m.device,
+                            dtype=torch.float32)
+        return self._draw(noise, scale)
+
+    def mode(self, scale: float = 1.0) -> torch.Tensor:
+        return self._draw(None, scale)
+
+
+class EncoderOutput:
+    __slots__ = ("latent_dist",)
+
+    def __init__(self, latent_dist):
+        self.latent_dist = latent_dist
+
+
 class AutoencoderKL(UNet2DConditionModel):
-    """Decoder-only AutoencoderKL.  `sample_size` is the IMAGE side (diffusers' meaning); the latent side is
-    sample_size / 2**(levels-1)."""
+    """AutoencoderKL.  `sample_size` is the IMAGE side (diffusers' meaning); the latent side is
+    sample_size / 2**(levels-1).  The object itself is the decoder half; `.encoder_half` (built on first use or when
+    the state_dict carries `encoder.*`) is the same class in the encoder role."""
 
-    MAX_CHUNK = 8                      # images per sdn_vae_decode call (32-bit offsets bound it at 15 for 512 x 512)
+    MAX_CHUNK = 8                      # images per sdn_vae_* call (32-bit offsets bound it at 15 for 512 x 512)
 
-    def __init__(self, dtype=torch.bfloat16, **config):
+    def __init__(self, dtype=torch.bfloat16, _role: str = "decoder", **config):
         if dtype not in (torch.bfloat16, torch.float16):
             raise _lib.SdnError("storage dtype must be torch.bfloat16 or torch.float16")
         self.dtype = dtype
@@ -55,7 +99,13 @@ class AutoencoderKL(UNet2DConditionModel):
                            layers_per_block=cfg["layers_per_block"], norm_groups=cfg["norm_num_groups"],
                            dtype=0 if dtype == torch.bfloat16 else 1)
         h = C.c_void_p()
-        _lib.check(_lib.lib().sdn_vae_decoder_create(C.byref(c), C.byref(h)), "sdn_vae_decoder_create")
+        self._role = _role
+        self._user_config = dict(config)
+        self.encoder_half = None
+        if _role == "encoder":
+            _lib.check(_lib.lib().sdn_vae_encoder_create(C.byref(c), C.byref(h)), "sdn_vae_encoder_create")
+        else:
+            _lib.check(_lib.lib().sdn_vae_decoder_create(C.byref(c), C.byref(h)), "sdn_vae_decoder_create")
         self._h = h
         self._weights = None
         self._ws = {}
@@ -75,8 +125,16 @@ class AutoencoderKL(UNet2DConditionModel):
     def state_dict_shapes(self) -> dict:
         out = super().state_dict_shapes()
         L = self.config.latent_channels
-        out["post_quant_conv.weight"] = (L, L, 1, 1)
+        if self._role == "encoder":
+            out["quant_conv.weight"] = (2 * L, 2 * L, 1, 1)
+        else:
+            out["post_quant_conv.weight"] = (L, L, 1, 1)
         return out
+
+    def _encoder(self):
+        if self.encoder_half is None:
+            self.encoder_half = AutoencoderKL(dtype=self.dtype, _role="encoder", **self._user_config)
+        return self.encoder_half
 
     @staticmethod
     def _canonical(sd: dict) -> dict:
@@ -93,14 +151,50 @@ class AutoencoderKL(UNet2DConditionModel):
     def pack_state_dict(self, sd: dict) -> torch.Tensor:
         sd = self._canonical(sd)
         sd = dict(sd)
-        sd["post_quant_conv.weight"] = sd["post_quant_conv.weight"].reshape(-1)      # [L, L, 1, 1] -> fp32 vector
+        qk = "quant_conv.weight" if self._role == "encoder" else "post_quant_conv.weight"
+        sd[qk] = sd[qk].reshape(-1)                                                   # [C, C, 1, 1] -> fp32 vector
         for k in list(sd):                                                            # deprecated linears stored as 1x1 convs
             if "attentions" in k and k.endswith("weight") and sd[k].dim() == 4:
                 sd[k] = sd[k].reshape(sd[k].shape[0], sd[k].shape[1])
         return super().pack_state_dict(sd)
 
     def load_state_dict(self, sd: dict, device="cuda"):
-        return super().load_state_dict(self._canonical(sd), device)
+        sd = self._canonical(sd)
+        if self._role == "decoder" and "encoder.conv_in.weight" in sd:
+            self._encoder().load_state_dict(sd, device)
+        return super().load_state_dict(sd, device)
+
+    def synthetic_state_dict(self, seed: int = 1234, with_encoder: bool = False) -> dict:
+        sd = super().synthetic_state_dict(seed)
+        if with_encoder and self._role == "decoder":
+            sd.update(self._encoder().synthetic_state_dict(seed + 1))
+        return sd
+
+    # ---- encode ---------------------------------------------------------------------------------------
+    def encode(self, x: torch.Tensor, return_dict: bool = True):
+        """quant_conv(encoder(x)) -> latent_dist; x = images [B, 3, H, W] in [-1, 1]."""
+        enc = self._encoder() if self._role == "decoder" else self
+        _lib.require_gpu()
+        if enc._weights is None:
+            raise _lib.SdnError("no encoder weights loaded: the state_dict given to load_state_dict() had no `encoder.*` keys")
+        x = x.float().contiguous()
+        side = enc.latent_size * enc.up_factor
+        if tuple(x.shape[1:]) != (enc.config.out_channels, side, side):
+            raise _lib.SdnError(f"images must be [B,{enc.config.out_channels},{side},{side}], got {tuple(x.shape)}")
+        L, s = enc.config.latent_channels, enc.latent_size
+        mom = torch.empty((x.shape[0], 2 * L, s, s), dtype=torch.float32, device=x.device)
+        for lo in range(0, x.shape[0], enc.MAX_CHUNK):
+            hi = min(lo + enc.MAX_CHUNK, x.shape[0])
+            ws = enc._workspace(hi - lo, x.device)
+            _lib.check(_lib.lib().sdn_vae_encode(enc._h, _lib.dptr(enc._weights), _lib.dptr(x[lo:hi], torch.float32),
+                                                 _lib.dptr(mom[lo:hi], torch.float32), hi - lo, _lib.dptr(ws), ws.numel(),
+                                                 _lib.stream_ptr()), "sdn_vae_encode")
+        dist = DiagonalGaussianDistribution(mom)
+        return EncoderOutput(dist) if return_dict else (dist,)
+
+    def embed_fn(self, generator=None):
+        """The reference's `embed_fn` (run_nudity.py:308): x -> vae.encode(x).latent_dist.sample() * scaling_factor."""
+        return lambda x: self.encode(x).latent_dist.sample(generator, scale=self.config.scaling_factor)
 
     # ---- decode ---------------------------------------------------------------------------------------
     def _decode_into(self, z: torch.Tensor, latent_scale: float, out: torch.Tensor):
@@ -149,4 +243,4 @@ class AutoencoderKL(UNet2DConditionModel):
         return self.postprocess(image, uint8=True)
 
     def __call__(self, *a, **k):
-        raise _lib.SdnError("AutoencoderKL front-end exposes decode() / decode_latents(); the encoder is not built yet")
+        raise _lib.SdnError("AutoencoderKL front-end exposes encode() / decode() / decode_latents(), not the autoencoding forward")

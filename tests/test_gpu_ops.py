@@ -110,6 +110,23 @@ def test_conv3x3_implicit_gemm(B, H, Cin, Cout, stride, ups):
     check_bf16(out.reshape(B, Ho, Ho, Cout).permute(0, 3, 1, 2), ref)
 
 
+@pytest.mark.parametrize("B,H,Cin,Cout", [(2, 16, 128, 128), (1, 32, 64, 256)])
+def test_conv3x3_stride2_with_right_bottom_padding(B, H, Cin, Cout):
+    """The VAE encoder's Downsample2D(padding=0): F.pad(x, (0, 1, 0, 1)) then conv3x3 stride 2 (diffusers-0.29.0)."""
+    x = rnd(B, Cin, H, H, seed=41)
+    w = rnd(Cout, Cin, 3, 3, seed=42, scale=(9 * Cin) ** -0.5)
+    bias = torch.randn(Cout, generator=torch.Generator().manual_seed(43))
+    ref = F.conv2d(F.pad(x.float(), (0, 1, 0, 1)), w.float(), bias, stride=2, padding=0)
+    Ho = ref.shape[-1]
+    assert Ho == H // 2
+    xn = x.permute(0, 2, 3, 1).contiguous().cuda()
+    wn = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().cuda()
+    out = ops.gemm(xn, wn, bias=bias.cuda(), conv=dict(Hs=H, Ws=H, Cin=Cin, Ho=Ho, Wo=Ho, stride=2, asym_pad=1))
+    check_bf16(out.reshape(B, Ho, Ho, Cout).permute(0, 3, 1, 2), ref)
+    with pytest.raises(sda.SdnError):                                # asym_pad is a stride-2 mode only
+        ops.gemm(xn, wn, bias=bias.cuda(), conv=dict(Hs=H, Ws=H, Cin=Cin, Ho=H, Wo=H, stride=1, asym_pad=1))
+
+
 def test_conv_out_padded_n_to_f32_nchw():
     B, H, Cin, Cout = 2, 16, 320, 4
     x = rnd(B, Cin, H, H, seed=18)

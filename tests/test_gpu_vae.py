@@ -144,3 +144,68 @@ def test_pipeline_ends_like_the_reference_with_images():
     assert float((torch.from_numpy(im_np) - ref).abs().mean()) <= 5e-3
     with pytest.raises(NotImplementedError):
         SafeDenoiserPipeline(u, DDPMScheduler())(prompt_embeddings=E, num_inference_steps=2, return_latents=False)
+
+
+# ------------------------------------------------------------------------------------------ encoder half / proj_ref builder
+from oracle.vae import OracleVAEEncoder  # noqa: E402
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 2.5e-2), (torch.float16, 3e-3)])
+def test_small_encoder_matches_oracle(dtype, tol):
+    v = AutoencoderKL(dtype=dtype, **SMALL)
+    sd = v.synthetic_state_dict(3, with_encoder=True)
+    v.load_state_dict(sd)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(3, 3, 16, 16, generator=g).clamp(-1, 1)
+    dist = v.encode(x.cuda()).latent_dist
+    assert dist.parameters.shape == (3, 8, 8, 8)
+    ref_q = OracleVAEEncoder(sd, SMALL_O, act_dtype=dtype).encode(x)
+    ref_32 = OracleVAEEncoder(sd, SMALL_O, act_dtype=None).encode(x)
+    r1, r2 = rel_l2(dist.parameters, ref_q), rel_l2(dist.parameters, ref_32)
+    print(f"small VAE encoder {dtype}: moments rel L2 vs emulating oracle {r1:.3e}, vs fp32 oracle {r2:.3e}")
+    assert r1 <= tol and r2 <= tol
+    # latent_dist: mean / clamped logvar / std views, mode, and sample = mean + std * randn(generator) * scale
+    torch.testing.assert_close(dist.mode(0.18215), dist.mean * 0.18215, rtol=1e-6, atol=1e-7)
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    z = dist.sample(gen, scale=0.18215)
+    noise = torch.randn(dist.mean.shape, generator=torch.Generator(device="cuda").manual_seed(9), device="cuda")
+    torch.testing.assert_close(z, (dist.mean + dist.std * noise) * 0.18215, rtol=1e-5, atol=1e-6)
+
+
+def test_full_sd14_encoder_matches_oracle():
+    v = AutoencoderKL()
+    sd = v.synthetic_state_dict(11, with_encoder=True)
+    v.load_state_dict(sd)
+    x = (torch.rand(1, 3, 512, 512, generator=torch.Generator().manual_seed(6)) * 2 - 1)
+    mom = v.encode(x.cuda()).latent_dist.parameters
+    assert mom.shape == (1, 8, 64, 64) and torch.isfinite(mom).all()
+    ref = OracleVAEEncoder(sd, None, act_dtype=torch.bfloat16).encode(x)
+    r = rel_l2(mom, ref)
+    print(f"full SD-v1.4 VAE encoder: moments rel L2 vs bf16-emulating oracle {r:.3e}")
+    assert r <= 2.5e-2
+
+
+def test_proj_ref_builder_runs_on_the_engine(tmp_path):
+    """RepellencyMethod.project / set_proj_ref (repellency_methods_threshold.py:54-106) with the engine's own embed_fn:
+    chunks of n_embed, channel normalisation, the saved cache -- and chunking does not change the result."""
+    from oracle import repellency as orp
+    from safe_denoiser_amd.repellency import repellency_methods_fast as thr
+    v = AutoencoderKL(**SMALL)
+    sd = v.synthetic_state_dict(3, with_encoder=True)
+    v.load_state_dict(sd)
+    imgs = (torch.rand(5, 3, 16, 16, generator=torch.Generator().manual_seed(8)) * 2 - 1).cuda()
+    embed = lambda x: v.encode(x).latent_dist.mode(scale=v.config.scaling_factor)       # noise-free: comparable across chunkings
+    outs = []
+    for n_embed in (2, 16):
+        path = str(tmp_path / f"refs_{n_embed}.pt")
+        proc = thr.get_repellency_method("kernel_fast", imgs, embed, None, 50, 1000, 0.00085, 0.012, n_embed=n_embed,
+                                         proj_ref_path=path, cache_proj_ref=False, scale=0.03, sigma=1.0, epsilon=1e-8)
+        outs.append(proc.proj_refs.float().cpu())
+        torch.testing.assert_close(torch.load(path).float(), outs[-1])
+    torch.testing.assert_close(outs[0], outs[1], rtol=0, atol=0)
+    ref = orp.channel_normalise(OracleVAEEncoder(sd, SMALL_O, act_dtype=torch.bfloat16).embed(imgs.cpu(), None))
+    assert outs[0].shape == (5, 4, 8, 8) and rel_l2(outs[0], ref) <= 2.5e-2
+    # the reference's stochastic embed_fn, seeded: same generator -> same cache
+    e1 = v.embed_fn(torch.Generator(device="cuda").manual_seed(3))(imgs)
+    e2 = v.embed_fn(torch.Generator(device="cuda").manual_seed(3))(imgs)
+    torch.testing.assert_close(e1, e2, rtol=0, atol=0)

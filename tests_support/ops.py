@@ -24,6 +24,7 @@ def gemm(a, w, *, bias=None, rowbias=None, residual=None, a2=None, conv=None, ac
         d.a_mode = 1
         d.Hs, d.Ws, d.Cin, d.Ho, d.Wo = conv["Hs"], conv["Ws"], conv["Cin"], conv["Ho"], conv["Wo"]
         d.stride, d.upsample = conv.get("stride", 1), conv.get("upsample", 0)
+        d.asym_pad = conv.get("asym_pad", 0)
         M = B * d.Ho * d.Wo
         rows_per_batch = d.Ho * d.Wo
     else:
