@@ -36,7 +36,10 @@ def build_engine(args, rank, world, dev):
     from safe_denoiser_amd.repellency import repellency_methods_threshold as thr
     from safe_denoiser_amd.unet import UNet2DConditionModel
 
-    unet = UNet2DConditionModel(dtype=torch.float16 if args.dtype == "f16" else torch.bfloat16)
+    # latent_repeat = 2: the engine-side form of the reference's cat([latents] * 2) -- the two CFG branches share their
+    # latents, so the UNet computes the branch-independent prefix once (bit-identical, tests/test_gpu_unet.py)
+    unet = UNet2DConditionModel(dtype=torch.float16 if args.dtype == "f16" else torch.bfloat16,
+                                latent_repeat=1 if args.no_latent_repeat else 2)
     unet.load_synthetic_on_device(1234, device=dev)
     sched = make_scheduler(args.scheduler)
 
@@ -105,6 +108,7 @@ def main():
     ap.add_argument("--refs", type=int, default=515)
     ap.add_argument("--total-prompts", type=int, default=515)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latent-repeat", action="store_true", help="feed cat([latents] * 2) to a plain UNet plan")
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed) VAE decoder measurement")
     args = ap.parse_args()
 
@@ -150,9 +154,9 @@ def main():
     assert torch.isfinite(out).all()
 
     # ---- live kernel timing (HIP events on the launch stream) of one UNet forward at the benchmark shape ----
-    x = torch.randn(2 * P, 4, 64, 64, device=dev)
+    x = torch.randn(2 * P // unet.latent_repeat, 4, 64, 64, device=dev)
     tb = unet.prepare_text(torch.randn(2 * P, 77, 768, device=dev))
-    y = torch.empty_like(x)
+    y = torch.empty((2 * P, 4, 64, 64), device=dev)
     unet.forward_into(x, 981.0, tb, y)
     rows_acc = {}
     for _ in range(3):

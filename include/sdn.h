@@ -289,6 +289,14 @@ typedef struct sdn_unet_config {
   int32_t cross_dim, text_len;                         /* 768, 77                                   */
   int32_t norm_groups;                                 /* 32                                        */
   int32_t dtype;                                       /* 0 = bf16 storage, 1 = fp16 storage        */
+  int32_t latent_repeat;                               /* 0/1 = off.  r > 1: the batch is r guidance branches of the
+                                                          SAME latents (`torch.cat([latents] * r)`, ...threshold_time.py
+                                                          :535): sdn_unet_forward then takes latents [B / r, ...] and
+                                                          repeats them itself, computing everything up to the first
+                                                          cross-attention (conv_in, resnet 0, the first self-attention)
+                                                          ONCE per latent instead of r times.  Text rows stay [B]:
+                                                          branch-major, row b and row b + B/r share a latent.  Results
+                                                          are bit-identical to the plain plan on repeated latents.   */
 } sdn_unet_config;
 
 typedef struct sdn_unet sdn_unet;   /* opaque: op plan + parameter manifest (host memory only) */
@@ -343,6 +351,9 @@ int sdn_mmdit_create(const sdn_mmdit_config* cfg_host, sdn_unet** out_host);
 int sdn_mmdit_forward(sdn_unet* m, const void* weights, const float* latents, float timestep, const void* text,
                       const void* pooled, float* out, int32_t batch, void* workspace, size_t workspace_bytes,
                       void* stream);
+
+/* out[k * bytes + i] = in[i], k < rep (device-side `torch.cat([x] * rep)`; bytes % 16 == 0) */
+int sdn_repeat(const void* in, size_t bytes, int32_t rep, void* out, void* stream);
 
 /* ---- AutoencoderKL decoder (the "next" row after the denoising loop) ------------------------------
  * Replaces `self.vae.decode(latents / scaling_factor)` inside StableDiffusionPipeline.decode_latents, called at

@@ -42,7 +42,7 @@ class UnetConfig(C.Structure):
     _fields_ = [("in_channels", C.c_int32), ("out_channels", C.c_int32), ("sample_size", C.c_int32),
                 ("n_levels", C.c_int32), ("block_out_channels", C.c_int32 * 4), ("level_has_attn", C.c_int32 * 4),
                 ("layers_per_block", C.c_int32), ("n_heads", C.c_int32), ("cross_dim", C.c_int32),
-                ("text_len", C.c_int32), ("norm_groups", C.c_int32), ("dtype", C.c_int32)]
+                ("text_len", C.c_int32), ("norm_groups", C.c_int32), ("dtype", C.c_int32), ("latent_repeat", C.c_int32)]
 
 
 class ProfileRow(C.Structure):
@@ -121,6 +121,7 @@ SIGNATURES = {
     "sdn_patchify_bf16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "sdn_patchify_f16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "sdn_unpatchify_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "sdn_repeat": (C.c_int, [_vp, _sz, _i32, _vp, _vp]),
     "sdn_vae_decoder_create": (C.c_int, [C.POINTER(VaeConfig), C.POINTER(_vp)]),
     "sdn_vae_decode": (C.c_int, [_vp, _vp, _vp, _f32, _vp, _i32, _vp, _sz, _vp]),
     "sdn_vae_encoder_create": (C.c_int, [C.POINTER(VaeConfig), C.POINTER(_vp)]),

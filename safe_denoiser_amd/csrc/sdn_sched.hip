@@ -242,3 +242,23 @@ int sdn_flow_renoise(const float* x0r, const float* x1, const float* z, int64_t 
 }
 
 }  // extern "C"
+
+namespace {
+__global__ void __launch_bounds__(256) k_repeat(const uint4* __restrict__ in, long n16, int rep, uint4* __restrict__ out) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n16; e += (long)gridDim.x * 256) {
+    const uint4 v = in[e];
+    for (int k = 0; k < rep; ++k) out[(long)k * n16 + e] = v;
+  }
+}
+}  // namespace
+
+extern "C" int sdn_repeat(const void* in, size_t bytes, int32_t rep, void* out, void* stream) {
+  if (!in || !out || rep <= 0 || (bytes & 15) || (reinterpret_cast<uintptr_t>(in) & 15) || (reinterpret_cast<uintptr_t>(out) & 15))
+    return SDN_E_INVALID;
+  if (bytes == 0) return SDN_OK;
+  const long n16 = (long)(bytes / 16);
+  long grid = (n16 + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(k_repeat, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const uint4*)in, n16, rep, (uint4*)out);
+  return sdn_launch_status();
+}

@@ -36,7 +36,7 @@ enum Space { SP_NONE = 0, SP_W = 1, SP_WS = 2, SP_LATENTS = 3, SP_TEXT = 4, SP_O
 struct Ref { int space = SP_NONE; int64_t off = 0; };
 
 enum OpKind { OP_TEMB, OP_CONV_IN, OP_GEMM, OP_GN, OP_LN, OP_ATTN, OP_PATCHIFY, OP_UNPATCHIFY, OP_LATENT_MIX, OP_SOFTMAX,
-              OP_TRANSPOSE, OP_GAUSS };
+              OP_TRANSPOSE, OP_GAUSS, OP_REPEAT };
 
 struct Op {
   int kind;
@@ -223,6 +223,12 @@ struct Builder {
     snprintf(o.label, sizeof(o.label), "k_layernorm");
     plan->ops.push_back(o);
   }
+  void repeat(const Act& in, const Act& out, int rep) {          // out = cat([in] * rep) along the batch
+    Op o; o.kind = OP_REPEAT; o.a = R(in); o.out = R(out); o.rows = in.bytes; o.c1 = rep;
+    o.bytes = (double)in.bytes * (1 + rep);
+    snprintf(o.label, sizeof(o.label), "k_repeat");
+    plan->ops.push_back(o);
+  }
   void attention(Ref q, Ref k, Ref v, Ref out, int nq, int nk, int C, int ldq, int ldk, int ldv) {
     Op o; o.kind = OP_ATTN; o.a = q; o.k = k; o.v = v; o.out = out; o.batch = B; o.heads = u->cfg.n_heads;
     o.nq = nq; o.nk = nk; o.hd = C / u->cfg.n_heads; o.ldq = ldq; o.ldk = ldk; o.ldv = ldv; o.ldo = C;
@@ -289,9 +295,14 @@ struct Builder {
     return out;
   }
 
-  void transformer_body(const std::string& pfx, Act& x, const Act& out, int64_t text_off) {
+  // rep > 1 (sdn_unet_config.latent_repeat, first block only): `x` holds the B / rep samples the guidance branches share
+  // and `x_full` their repetition; everything up to the cross-attention's query is computed once and repeated.
+  void transformer_body(const std::string& pfx, Act& x, const Act& out, int64_t text_off, int rep = 1,
+                        const Act* x_full = nullptr) {
     const int C = x.C, hw = x.hw, T = u->cfg.text_len, X = u->cfg.cross_dim;
-    const int64_t rows = (int64_t)B * hw;
+    const int Bfull = B;
+    B = Bfull / rep;
+    int64_t rows = (int64_t)B * hw;
     const std::string tb = pfx + ".transformer_blocks.0";
     Ref ng = param(pfx + ".norm.weight", SDN_P_VEC_F32, C, 0), nb = param(pfx + ".norm.bias", SDN_P_VEC_F32, C, 0);
     Ref piw = param(pfx + ".proj_in.weight", SDN_P_MAT, C, C), pib = param(pfx + ".proj_in.bias", SDN_P_VEC_F32, C, 0);
@@ -328,6 +339,15 @@ struct Builder {
     layernorm(h2, l2g, l2b, ln);
     Act qb = act(rows, C, hw, x.side);
     gemm(rows, C, C, R(ln), q2w, Ref(), R(qb));
+    if (rep > 1) {                                 // from here on the branches differ (their text does)
+      drop(ln); drop(at);
+      B = Bfull; rows = (int64_t)B * hw;
+      Act h2f = act(rows, C, hw, x.side), qbf = act(rows, C, hw, x.side);
+      repeat(h2, h2f, rep); repeat(qb, qbf, rep);
+      drop(h2); drop(qb);
+      h2 = h2f; qb = qbf;
+      ln = act(rows, C, hw, x.side); at = act(rows, C, hw, x.side);
+    }
     Act kvb = act((int64_t)B * T, 2 * C);
     gemm((int64_t)B * T, 2 * C, X, Ref{SP_TEXT, text_off}, kv2, Ref(), R(kvb));
     attention(R(qb), R(kvb), Ref{SP_WS, kvb.off + (int64_t)C * 2}, R(at), hw, T, C, C, 2 * C, 2 * C);
@@ -343,7 +363,7 @@ struct Builder {
     Act h4 = act(rows, C, hw, x.side);
     gemm(rows, C, 4 * C, R(ff), f2w, f2b, R(h4), SDN_ACT_NONE, R(h3));
     drop(ff); drop(h3);
-    gemm(rows, C, C, R(h4), pow_, pob, R(out), SDN_ACT_NONE, R(x));
+    gemm(rows, C, C, R(h4), pow_, pob, R(out), SDN_ACT_NONE, R(rep > 1 ? *x_full : x));
     drop(h4);
   }
 
@@ -601,11 +621,18 @@ struct Builder {
 
     // ---- conv_in ----
     Ref ciw = param("conv_in.weight", SDN_P_CONV3X3, ch0, 9 * c.in_channels), cib = param("conv_in.bias", SDN_P_VEC_F32, ch0, 0);
-    Act h = act((int64_t)B * S * S, ch0, S * S, S);
-    { Op o; o.kind = OP_CONV_IN; o.batch = B; o.c1 = c.in_channels; o.c2 = ch0; o.hw = S; o.a = Ref{SP_LATENTS, 0}; o.w = ciw; o.bias = cib; o.out = R(h);
-      o.flops = 2.0 * B * S * S * (double)ch0 * 9 * c.in_channels; o.bytes = (double)B * S * S * (4.0 * c.in_channels + 2.0 * ch0);
+    // latent_repeat: the r guidance branches share their latents -> conv_in, the first resnet and the first transformer
+    // block up to its cross-attention query run on B / r samples (see transformer_body)
+    const int rep = (c.latent_repeat > 1 && c.level_has_attn[0] && u->subbatch_bytes == 0) ? c.latent_repeat : 1;
+    if (B % rep != 0) { plan->ws_bytes = -1; return; }            // forward rejects this batch
+    const int Bfull = B, Bp = B / rep;
+    Act hp = act((int64_t)Bp * S * S, ch0, S * S, S);
+    { Op o; o.kind = OP_CONV_IN; o.batch = Bp; o.c1 = c.in_channels; o.c2 = ch0; o.hw = S; o.a = Ref{SP_LATENTS, 0}; o.w = ciw; o.bias = cib; o.out = R(hp);
+      o.flops = 2.0 * Bp * S * S * (double)ch0 * 9 * c.in_channels; o.bytes = (double)Bp * S * S * (4.0 * c.in_channels + 2.0 * ch0);
       snprintf(o.label, sizeof(o.label), "k_conv_in"); plan->ops.push_back(o);
       plan->flops += o.flops; }
+    Act h = hp;
+    if (rep > 1) { h = act((int64_t)B * S * S, ch0, S * S, S); repeat(hp, h, rep); }
 
     std::vector<Act> skips;
     skips.push_back(h);                       // h stays alive as a skip; keep using it as the running tensor
@@ -617,6 +644,20 @@ struct Builder {
       const int cout = c.block_out_channels[i];
       for (int j = 0; j < c.layers_per_block; ++j) {
         snprintf(buf, sizeof(buf), "down_blocks.%d.resnets.%d", i, j);
+        if (rep > 1 && i == 0 && j == 0) {        // shared prefix: resnet 0 and the head of transformer 0 at B / rep
+          B = Bp;
+          Act rp = resnet(buf, hp, nullptr, cout);
+          B = Bfull;
+          drop(hp);
+          Act rf = act((int64_t)B * rp.hw, cout, rp.hw, rp.side);
+          repeat(rp, rf, rep);
+          snprintf(buf, sizeof(buf), "down_blocks.%d.attentions.%d", i, j);
+          Act t = act((int64_t)B * rp.hw, cout, rp.hw, rp.side);
+          transformer_body(buf, rp, t, 0, rep, &rf);
+          drop(rp); drop(rf);
+          cur = t; skips.push_back(cur); cur_is_skip = true;
+          continue;
+        }
         Act r = resnet(buf, cur, nullptr, cout);
         if (!cur_is_skip) drop(cur);
         cur = r; cur_is_skip = false;
@@ -910,7 +951,8 @@ int sdn_unet_create(const sdn_unet_config* cfg, sdn_unet** out) {
   if (cfg->n_levels < 1 || cfg->n_levels > 4 || cfg->layers_per_block < 1 || cfg->n_heads <= 0 ||
       cfg->in_channels <= 0 || cfg->in_channels > 16 || cfg->out_channels <= 0 || cfg->out_channels > 32 ||
       cfg->sample_size <= 0 || (cfg->sample_size % (1 << (cfg->n_levels - 1))) != 0 || cfg->cross_dim % 64 != 0 ||
-      cfg->text_len <= 0 || cfg->norm_groups <= 0 || cfg->norm_groups > 64 || cfg->dtype < 0 || cfg->dtype > 1)
+      cfg->text_len <= 0 || cfg->norm_groups <= 0 || cfg->norm_groups > 64 || cfg->dtype < 0 || cfg->dtype > 1 ||
+      cfg->latent_repeat < 0 || cfg->latent_repeat > 8)
     return SDN_E_INVALID;
   for (int i = 0; i < cfg->n_levels; ++i) {
     const int c = cfg->block_out_channels[i];
@@ -925,7 +967,7 @@ int sdn_unet_create(const sdn_unet_config* cfg, sdn_unet** out) {
   }
   sdn_unet* u = new sdn_unet();
   u->cfg = *cfg;
-  get_plan(u, 1);                 // registers the parameter manifest (batch-independent)
+  get_plan(u, cfg->latent_repeat > 1 ? cfg->latent_repeat : 1);   // registers the parameter manifest (batch-independent)
   *out = u;
   return SDN_OK;
 }
@@ -999,7 +1041,8 @@ size_t sdn_unet_weight_bytes(const sdn_unet* u) { return u ? (size_t)u->weight_b
 
 size_t sdn_unet_workspace_bytes(sdn_unet* u, int32_t batch) {
   if (!u || batch <= 0) return 0;
-  return (size_t)get_plan(u, batch)->ws_bytes;
+  const int64_t b = get_plan(u, batch)->ws_bytes;
+  return b < 0 ? 0 : (size_t)b;
 }
 
 double sdn_unet_flops(sdn_unet* u, int32_t batch, double* attn) {
@@ -1054,6 +1097,7 @@ static int run_plan(sdn_unet* u, const void* weights, const float* latents, floa
                     const void* pooled, float* out, int32_t batch, void* workspace, size_t workspace_bytes, void* stream) {
   if (!u || !weights || !latents || !text || !out || !workspace || batch <= 0) return SDN_E_INVALID;
   Plan* p = get_plan(u, batch);
+  if (p->ws_bytes < 0) return SDN_E_INVALID;                      // e.g. batch not a multiple of latent_repeat
   if (workspace_bytes < (size_t)p->ws_bytes) return SDN_E_WORKSPACE;
   const char* W = (const char*)weights; const char* WS = (const char*)workspace;
   const char* L = (const char*)latents; const char* T = (const char*)text; const char* O = (const char*)out;
@@ -1085,6 +1129,9 @@ static int run_plan(sdn_unet* u, const void* weights, const float* latents, floa
       case OP_GN:
         rc = (f16 ? sdn_groupnorm_f16 : sdn_groupnorm_bf16)(P(o.a), P(o.a2), o.batch, o.hw, o.c1, o.c2, o.groups, o.eps, o.silu,
                                 (const float*)P(o.w), (const float*)P(o.bias), (void*)P(o.out), (float*)P(o.aux), stream);
+        break;
+      case OP_REPEAT:
+        rc = sdn_repeat(P(o.a), (size_t)o.rows, o.c1, (void*)P(o.out), stream);
         break;
       case OP_LATENT_MIX:
         rc = sdn_latent_mix((const float*)P(o.a), (const float*)P(o.w), (const float*)P(o.bias), o.batch, o.c1, o.hw,

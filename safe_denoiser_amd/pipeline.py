@@ -123,8 +123,13 @@ class SafeDenoiserPipeline:
 
         L = _lib.lib()
         st = _lib.stream_ptr()
-        x_in = torch.empty((nb * P, C_, s, s), dtype=torch.float32, device=dev)
-        model_out = torch.empty_like(x_in)
+        # a UNet built with latent_repeat = nb repeats the latents itself (and shares the branch-independent prefix)
+        rep = getattr(self.unet, "latent_repeat", 1)
+        if rep not in (1, nb):
+            raise _lib.SdnError(f"unet.latent_repeat = {rep} but this call runs {nb} guidance branches")
+        shared_latents = rep == nb
+        x_in = None if shared_latents else torch.empty((nb * P, C_, s, s), dtype=torch.float32, device=dev)
+        model_out = torch.empty((nb * P, C_, s, s), dtype=torch.float32, device=dev)
         eps = torch.empty((P, C_, s, s), dtype=torch.float32, device=dev)
         x0 = torch.empty_like(eps)
         noise = torch.empty_like(eps)
@@ -135,12 +140,13 @@ class SafeDenoiserPipeline:
         momentum = torch.zeros_like(eps) if sld else None
 
         for i, t in enumerate(timesteps):
-            x_in.view(nb, P, C_, s, s).copy_(lat)                                   # cat([latents] * nb)
+            if not shared_latents:
+                x_in.view(nb, P, C_, s, s).copy_(lat)                               # cat([latents] * nb)
             if sf["svf"]:
                 use_safe = tb_safe is not None and beta_adjusted is not None and i <= beta_adjusted
             else:
                 use_safe = tb_safe is not None and sf["re_attn_t"][0] <= i <= sf["re_attn_t"][1]
-            self.unet.forward_into(x_in, float(t), tb_safe if use_safe else tb_plain, model_out)
+            self.unet.forward_into(lat if shared_latents else x_in, float(t), tb_safe if use_safe else tb_plain, model_out)
             if sld:
                 _lib.check(L.sdn_sld_guidance(model_out.data_ptr(), P, D, float(guidance_scale), sld["scale"], sld["thr"],
                                               sld["ms"], sld["mb"], int(i >= sld["warmup"]), momentum.data_ptr(),

@@ -40,10 +40,14 @@ def _interleave16(t: torch.Tensor) -> torch.Tensor:
 
 
 class UNet2DConditionModel:
-    def __init__(self, text_len: int = 77, dtype=torch.bfloat16, **config):
+    def __init__(self, text_len: int = 77, dtype=torch.bfloat16, latent_repeat: int = 1, **config):
+        """latent_repeat = r > 1: the engine-side form of `torch.cat([latents] * r)` (classifier-free guidance): `sample`
+        then holds B / r latents, `encoder_hidden_states` stays [B] branch-major, and everything up to the first
+        cross-attention is computed once per latent (sdn_unet_config.latent_repeat).  Bit-identical results."""
         if dtype not in (torch.bfloat16, torch.float16):
             raise _lib.SdnError("storage dtype must be torch.bfloat16 or torch.float16")
         self.dtype = dtype
+        self.latent_repeat = max(1, int(latent_repeat))
         cfg = dict(SD14_CONFIG)
         cfg.update(config)
         self.config = SimpleNamespace(**cfg)
@@ -58,7 +62,8 @@ class UNet2DConditionModel:
                                                               for t in cfg["down_block_types"]] + [0] * (4 - n))),
                             layers_per_block=cfg["layers_per_block"], n_heads=cfg["attention_head_dim"],
                             cross_dim=cfg["cross_attention_dim"], text_len=text_len,
-                            norm_groups=cfg["norm_num_groups"], dtype=0 if dtype == torch.bfloat16 else 1)
+                            norm_groups=cfg["norm_num_groups"], dtype=0 if dtype == torch.bfloat16 else 1,
+                            latent_repeat=self.latent_repeat)
         h = C.c_void_p()
         _lib.check(_lib.lib().sdn_unet_create(C.byref(c), C.byref(h)), "sdn_unet_create")
         self._h = h
@@ -203,8 +208,11 @@ class UNet2DConditionModel:
         return e.to(self.dtype).contiguous()
 
     def forward_into(self, sample, timestep, text_bf16, out):
-        """No-allocation form used by the engine loop (text already bf16, `out` preallocated fp32)."""
-        b = sample.shape[0]
+        """No-allocation form used by the engine loop (text already bf16, `out` preallocated fp32).  With latent_repeat = r
+        the sample has B / r rows, text and out have B."""
+        b = text_bf16.shape[0]
+        if sample.shape[0] * self.latent_repeat != b or out.shape[0] != b:
+            raise _lib.SdnError(f"batch mismatch: {sample.shape[0]} latents x latent_repeat {self.latent_repeat} vs {b} text rows")
         ws = self._workspace(b, sample.device)
         _lib.check(_lib.lib().sdn_unet_forward(self._h, _lib.dptr(self._weights), _lib.dptr(sample, torch.float32),
                                                float(timestep), _lib.dptr(text_bf16, self.dtype),
@@ -221,8 +229,8 @@ class UNet2DConditionModel:
         if tuple(x.shape[1:]) != (self.config.in_channels, s, s):
             raise _lib.SdnError(f"sample must be [B,{self.config.in_channels},{s},{s}], got {tuple(x.shape)}")
         e = self.prepare_text(encoder_hidden_states)
-        if e.shape[0] != x.shape[0]:
+        if e.shape[0] != x.shape[0] * self.latent_repeat:
             raise _lib.SdnError("batch mismatch between sample and encoder_hidden_states")
-        out = torch.empty((x.shape[0], self.config.out_channels, s, s), dtype=torch.float32, device=x.device)
+        out = torch.empty((e.shape[0], self.config.out_channels, s, s), dtype=torch.float32, device=x.device)
         self.forward_into(x, float(timestep), e, out)
         return UNetOutput(out) if return_dict else (out,)

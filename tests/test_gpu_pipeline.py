@@ -138,6 +138,24 @@ def test_device_generators_are_per_prompt(world):
         pipe(prompt="a photo", num_inference_steps=5)
 
 
+def test_loop_with_engine_side_latent_repeat_is_bit_identical(world, tmp_path):
+    """A UNet built with latent_repeat = 2 takes the P latents directly (no cat([latents] * 2) copy) and shares the
+    branch-independent prefix: the loop's latents must not change by a single bit."""
+    u, sd, E, refs, P = world
+    u2 = UNet2DConditionModel(text_len=77, latent_repeat=2, **SMALL)
+    u2.load_state_dict(sd)
+    outs = []
+    for unet in (u, u2):
+        proc = make_proc(thr, refs, tmp_path, scale=0.03, sigma=1.0, epsilon=1e-8, beta_threshold=0.5, beta_threshold_margin=0.1)
+        pipe = SafeDenoiserPipeline(unet, DDPMScheduler(), variant="threshold_time")
+        gens = [torch.Generator(device="cuda").manual_seed(50 + i) for i in range(P)]
+        outs.append(pipe(prompt_embeddings=E.cuda(), num_inference_steps=8, generator=gens, repellency_processor=proc))
+    torch.testing.assert_close(outs[1], outs[0], rtol=0, atol=0)
+    with pytest.raises(Exception):                                   # 3 branches on a repeat-2 plan
+        SafeDenoiserPipeline(u2, DDPMScheduler())(prompt_embeddings=torch.cat([E, E[:P]]).cuda(), num_inference_steps=2,
+                                                   sld_guidance_scale=2000.0)
+
+
 def test_fp16_storage_loop_parity(tmp_path):
     """Same tape test with fp16 storage: final 20-step latents within 1.5e-2 rel L2 (bf16: 2.5-4e-2)."""
     u = UNet2DConditionModel(text_len=77, dtype=torch.float16, **SMALL)

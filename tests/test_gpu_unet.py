@@ -82,6 +82,37 @@ def test_full_sd14_unet_bench_batch_rows_equal_small_batch_rows(batch):
         torch.testing.assert_close(y2, y[lo:lo + 2], rtol=0, atol=0)
 
 
+@pytest.mark.parametrize("rep,full", [(2, False), (3, False), (2, True)])
+def test_latent_repeat_plan_is_bit_identical_to_repeated_latents(rep, full):
+    """sdn_unet_config.latent_repeat: the guidance branches share their latents, so conv_in, resnet 0 and the head of the
+    first transformer block run once per latent.  Same weights, same text -> bit-identical output to the plain plan fed
+    torch.cat([latents] * rep) (the reference's form, ...threshold_time.py:535)."""
+    cfg = {} if full else SMALL
+    side = 64 if full else 16
+    plain = UNet2DConditionModel(text_len=77, **cfg)
+    shared = UNet2DConditionModel(text_len=77, latent_repeat=rep, **cfg)
+    assert [p["name"] for p in plain.manifest] == [p["name"] for p in shared.manifest]
+    if full:
+        plain.load_synthetic_on_device(77)
+        shared._weights = plain._weights
+    else:
+        sd = plain.synthetic_state_dict(7)
+        plain.load_state_dict(sd); shared.load_state_dict(sd)
+    g = torch.Generator().manual_seed(rep)
+    P = 3
+    x = torch.randn(P, 4, side, side, generator=g).cuda()
+    e = torch.randn(rep * P, 77, 768, generator=g).cuda()
+    y_plain = plain(torch.cat([x] * rep), 801.0, encoder_hidden_states=e).sample
+    y_shared = shared(x, 801.0, encoder_hidden_states=e).sample
+    assert y_shared.shape == y_plain.shape
+    torch.testing.assert_close(y_shared, y_plain, rtol=0, atol=0)
+    f_plain, f_shared = plain.flops(rep * P)[0], shared.flops(rep * P)[0]
+    assert f_shared < f_plain
+    print(f"latent_repeat={rep}: {100 * (1 - f_shared / f_plain):.1f} % fewer FLOPs per forward")
+    with pytest.raises(Exception):
+        shared(x[:2], 801.0, encoder_hidden_states=e)              # text rows != latents x repeat
+
+
 def test_small_unet_fp16_storage_meets_fp16_tolerance():
     """fp16 storage (the reference's SD-v3 dtype; north-star "within fp16 tolerance"): rel L2 <= 4e-3 vs the fp32
     oracle and vs the fp16-emulating oracle (the oracle itself: fp16 emulation vs fp32 = 1.4e-3)."""
