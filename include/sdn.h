@@ -402,6 +402,12 @@ int sdn_softmax_rows(int32_t dtype, const float* scores, int64_t ld_scores, int6
 /* out[c, r] = in[r, c] for a 16-bit [rows, cols] matrix */
 int sdn_transpose16(const void* in, int32_t rows, int32_t cols, int64_t ld_in, void* out, int64_t ld_out, void* stream);
 
+/* Graph mode for launch-bound (small) batches: sdn_unet_forward / sdn_mmdit_forward capture their ~850 launches into a
+ * hipGraph once per (batch, operand addresses) and replay it afterwards -- one launch per forward plus a one-float store
+ * of the timestep.  Results are identical.  Off by default; a forward issued while the caller's stream is itself being
+ * captured, or a profiled forward, always launches op by op.  Keeps up to 16 instantiated graphs per handle. */
+void sdn_unet_set_graph_mode(sdn_unet* u, int32_t on);
+
 /* ---- opt-in measurement: HIP events around every launch of ONE forward, on the forward's own stream ---- */
 typedef struct sdn_profile_row {
   char    kernel[24];     /* kernel symbol, e.g. "k_gemm<5>", "k_attn<40>"                              */

@@ -131,6 +131,7 @@ SIGNATURES = {
     "sdn_latent_mix": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp]),
     "sdn_softmax_rows": (C.c_int, [_i32, _vp, _i64, _i64, _i32, _f32, _vp, _i64, _vp]),
     "sdn_transpose16": (C.c_int, [_vp, _i32, _i32, _i64, _vp, _i64, _vp]),
+    "sdn_unet_set_graph_mode": (None, [_vp, _i32]),
     "sdn_unet_profile_next": (None, [_vp]),
     "sdn_unet_profile_read": (C.c_int, [_vp, C.POINTER(ProfileRow), _i32]),
 }

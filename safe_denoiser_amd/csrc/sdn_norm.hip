@@ -277,7 +277,8 @@ k_conv_in(const float* __restrict__ lat, const unsigned short* __restrict__ w, c
 }
 
 template <typename T>
-__global__ void k_temb(float t, int B, int dim, unsigned short* __restrict__ out) {
+__global__ void k_temb(float t_val, const float* __restrict__ t_dev, int B, int dim, unsigned short* __restrict__ out) {
+  const float t = t_dev ? *t_dev : t_val;           // t_dev: graph replays read the step's timestep from device memory
   const int half = dim / 2;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * dim; i += gridDim.x * blockDim.x) {
     const int k = i % dim;
@@ -415,16 +416,29 @@ int conv_in_impl(const float* lat, const void* w, const float* bias, int32_t bat
 }
 
 template <typename T>
-int temb_impl(float timestep, int32_t batch, int32_t dim, void* out, void* stream) {
+int temb_impl(float timestep, int32_t batch, int32_t dim, void* out, void* stream, const float* t_dev = nullptr) {
   if (!out || batch < 0 || dim <= 0 || (dim & 1)) return SDN_E_INVALID;
   if (batch == 0) return SDN_OK;
   const int n = batch * dim;
-  hipLaunchKernelGGL((k_temb<T>), dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, timestep, batch, dim,
+  hipLaunchKernelGGL((k_temb<T>), dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, timestep, t_dev, batch, dim,
                      (unsigned short*)out);
   return sdn_launch_status();
 }
 
 }  // namespace sdn_norm_detail
+
+// internal (sdn_ops.h): timestep features with the timestep read from device memory; a one-float store
+int sdn_temb_from_device(int dtype, const float* t_dev, int batch, int dim, void* out, void* stream) {
+  if (!t_dev) return SDN_E_INVALID;
+  return dtype == 1 ? sdn_norm_detail::temb_impl<SdnF16>(0.f, batch, dim, out, stream, t_dev)
+                    : sdn_norm_detail::temb_impl<SdnBF16>(0.f, batch, dim, out, stream, t_dev);
+}
+namespace { __global__ void k_set_scalar(float* dst, float v) { *dst = v; } }
+int sdn_set_scalar(float* dst, float v, void* stream) {
+  if (!dst) return SDN_E_INVALID;
+  hipLaunchKernelGGL(k_set_scalar, dim3(1), dim3(1), 0, (hipStream_t)stream, dst, v);
+  return sdn_launch_status();
+}
 using namespace sdn_norm_detail;
 
 #define SDN_NORM_ENTRY(SUF, T)                                                                                          \

@@ -5,3 +5,7 @@
 int sdn_gemm_pick_nrep(int n_padded, int act);
 // NREP actually launched for this shape (10 / 8 = the 256-row, 8-wave tile; 5 / 4 / 2 / 1 = the 128-row tile).
 int sdn_gemm_pick_tile(int M, int N, int K, int act);
+
+// graph mode of the plan runner: the step's timestep lives in device memory so that a captured forward can be replayed
+int sdn_temb_from_device(int dtype, const float* t_dev, int batch, int dim, void* out, void* stream);
+int sdn_set_scalar(float* dst, float v, void* stream);

@@ -25,6 +25,7 @@
 
 #include <map>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "sdn_common.h"
@@ -104,6 +105,7 @@ struct Act {                         // a bf16 [rows, C] activation living in th
 
 struct Plan {
   int batch = 0;
+  int64_t tscalar_off = -1;          // 256-byte workspace slot holding the step's timestep (graph mode)
   std::vector<Op> ops;
   int64_t ws_bytes = 0;
   double flops = 0.0, attn_flops = 0.0;
@@ -127,6 +129,21 @@ struct sdn_unet {
                                          // activation.  Measured at B = 64 (tools/profile_ops.py, SUBBATCH=...): 48 MB
                                          // -> +5 %, 24 MB -> +10 % forward time, i.e. no cache-residency win -> OFF.
   bool profile_next = false;
+  // graph mode (sdn_unet_set_graph_mode): one captured hipGraph per (batch, operand addresses); replays cost one launch
+  bool use_graph = false;
+  struct GraphKey {
+    int batch; const void *w, *lat, *text, *pooled, *out, *ws;
+    bool operator<(const GraphKey& o) const {
+      return std::tie(batch, w, lat, text, pooled, out, ws) < std::tie(o.batch, o.w, o.lat, o.text, o.pooled, o.out, o.ws);
+    }
+  };
+  std::map<GraphKey, hipGraphExec_t> graphs;
+  hipStream_t cap_stream = nullptr;     // capture happens here (the caller's stream may be the legacy null stream)
+  ~sdn_unet() {
+    for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
+    for (auto e : ev) (void)hipEventDestroy(e);
+    if (cap_stream) (void)hipStreamDestroy(cap_stream);
+  }
   std::vector<hipEvent_t> ev;          // 2 per op of the profiled forward
   int profiled_batch = 0;
 };
@@ -441,6 +458,7 @@ struct Builder {
     u->tproj_total = total;
 
     // ---- conditioning: silu(time_emb + pooled_emb) -> all modulation vectors ----
+    plan->tscalar_off = arena.alloc(256);
     Act tsin = act(B, c.time_dim);
     { Op o; o.kind = OP_TEMB; o.batch = B; o.c1 = c.time_dim; o.out = R(tsin); snprintf(o.label, sizeof(o.label), "k_temb"); plan->ops.push_back(o); }
     Act th = act(B, C);
@@ -606,6 +624,7 @@ struct Builder {
     }
     u->tproj_total = total;
     gn_stats = Ref{SP_WS, arena.alloc((int64_t)B * 129 * 64 * 2 * 4)};
+    plan->tscalar_off = arena.alloc(256);
     Act tsin = act(B, ch0);
     { Op o; o.kind = OP_TEMB; o.batch = B; o.c1 = ch0; o.out = R(tsin); snprintf(o.label, sizeof(o.label), "k_temb"); plan->ops.push_back(o); }
     Act t1 = act(B, tdim);
@@ -1093,22 +1112,10 @@ int sdn_mmdit_forward(sdn_unet* u, const void* weights, const float* latents, fl
   return run_plan(u, weights, latents, timestep, text, pooled, out, batch, workspace, workspace_bytes, stream);
 }
 
-static int run_plan(sdn_unet* u, const void* weights, const float* latents, float timestep, const void* text,
-                    const void* pooled, float* out, int32_t batch, void* workspace, size_t workspace_bytes, void* stream) {
-  if (!u || !weights || !latents || !text || !out || !workspace || batch <= 0) return SDN_E_INVALID;
-  Plan* p = get_plan(u, batch);
-  if (p->ws_bytes < 0) return SDN_E_INVALID;                      // e.g. batch not a multiple of latent_repeat
-  if (workspace_bytes < (size_t)p->ws_bytes) return SDN_E_WORKSPACE;
-  const char* W = (const char*)weights; const char* WS = (const char*)workspace;
-  const char* L = (const char*)latents; const char* T = (const char*)text; const char* O = (const char*)out;
-  const char* PL = (const char*)pooled;
+// Launches every op of the plan on `stream`.  t_dev != nullptr: the timestep is read from device memory (graph mode).
+static int launch_ops(sdn_unet* u, Plan* p, const char* W, const char* WS, const char* L, const char* T, const char* O,
+                      const char* PL, float timestep, const float* t_dev, bool prof, void* stream) {
   auto P = [&](const Ref& r) { return resolve(r, W, WS, L, T, O, PL); };
-  const bool prof = u->profile_next;
-  if (prof) {                                    // opt-in diagnostics: HIP events around every launch of this forward
-    u->profile_next = false;
-    while (u->ev.size() < 2 * p->ops.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return SDN_E_LAUNCH; u->ev.push_back(e); }
-    u->profiled_batch = batch;
-  }
   size_t opi = 0;
   const bool f16 = (u->is_mmdit ? u->mcfg.dtype : u->cfg.dtype) == 1;
   for (const Op& o : p->ops) {
@@ -1116,7 +1123,8 @@ static int run_plan(sdn_unet* u, const void* weights, const float* latents, floa
     if (prof) (void)hipEventRecord(u->ev[2 * opi], (hipStream_t)stream);
     switch (o.kind) {
       case OP_TEMB:
-        rc = (f16 ? sdn_timestep_embed_f16 : sdn_timestep_embed_bf16)(timestep, o.batch, o.c1, (void*)P(o.out), stream);
+        if (t_dev) rc = sdn_temb_from_device(f16 ? 1 : 0, t_dev, o.batch, o.c1, (void*)P(o.out), stream);
+        else rc = (f16 ? sdn_timestep_embed_f16 : sdn_timestep_embed_bf16)(timestep, o.batch, o.c1, (void*)P(o.out), stream);
         break;
       case OP_CONV_IN:
         rc = (f16 ? sdn_conv_in_f16 : sdn_conv_in_bf16)((const float*)P(o.a), P(o.w), (const float*)P(o.bias), o.batch, o.c1, o.hw, o.hw, o.c2,
@@ -1179,7 +1187,64 @@ static int run_plan(sdn_unet* u, const void* weights, const float* latents, floa
   return SDN_OK;
 }
 
+
+static int run_plan(sdn_unet* u, const void* weights, const float* latents, float timestep, const void* text,
+                    const void* pooled, float* out, int32_t batch, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!u || !weights || !latents || !text || !out || !workspace || batch <= 0) return SDN_E_INVALID;
+  Plan* p = get_plan(u, batch);
+  if (p->ws_bytes < 0) return SDN_E_INVALID;                      // e.g. batch not a multiple of latent_repeat
+  if (workspace_bytes < (size_t)p->ws_bytes) return SDN_E_WORKSPACE;
+  const char* W = (const char*)weights; const char* WS = (const char*)workspace;
+  const char* L = (const char*)latents; const char* T = (const char*)text; const char* O = (const char*)out;
+  const char* PL = (const char*)pooled;
+  const bool prof = u->profile_next;
+  if (prof) {                                    // opt-in diagnostics: HIP events around every launch of this forward
+    u->profile_next = false;
+    while (u->ev.size() < 2 * p->ops.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return SDN_E_LAUNCH; u->ev.push_back(e); }
+    u->profiled_batch = batch;
+  }
+  hipStream_t hs = (hipStream_t)stream;
+  if (u->use_graph && !prof && !u->is_vae && p->tscalar_off >= 0) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(hs, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) {
+      // Graph mode: small batches are launch-bound (~850 launches per forward); the forward is captured once per
+      // (batch, operand addresses) and replayed.  The timestep is the only per-step scalar: it is stored to the
+      // workspace by one ordinary launch and k_temb reads it from there.
+      float* t_dev = (float*)(WS + p->tscalar_off);
+      int rc = sdn_set_scalar(t_dev, timestep, stream);
+      if (rc != SDN_OK) return rc;
+      const sdn_unet::GraphKey key{batch, weights, latents, text, pooled, out, workspace};
+      auto it = u->graphs.find(key);
+      if (it == u->graphs.end()) {
+        if (u->graphs.size() >= 16) {                          // operands keep moving: graphs do not pay, stop hoarding
+          for (auto& kv : u->graphs) (void)hipGraphExecDestroy(kv.second);
+          u->graphs.clear();
+        }
+        hipGraph_t graph = nullptr;
+        if (!u->cap_stream && hipStreamCreateWithFlags(&u->cap_stream, hipStreamNonBlocking) != hipSuccess) return SDN_E_LAUNCH;
+        if (hipStreamBeginCapture(u->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return SDN_E_LAUNCH;
+        rc = launch_ops(u, p, W, WS, L, T, O, PL, timestep, t_dev, false, (void*)u->cap_stream);   // records, does not run
+        const hipError_t ec = hipStreamEndCapture(u->cap_stream, &graph);
+        if (rc != SDN_OK || ec != hipSuccess || !graph) { if (graph) (void)hipGraphDestroy(graph); return rc != SDN_OK ? rc : SDN_E_LAUNCH; }
+        hipGraphExec_t exec = nullptr;
+        const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (ei != hipSuccess || !exec) return SDN_E_LAUNCH;
+        it = u->graphs.emplace(key, exec).first;
+      }
+      return hipGraphLaunch(it->second, hs) == hipSuccess ? SDN_OK : SDN_E_LAUNCH;
+    }
+  }
+  return launch_ops(u, p, W, WS, L, T, O, PL, timestep, nullptr, prof, stream);
+}
+
 void sdn_unet_profile_next(sdn_unet* u) { if (u) u->profile_next = true; }
+
+void sdn_unet_set_graph_mode(sdn_unet* u, int32_t on) {
+  if (!u) return;
+  u->use_graph = on != 0;
+  if (!on) { for (auto& kv : u->graphs) (void)hipGraphExecDestroy(kv.second); u->graphs.clear(); }
+}
 
 // Undeclared tuning hook (tools/): size threshold of the transformer sub-batching; rebuilds the plans.
 extern "C" void sdn_debug_set_subbatch_bytes(sdn_unet* u, long long bytes) {

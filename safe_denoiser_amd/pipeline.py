@@ -38,10 +38,13 @@ VARIANTS = {
 
 
 class SafeDenoiserPipeline:
-    def __init__(self, unet, scheduler, variant: str = "threshold_time", vae=None):
+    GRAPH_MAX_BATCH = 16      # UNet rows (branches x prompts) up to which a forward is launch-bound and replayed as a hipGraph
+
+    def __init__(self, unet, scheduler, variant: str = "threshold_time", vae=None, use_graphs: Optional[bool] = None):
         if variant not in VARIANTS:
             raise KeyError(f"unknown variant {variant}; have {sorted(VARIANTS)}")
         self.unet, self.scheduler, self.variant, self.vae = unet, scheduler, variant, vae
+        self.use_graphs = use_graphs          # None = automatic: on for small batches (the reference's one-prompt calls)
         self.vae_scale_factor = 8
         self.last_stats = {}
 
@@ -128,6 +131,8 @@ class SafeDenoiserPipeline:
         if rep not in (1, nb):
             raise _lib.SdnError(f"unet.latent_repeat = {rep} but this call runs {nb} guidance branches")
         shared_latents = rep == nb
+        if hasattr(self.unet, "set_graph_mode"):
+            self.unet.set_graph_mode(nb * P <= self.GRAPH_MAX_BATCH if self.use_graphs is None else bool(self.use_graphs))
         x_in = None if shared_latents else torch.empty((nb * P, C_, s, s), dtype=torch.float32, device=dev)
         model_out = torch.empty((nb * P, C_, s, s), dtype=torch.float32, device=dev)
         eps = torch.empty((P, C_, s, s), dtype=torch.float32, device=dev)

@@ -113,6 +113,39 @@ def test_latent_repeat_plan_is_bit_identical_to_repeated_latents(rep, full):
         shared(x[:2], 801.0, encoder_hidden_states=e)              # text rows != latents x repeat
 
 
+def test_graph_mode_replays_are_bit_identical():
+    """sdn_unet_set_graph_mode: the forward is captured once per (batch, operand addresses) and replayed; the timestep is
+    the only per-step scalar and is read from device memory, so replays at other timesteps must match op-by-op launches."""
+    u = UNet2DConditionModel(text_len=77, latent_repeat=2, **SMALL)
+    u.load_state_dict(u.synthetic_state_dict(7))
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 4, 16, 16, generator=g).cuda()
+    e1 = u.prepare_text(torch.randn(4, 77, 768, generator=g).cuda())
+    e2 = u.prepare_text(torch.randn(4, 77, 768, generator=g).cuda())
+    out = torch.empty(4, 4, 16, 16, device="cuda")
+    ref = {}
+    for t in (981.0, 501.0, 1.0):
+        for name, e in (("e1", e1), ("e2", e2)):
+            ref[(t, name)] = u.forward_into(x, t, e, out).clone()
+    u.set_graph_mode(True)
+    for rnd in range(2):                                             # first round captures, second replays
+        for t in (981.0, 501.0, 1.0):
+            for name, e in (("e1", e1), ("e2", e2)):                 # two text buffers -> two graphs, alternating
+                torch.testing.assert_close(u.forward_into(x, t, e, out), ref[(t, name)], rtol=0, atol=0)
+    x2 = x.clone() * 0.5                                              # the latents changed IN PLACE: same graph, new result
+    want = None
+    u.set_graph_mode(False)
+    want = u.forward_into(x2, 501.0, e1, out).clone()
+    u.set_graph_mode(True)
+    x.copy_(x2)
+    torch.testing.assert_close(u.forward_into(x, 501.0, e1, out), want, rtol=0, atol=0)
+    # profiling a forward bypasses the graph and still works
+    u.profile_next()
+    u.forward_into(x, 501.0, e1, out)
+    assert sum(r["launches"] for r in u.profile_read()) > 50
+    torch.cuda.synchronize()
+
+
 def test_small_unet_fp16_storage_meets_fp16_tolerance():
     """fp16 storage (the reference's SD-v3 dtype; north-star "within fp16 tolerance"): rel L2 <= 4e-3 vs the fp32
     oracle and vs the fp16-emulating oracle (the oracle itself: fp16 emulation vs fp32 = 1.4e-3)."""
