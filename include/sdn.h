@@ -171,6 +171,7 @@ int sdn_flow_renoise(const float* x0r, const float* x1, const float* z, int64_t 
 #define SDN_ACT_SILU   1
 #define SDN_ACT_GEGLU  2   /* W rows interleaved value/gate in blocks of 16; out = v*gelu(g)  */
 #define SDN_ACT_GELU_TANH 3 /* GELU(approximate="tanh") -- MMDiT feed-forward                   */
+#define SDN_ACT_QUICK_GELU 4 /* x * sigmoid(1.702 x) -- CLIP text encoder MLP                     */
 #define SDN_OUT_BF16      0   /* [M, ldc] bf16                                                */
 #define SDN_OUT_F32       1   /* [M, ldc] f32                                                 */
 #define SDN_OUT_F32_NCHW  2   /* [B, n_valid, rows_per_batch] f32 (conv_out -> latent layout) */
@@ -401,6 +402,31 @@ int sdn_softmax_rows(int32_t dtype, const float* scores, int64_t ld_scores, int6
                      void* out, int64_t ld_out, void* stream);
 /* out[c, r] = in[r, c] for a 16-bit [rows, cols] matrix */
 int sdn_transpose16(const void* in, int32_t rows, int32_t cols, int64_t ld_in, void* out, int64_t ld_out, void* stream);
+
+/* ---- CLIP text encoder ------------------------------------------------------------------------------
+ * Replaces `self.text_encoder(input_ids, attention_mask=...)[0]` (transformers CLIPTextModel, third party), called at
+ * models/textuals_visual/modified_safree_diffusion_pipeline_threshold_time.py:197,225,287,333.  Handle = sdn_unet
+ * (manifest / weights / workspace through the sdn_unet_* queries); manifest keys are CLIPTextModel's, without the
+ * `text_model.` prefix: embeddings.{token,position}_embedding.weight, encoder.layers.N.{layer_norm1,self_attn.{q,k,v,out}_proj,
+ * layer_norm2,mlp.fc1,mlp.fc2}.*, final_layer_norm.*.  The tokenizer (vocabulary files) stays with the caller. */
+typedef struct sdn_clip_config {
+  int32_t vocab_size;                    /* 49408                                                      */
+  int32_t hidden_size, intermediate_size;/* 768, 3072                                                  */
+  int32_t num_layers, num_heads;         /* 12, 12 (head dim must be 64)                               */
+  int32_t max_position_embeddings;       /* 77 = the sequence length every call uses                   */
+  int32_t dtype;                         /* 0 = bf16, 1 = fp16 storage                                 */
+} sdn_clip_config;
+int sdn_clip_create(const sdn_clip_config* cfg_host, sdn_unet** out_host);
+/* last_hidden_state [B, 77, hidden] 16-bit (after final_layer_norm) = text_model(input_ids [B, 77] int32,
+ * attention_mask [B, 77] int32 with 1 = attend / 0 = padding, or NULL).  Attention is causal, as in CLIP. */
+int sdn_clip_forward(sdn_unet* clip, const void* weights, const int32_t* input_ids, const int32_t* attention_mask,
+                     void* last_hidden_state, int32_t batch, void* workspace, size_t workspace_bytes, void* stream);
+/* its building blocks: embedding lookup, and attention with a causal and / or key-padding mask (head dim 64 only) */
+int sdn_clip_embed(int32_t dtype, const int32_t* input_ids, const void* token_embedding, const void* position_embedding,
+                   int64_t rows, int32_t seq_len, int32_t hidden, int32_t vocab, void* out, void* stream);
+int sdn_masked_attention(int32_t dtype, const void* q, const void* k, const void* v, void* out, const int32_t* key_mask,
+                         int32_t causal, int32_t batch, int32_t heads, int32_t n, int32_t head_dim, int32_t ldq,
+                         int32_t ldk, int32_t ldv, int32_t ldo, float scale, void* stream);
 
 /* Graph mode for launch-bound (small) batches: sdn_unet_forward / sdn_mmdit_forward capture their ~850 launches into a
  * hipGraph once per (batch, operand addresses) and replay it afterwards -- one launch per forward plus a one-float store

@@ -62,6 +62,11 @@ class VaeConfig(C.Structure):
                 ("norm_groups", C.c_int32), ("dtype", C.c_int32)]
 
 
+class ClipConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("vocab_size", "hidden_size", "intermediate_size", "num_layers", "num_heads",
+                                         "max_position_embeddings", "dtype")]
+
+
 class AttnSegment2(C.Structure):
     _fields_ = [("q2", C.c_void_p), ("k2", C.c_void_p), ("v2", C.c_void_p), ("out2", C.c_void_p), ("n1", C.c_int32),
                 ("ldq2", C.c_int32), ("ldk2", C.c_int32), ("ldv2", C.c_int32), ("ldo2", C.c_int32)]
@@ -131,6 +136,11 @@ SIGNATURES = {
     "sdn_latent_mix": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp]),
     "sdn_softmax_rows": (C.c_int, [_i32, _vp, _i64, _i64, _i32, _f32, _vp, _i64, _vp]),
     "sdn_transpose16": (C.c_int, [_vp, _i32, _i32, _i64, _vp, _i64, _vp]),
+    "sdn_clip_create": (C.c_int, [C.POINTER(ClipConfig), C.POINTER(_vp)]),
+    "sdn_clip_forward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _sz, _vp]),
+    "sdn_clip_embed": (C.c_int, [_i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
+    "sdn_masked_attention": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
+                                       _f32, _vp]),
     "sdn_unet_set_graph_mode": (None, [_vp, _i32]),
     "sdn_unet_profile_next": (None, [_vp]),
     "sdn_unet_profile_read": (C.c_int, [_vp, C.POINTER(ProfileRow), _i32]),

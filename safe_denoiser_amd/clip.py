@@ -1,0 +1,93 @@
+"""CLIPTextModel front-end: `text_encoder(input_ids, attention_mask=None)[0]` as the reference's pipelines call it
+(models/textuals_visual/modified_safree_diffusion_pipeline_threshold_time.py:197,225,287,333), executed by libsdn's launch
+plan (sdn_clip_create / sdn_clip_forward).  SURVEY section 8f row 4.
+
+Weights: a transformers CLIPTextModel state_dict (keys with or without the `text_model.` prefix), packed once into the
+engine layout.  The tokenizer stays with the caller (its vocabulary files are not part of this engine): pass token ids.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from types import SimpleNamespace
+
+import torch
+
+from . import _lib
+from .unet import UNet2DConditionModel
+
+SD14_CLIP_CONFIG = dict(vocab_size=49408, hidden_size=768, intermediate_size=3072, num_hidden_layers=12,
+                        num_attention_heads=12, max_position_embeddings=77)
+
+
+class TextEncoderOutput(tuple):
+    """(last_hidden_state, pooler_output) with attribute access, like transformers' BaseModelOutputWithPooling."""
+
+    def __new__(cls, last_hidden_state, pooler_output):
+        o = super().__new__(cls, (last_hidden_state, pooler_output))
+        o.last_hidden_state, o.pooler_output = last_hidden_state, pooler_output
+        return o
+
+
+class CLIPTextModel(UNet2DConditionModel):
+    def __init__(self, dtype=torch.bfloat16, **config):
+        if dtype not in (torch.bfloat16, torch.float16):
+            raise _lib.SdnError("storage dtype must be torch.bfloat16 or torch.float16")
+        self.dtype = dtype
+        self.latent_repeat = 1
+        cfg = dict(SD14_CLIP_CONFIG)
+        cfg.update(config)
+        self.config = SimpleNamespace(**cfg)
+        c = _lib.ClipConfig(vocab_size=cfg["vocab_size"], hidden_size=cfg["hidden_size"],
+                            intermediate_size=cfg["intermediate_size"], num_layers=cfg["num_hidden_layers"],
+                            num_heads=cfg["num_attention_heads"], max_position_embeddings=cfg["max_position_embeddings"],
+                            dtype=0 if dtype == torch.bfloat16 else 1)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().sdn_clip_create(C.byref(c), C.byref(h)), "sdn_clip_create")
+        self._h = h
+        self._weights = None
+        self._ws = {}
+        self.manifest = []
+        info = _lib.ParamInfo()
+        for i in range(_lib.lib().sdn_unet_param_count(h)):
+            _lib.check(_lib.lib().sdn_unet_param_info(h, i, C.byref(info)), "sdn_unet_param_info")
+            self.manifest.append(dict(name=info.name.decode(), kind=info.kind, rows=info.rows, cols=info.cols,
+                                      rows_padded=info.rows_padded, offset=info.offset))
+        self.weight_bytes = _lib.lib().sdn_unet_weight_bytes(h)
+
+    def state_dict_shapes(self) -> dict:
+        return {p["name"]: ((p["rows"],) if p["cols"] == 0 else (p["rows"], p["cols"])) for p in self.manifest}
+
+    @staticmethod
+    def _is_norm_param(name: str) -> bool:
+        return "norm" in name.split(".")[-2]
+
+    @staticmethod
+    def _canonical(sd: dict) -> dict:
+        return {(k[len("text_model."):] if k.startswith("text_model.") else k): v for k, v in sd.items()}
+
+    def pack_state_dict(self, sd: dict) -> torch.Tensor:
+        return super().pack_state_dict(self._canonical(sd))
+
+    def load_state_dict(self, sd: dict, device="cuda"):
+        return super().load_state_dict(self._canonical(sd), device)
+
+    def __call__(self, input_ids: torch.Tensor, attention_mask: torch.Tensor | None = None, **unused):
+        _lib.require_gpu()
+        if self._weights is None:
+            raise _lib.SdnError("no weights loaded: call load_state_dict() first")
+        n = self.config.max_position_embeddings
+        if input_ids.dim() != 2 or input_ids.shape[1] != n:
+            raise _lib.SdnError(f"input_ids must be [B,{n}] (tokenizer padding='max_length'), got {tuple(input_ids.shape)}")
+        ids = input_ids.to(torch.int32).contiguous()
+        mask = None if attention_mask is None else attention_mask.to(device=ids.device, dtype=torch.int32).contiguous()
+        if mask is not None and tuple(mask.shape) != tuple(ids.shape):
+            raise _lib.SdnError("attention_mask must have the shape of input_ids")
+        b = ids.shape[0]
+        out = torch.empty((b, n, self.config.hidden_size), dtype=self.dtype, device=ids.device)
+        ws = self._workspace(b, ids.device)
+        _lib.check(_lib.lib().sdn_clip_forward(self._h, _lib.dptr(self._weights), _lib.dptr(ids, torch.int32),
+                                               None if mask is None else _lib.dptr(mask, torch.int32), _lib.dptr(out, self.dtype),
+                                               b, _lib.dptr(ws), ws.numel(), _lib.stream_ptr()), "sdn_clip_forward")
+        # pooled = features at the EOT token = the highest id of each sequence (CLIPTextTransformer.forward)
+        pooled = out[torch.arange(b, device=ids.device), ids.argmax(dim=-1)]
+        return TextEncoderOutput(out, pooled)

@@ -66,6 +66,7 @@ struct AttnArgs {
   // in its own buffer -> the concatenated sequence is never materialised)
   const unsigned short* q2; const unsigned short* k2; const unsigned short* v2; unsigned short* out2;
   int n1, ldq2, ldk2, ldv2, ldo2;
+  int causal; const int* kmask;      // MASK instantiation only: key <= query; kmask [B, nk] (0 = padded key), nullable
 };
 
 // Row `row` of sample b in a (possibly two-segment) [B, n, ld] tensor.
@@ -76,7 +77,9 @@ __device__ __forceinline__ const unsigned short* row_ptr(const unsigned short* p
   return p1 + ((long)b * (SEG ? n1 : n) + row) * ld1;
 }
 
-template <typename T, int HD, bool SEG>
+// MASK (CLIP text encoder): causal mask (key <= query) and an optional per-sample key-padding mask; a separate
+// instantiation so that the UNet / MMDiT kernels carry no trace of it.
+template <typename T, int HD, bool SEG, bool MASK = false>
 __global__ void __launch_bounds__(THREADS)
 k_attn(const AttnArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -289,7 +292,18 @@ k_attn(const AttnArgs a) {
         st[kb] = T::mfma32(kf, qf[s], st[kb]);
       }
     }
-    if ((t + 1) * KV > a.nk) {                    // ragged last tile (cross-attention: 77 keys)
+    if constexpr (MASK) {
+      const int k0 = t * KV;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int key = k0 + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
+          bool off = key >= a.nk || (a.causal && key > q0 + r);
+          if (!off && a.kmask) off = a.kmask[(long)b * a.nk + key] == 0;
+          if (off) st[kb][i] = -1e30f;
+        }
+    } else if ((t + 1) * KV > a.nk) {             // ragged last tile (cross-attention: 77 keys)
       const int k0 = t * KV;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -441,6 +455,15 @@ k_attn(const AttnArgs a) {
 
 template <typename T, int HD>
 int launch(const AttnArgs& a, int batch, int heads, hipStream_t st) {
+  if (a.causal || a.kmask) {
+    if constexpr (HD == 64) {
+      if (a.q2) return SDN_E_INVALID;
+      hipLaunchKernelGGL((k_attn<T, HD, false, true>), dim3(a.nqb * a.npairs), dim3(THREADS), 0, st, a);
+      return sdn_launch_status();
+    } else {
+      return SDN_E_INVALID;                     // masked attention is instantiated for d = 64 (CLIP) only
+    }
+  }
   if (a.q2) hipLaunchKernelGGL((k_attn<T, HD, true>), dim3(a.nqb * a.npairs), dim3(THREADS), 0, st, a);
   else hipLaunchKernelGGL((k_attn<T, HD, false>), dim3(a.nqb * a.npairs), dim3(THREADS), 0, st, a);
   return sdn_launch_status();
@@ -449,7 +472,7 @@ int launch(const AttnArgs& a, int batch, int heads, hipStream_t st) {
 template <typename T>
 int run(const void* q, const void* k, const void* v, void* out, int32_t batch, int32_t heads, int32_t nq, int32_t nk,
         int32_t head_dim, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo, float scale, void* stream,
-        const sdn_attn_segment2* s2 = nullptr) {
+        const sdn_attn_segment2* s2 = nullptr, int causal = 0, const int* kmask = nullptr) {
   if (!q || !k || !v || !out || batch < 0 || heads <= 0 || nq <= 0 || nk <= 0) return SDN_E_INVALID;
   if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3) || nk > 65535) return SDN_E_INVALID;
   if (ldq < heads * head_dim || ldk < heads * head_dim || ldv < heads * head_dim || ldo < heads * head_dim)
@@ -459,7 +482,8 @@ int run(const void* q, const void* k, const void* v, void* out, int32_t batch, i
   if (batch == 0) return SDN_OK;
   AttnArgs a{(const unsigned short*)q, (const unsigned short*)k, (const unsigned short*)v, (unsigned short*)out,
              nq, nk, ldq, ldk, ldv, ldo, scale * 1.4426950408889634f, heads, (nq + QB - 1) / QB, batch * heads,
-             nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0};
+             nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, causal, kmask};
+  if (causal && nq != nk) return SDN_E_INVALID;
   if (s2) {                                                  // joint attention over two token streams (nq == nk)
     if (!s2->q2 || !s2->k2 || !s2->v2 || !s2->out2 || s2->n1 <= 0 || s2->n1 >= nq || nq != nk) return SDN_E_INVALID;
     if ((s2->ldq2 & 7) || (s2->ldk2 & 7) || (s2->ldv2 & 7) || (s2->ldo2 & 3)) return SDN_E_INVALID;
@@ -505,4 +529,16 @@ extern "C" int sdn_joint_attention(int32_t dtype, const void* q, const void* k, 
                                         stream, seg2);
   return sdn_attn_detail::run<SdnBF16>(q, k, v, out, batch, heads, n_total, n_total, head_dim, ldq, ldk, ldv, ldo, scale,
                                        stream, seg2);
+}
+
+extern "C" int sdn_masked_attention(int32_t dtype, const void* q, const void* k, const void* v, void* out,
+                                    const int32_t* key_mask, int32_t causal, int32_t batch, int32_t heads, int32_t n,
+                                    int32_t head_dim, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo, float scale,
+                                    void* stream) {
+  if (!causal && !key_mask) return SDN_E_INVALID;
+  if (dtype == 1)
+    return sdn_attn_detail::run<SdnF16>(q, k, v, out, batch, heads, n, n, head_dim, ldq, ldk, ldv, ldo, scale, stream, nullptr,
+                                        causal ? 1 : 0, key_mask);
+  return sdn_attn_detail::run<SdnBF16>(q, k, v, out, batch, heads, n, n, head_dim, ldq, ldk, ldv, ldo, scale, stream, nullptr,
+                                       causal ? 1 : 0, key_mask);
 }

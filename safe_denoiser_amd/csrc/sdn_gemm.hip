@@ -73,6 +73,10 @@ __device__ __forceinline__ float gelu_tanh(float v) {                       // G
   return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * u));
 }
 
+__device__ __forceinline__ float quick_gelu(float v) {                      // x * sigmoid(1.702 x), CLIP text encoder
+  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * v));
+}
+
 // byte offset of 16-B chunk c of row r inside a [rows][8 chunks] tile
 __device__ __forceinline__ int lds_off(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
 
@@ -444,7 +448,7 @@ static int sdn_gemm_impl(int dtype, const sdn_gemm_desc* d, const void* a, const
   } else {
     return SDN_E_INVALID;
   }
-  if (d->act < 0 || d->act > 3 || d->out_kind < 0 || d->out_kind > 2) return SDN_E_INVALID;
+  if (d->act < 0 || d->act > 4 || d->out_kind < 0 || d->out_kind > 2) return SDN_E_INVALID;
   if (d->act == SDN_ACT_GEGLU && (d->out_kind != SDN_OUT_BF16 || rowbias || rowgate || residual || n_valid != d->N))
     return SDN_E_INVALID;
   if ((rowbias || rowgate || d->residual_bcast || d->out_kind == SDN_OUT_F32_NCHW) && d->rows_per_batch <= 0) return SDN_E_INVALID;

@@ -37,7 +37,7 @@ enum Space { SP_NONE = 0, SP_W = 1, SP_WS = 2, SP_LATENTS = 3, SP_TEXT = 4, SP_O
 struct Ref { int space = SP_NONE; int64_t off = 0; };
 
 enum OpKind { OP_TEMB, OP_CONV_IN, OP_GEMM, OP_GN, OP_LN, OP_ATTN, OP_PATCHIFY, OP_UNPATCHIFY, OP_LATENT_MIX, OP_SOFTMAX,
-              OP_TRANSPOSE, OP_GAUSS, OP_REPEAT };
+              OP_TRANSPOSE, OP_GAUSS, OP_REPEAT, OP_CLIP_EMBED, OP_MATTN };
 
 struct Op {
   int kind;
@@ -120,6 +120,9 @@ struct sdn_unet {
   bool is_mmdit = false;
   bool is_vae = false;
   bool is_vae_encoder = false;
+  bool is_clip = false;
+  sdn_clip_config ccfg;
+  const void* clip_mask = nullptr;      // key-padding mask of the forward in flight (nullable)
   std::vector<sdn_param_info> params;
   std::map<std::string, int> param_index;
   int64_t weight_bytes = 0;
@@ -935,6 +938,69 @@ struct Builder {
     drop(mom);
     plan->ws_bytes = arena.peak;
   }
+  // =================================================================================================
+  // CLIP text encoder: `self.text_encoder(input_ids, attention_mask)[0]`
+  // (...threshold_time.py:197,225,287,333).  transformers' CLIPTextModel (third party): token + position embeddings,
+  // pre-LN transformer layers with CAUSAL self-attention and a quick-GELU MLP, final LayerNorm.
+  // =================================================================================================
+  Ref stacked_vec(const std::vector<std::string>& names, int n_each) {
+    Ref first; int64_t expect = -1;
+    for (size_t i = 0; i < names.size(); ++i) {
+      Ref r = param(names[i], SDN_P_VEC_F32, n_each, 0);
+      if (i == 0) first = r;
+      else if (r.off != expect) { fprintf(stderr, "libsdn: stacked bias %s is not contiguous\n", names[i].c_str()); abort(); }
+      expect = r.off + (int64_t)n_each * 4;
+    }
+    return first;
+  }
+  void build_clip() {
+    const sdn_clip_config& c = u->ccfg;
+    const int C = c.hidden_size, I = c.intermediate_size, n = c.max_position_embeddings, H = c.num_heads;
+    const int64_t rows = (int64_t)B * n;
+    Ref tok = param("embeddings.token_embedding.weight", SDN_P_MAT, c.vocab_size, C);
+    Ref pos = param("embeddings.position_embedding.weight", SDN_P_MAT, n, C);
+    Act x = act(rows, C, n, 0);
+    { Op o; o.kind = OP_CLIP_EMBED; o.a = Ref{SP_LATENTS, 0}; o.w = tok; o.bias = pos; o.out = R(x); o.rows = rows; o.hw = n; o.c1 = C;
+      o.c2 = c.vocab_size; o.bytes = 6.0 * rows * C; snprintf(o.label, sizeof(o.label), "k_clip_embed"); plan->ops.push_back(o); }
+    char buf[96];
+    for (int l = 0; l < c.num_layers; ++l) {
+      snprintf(buf, sizeof(buf), "encoder.layers.%d", l);
+      const std::string p = buf;
+      Ref l1g = param(p + ".layer_norm1.weight", SDN_P_VEC_F32, C, 0), l1b = param(p + ".layer_norm1.bias", SDN_P_VEC_F32, C, 0);
+      Ref qkvw = stacked({p + ".self_attn.q_proj.weight", p + ".self_attn.k_proj.weight", p + ".self_attn.v_proj.weight"}, C, C);
+      Ref qkvb = stacked_vec({p + ".self_attn.q_proj.bias", p + ".self_attn.k_proj.bias", p + ".self_attn.v_proj.bias"}, C);
+      Ref ow = param(p + ".self_attn.out_proj.weight", SDN_P_MAT, C, C), ob = param(p + ".self_attn.out_proj.bias", SDN_P_VEC_F32, C, 0);
+      Ref l2g = param(p + ".layer_norm2.weight", SDN_P_VEC_F32, C, 0), l2b = param(p + ".layer_norm2.bias", SDN_P_VEC_F32, C, 0);
+      Ref f1w = param(p + ".mlp.fc1.weight", SDN_P_MAT, I, C), f1b = param(p + ".mlp.fc1.bias", SDN_P_VEC_F32, I, 0);
+      Ref f2w = param(p + ".mlp.fc2.weight", SDN_P_MAT, C, I), f2b = param(p + ".mlp.fc2.bias", SDN_P_VEC_F32, C, 0);
+      Act ln = act(rows, C, n, 0);
+      layernorm(x, l1g, l1b, ln);
+      Act qkv = act(rows, 3 * C, n, 0);
+      gemm(rows, 3 * C, C, R(ln), qkvw, qkvb, R(qkv));
+      Act at = act(rows, C, n, 0);
+      { Op o; o.kind = OP_MATTN; o.a = R(qkv); o.k = Ref{SP_WS, qkv.off + (int64_t)C * 2}; o.v = Ref{SP_WS, qkv.off + (int64_t)2 * C * 2};
+        o.out = R(at); o.batch = B; o.heads = H; o.nq = n; o.nk = n; o.hd = C / H; o.ldq = o.ldk = o.ldv = 3 * C; o.ldo = C;
+        o.scale = 1.0f / sqrtf((float)o.hd);
+        o.flops = 4.0 * B * H * (double)n * n * o.hd; o.bytes = 2.0 * 4.0 * rows * C;
+        snprintf(o.label, sizeof(o.label), "k_attn<%d>", o.hd); plan->ops.push_back(o); plan->flops += o.flops; plan->attn_flops += o.flops; }
+      drop(qkv);
+      Act x2 = act(rows, C, n, 0);
+      gemm(rows, C, C, R(at), ow, ob, R(x2), SDN_ACT_NONE, R(x));
+      drop(at); drop(x);
+      layernorm(x2, l2g, l2b, ln);
+      Act h = act(rows, I, n, 0);
+      gemm(rows, I, C, R(ln), f1w, f1b, R(h), SDN_ACT_QUICK_GELU);
+      drop(ln);
+      x = act(rows, C, n, 0);
+      gemm(rows, C, I, R(h), f2w, f2b, R(x), SDN_ACT_NONE, R(x2));
+      drop(h); drop(x2);
+    }
+    Ref fg = param("final_layer_norm.weight", SDN_P_VEC_F32, C, 0), fb = param("final_layer_norm.bias", SDN_P_VEC_F32, C, 0);
+    { Op o; o.kind = OP_LN; o.a = R(x); o.rows = rows; o.c1 = C; o.eps = 1e-5f; o.w = fg; o.bias = fb; o.out = Ref{SP_OUT, 0};
+      o.bytes = 4.0 * rows * C; snprintf(o.label, sizeof(o.label), "k_layernorm"); plan->ops.push_back(o); }
+    drop(x);
+    plan->ws_bytes = arena.peak;
+  }
 };
 
 Plan* get_plan(sdn_unet* u, int batch) {
@@ -944,7 +1010,7 @@ Plan* get_plan(sdn_unet* u, int batch) {
   p.batch = batch;
   Builder b{u, &p};
   b.B = batch;
-  if (u->is_vae_encoder) b.build_vae_encoder(); else if (u->is_vae) b.build_vae(); else if (u->is_mmdit) b.build_mmdit(); else b.build();
+  if (u->is_clip) b.build_clip(); else if (u->is_vae_encoder) b.build_vae_encoder(); else if (u->is_vae) b.build_vae(); else if (u->is_mmdit) b.build_mmdit(); else b.build();
   return &p;
 }
 
@@ -1046,6 +1112,26 @@ int sdn_vae_encoder_create(const sdn_vae_config* cfg, sdn_unet** out) {
   return SDN_OK;
 }
 
+int sdn_clip_create(const sdn_clip_config* cfg, sdn_unet** out) {
+  if (!cfg || !out) return SDN_E_INVALID;
+  if (cfg->vocab_size <= 0 || cfg->hidden_size <= 0 || cfg->hidden_size % 128 != 0 || cfg->hidden_size > 1024 ||
+      cfg->intermediate_size <= 0 || cfg->intermediate_size % 128 != 0 || cfg->num_layers <= 0 || cfg->num_heads <= 0 ||
+      cfg->hidden_size != 64 * cfg->num_heads || cfg->max_position_embeddings <= 0 || cfg->max_position_embeddings > 4096 ||
+      cfg->dtype < 0 || cfg->dtype > 1)
+    return SDN_E_INVALID;
+  sdn_unet* u = new sdn_unet();
+  memset(&u->cfg, 0, sizeof(u->cfg));
+  u->cfg.dtype = cfg->dtype;
+  u->ccfg = *cfg;
+  u->is_clip = true;
+  get_plan(u, 1);
+  *out = u;
+  return SDN_OK;
+}
+
+int sdn_clip_forward(sdn_unet* m, const void* weights, const int32_t* input_ids, const int32_t* attention_mask,
+                     void* last_hidden_state, int32_t batch, void* workspace, size_t workspace_bytes, void* stream);
+
 void sdn_unet_destroy(sdn_unet* u) { delete u; }
 
 int sdn_unet_param_count(const sdn_unet* u) { return u ? (int)u->params.size() : 0; }
@@ -1099,16 +1185,24 @@ int sdn_vae_encode(sdn_unet* v, const void* weights, const float* image, float* 
                   stream);
 }
 
+int sdn_clip_forward(sdn_unet* m, const void* weights, const int32_t* input_ids, const int32_t* attention_mask,
+                     void* last_hidden_state, int32_t batch, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!m || !m->is_clip) return SDN_E_INVALID;
+  m->clip_mask = attention_mask;
+  return run_plan(m, weights, (const float*)input_ids, 0.f, weights /* no text operand */, nullptr, (float*)last_hidden_state,
+                  batch, workspace, workspace_bytes, stream);
+}
+
 int sdn_unet_forward(sdn_unet* u, const void* weights, const float* latents, float timestep, const void* text,
                      float* out, int32_t batch, void* workspace, size_t workspace_bytes, void* stream) {
-  if (!u || u->is_mmdit || u->is_vae) return SDN_E_INVALID;
+  if (!u || u->is_mmdit || u->is_vae || u->is_clip) return SDN_E_INVALID;
   return run_plan(u, weights, latents, timestep, text, nullptr, out, batch, workspace, workspace_bytes, stream);
 }
 
 int sdn_mmdit_forward(sdn_unet* u, const void* weights, const float* latents, float timestep, const void* text,
                       const void* pooled, float* out, int32_t batch, void* workspace, size_t workspace_bytes,
                       void* stream) {
-  if (!u || !u->is_mmdit || u->is_vae || !pooled) return SDN_E_INVALID;
+  if (!u || !u->is_mmdit || u->is_vae || u->is_clip || !pooled) return SDN_E_INVALID;
   return run_plan(u, weights, latents, timestep, text, pooled, out, batch, workspace, workspace_bytes, stream);
 }
 
@@ -1117,7 +1211,7 @@ static int launch_ops(sdn_unet* u, Plan* p, const char* W, const char* WS, const
                       const char* PL, float timestep, const float* t_dev, bool prof, void* stream) {
   auto P = [&](const Ref& r) { return resolve(r, W, WS, L, T, O, PL); };
   size_t opi = 0;
-  const bool f16 = (u->is_mmdit ? u->mcfg.dtype : u->cfg.dtype) == 1;
+  const bool f16 = (u->is_mmdit ? u->mcfg.dtype : u->cfg.dtype) == 1;       // (VAE / CLIP creators mirror dtype into cfg)
   for (const Op& o : p->ops) {
     int rc = SDN_OK;
     if (prof) (void)hipEventRecord(u->ev[2 * opi], (hipStream_t)stream);
@@ -1137,6 +1231,13 @@ static int launch_ops(sdn_unet* u, Plan* p, const char* W, const char* WS, const
       case OP_GN:
         rc = (f16 ? sdn_groupnorm_f16 : sdn_groupnorm_bf16)(P(o.a), P(o.a2), o.batch, o.hw, o.c1, o.c2, o.groups, o.eps, o.silu,
                                 (const float*)P(o.w), (const float*)P(o.bias), (void*)P(o.out), (float*)P(o.aux), stream);
+        break;
+      case OP_CLIP_EMBED:
+        rc = sdn_clip_embed(f16 ? 1 : 0, (const int32_t*)P(o.a), P(o.w), P(o.bias), o.rows, o.hw, o.c1, o.c2, (void*)P(o.out), stream);
+        break;
+      case OP_MATTN:
+        rc = sdn_masked_attention(f16 ? 1 : 0, P(o.a), P(o.k), P(o.v), (void*)P(o.out), (const int32_t*)u->clip_mask, 1, o.batch,
+                                  o.heads, o.nq, o.hd, o.ldq, o.ldk, o.ldv, o.ldo, o.scale, stream);
         break;
       case OP_REPEAT:
         rc = sdn_repeat(P(o.a), (size_t)o.rows, o.c1, (void*)P(o.out), stream);
@@ -1204,7 +1305,7 @@ static int run_plan(sdn_unet* u, const void* weights, const float* latents, floa
     u->profiled_batch = batch;
   }
   hipStream_t hs = (hipStream_t)stream;
-  if (u->use_graph && !prof && !u->is_vae && p->tscalar_off >= 0) {
+  if (u->use_graph && !prof && !u->is_vae && !u->is_clip && p->tscalar_off >= 0) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(hs, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) {
       // Graph mode: small batches are launch-bound (~850 launches per forward); the forward is captured once per

@@ -125,6 +125,22 @@ k_gauss_sample(const float* __restrict__ mom, const float* __restrict__ noise, i
   }
 }
 
+// CLIPTextEmbeddings: out[b, t, :] = token_embedding[ids[b, t]] + position_embedding[t]   (16-bit tables, one rounding)
+template <typename T>
+__global__ void __launch_bounds__(THREADS)
+k_clip_embed(const int* __restrict__ ids, const unsigned short* __restrict__ tok, const unsigned short* __restrict__ pos,
+             long rows, int n, int C, int vocab, unsigned short* __restrict__ out) {
+  const int cch = C / 2;
+  const long total = rows * cch;
+  for (long e = (long)blockIdx.x * THREADS + threadIdx.x; e < total; e += (long)gridDim.x * THREADS) {
+    const long r = e / cch; const int c = (int)(e - r * cch) * 2;
+    int id = ids[r]; id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);       // out-of-range ids are clamped, not faulted on
+    const unsigned a = *reinterpret_cast<const unsigned*>(tok + (long)id * C + c);
+    const unsigned p = *reinterpret_cast<const unsigned*>(pos + (long)(r % n) * C + c);
+    *reinterpret_cast<unsigned*>(out + r * C + c) = T::pack2(T::to_f(a & 0xffff) + T::to_f(p & 0xffff), T::to_f(a >> 16) + T::to_f(p >> 16));
+  }
+}
+
 inline unsigned grid_for(long total) {
   long g = (total + THREADS - 1) / THREADS;
   return (unsigned)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
@@ -183,5 +199,22 @@ extern "C" int sdn_gaussian_sample(const float* moments, const float* noise, int
   if (batch == 0) return SDN_OK;
   hipLaunchKernelGGL(k_gauss_sample, dim3(grid_for((long)batch * latent_channels * hw)), dim3(THREADS), 0, (hipStream_t)stream,
                      moments, noise, batch, latent_channels, hw, scale, out);
+  return sdn_launch_status();
+}
+
+extern "C" int sdn_clip_embed(int32_t dtype, const int32_t* input_ids, const void* token_embedding, const void* position_embedding,
+                              int64_t rows, int32_t seq_len, int32_t hidden, int32_t vocab, void* out, void* stream) {
+  if (!input_ids || !token_embedding || !position_embedding || !out || rows < 0 || seq_len <= 0 || hidden <= 0 || (hidden & 1) ||
+      vocab <= 0 || dtype < 0 || dtype > 1)
+    return SDN_E_INVALID;
+  if (rows == 0) return SDN_OK;
+  if (dtype == 1)
+    hipLaunchKernelGGL((k_clip_embed<SdnF16>), dim3(grid_for(rows * (hidden / 2))), dim3(THREADS), 0, (hipStream_t)stream, input_ids,
+                       (const unsigned short*)token_embedding, (const unsigned short*)position_embedding, (long)rows, seq_len, hidden,
+                       vocab, (unsigned short*)out);
+  else
+    hipLaunchKernelGGL((k_clip_embed<SdnBF16>), dim3(grid_for(rows * (hidden / 2))), dim3(THREADS), 0, (hipStream_t)stream, input_ids,
+                       (const unsigned short*)token_embedding, (const unsigned short*)position_embedding, (long)rows, seq_len, hidden,
+                       vocab, (unsigned short*)out);
   return sdn_launch_status();
 }

@@ -40,11 +40,14 @@ VARIANTS = {
 class SafeDenoiserPipeline:
     GRAPH_MAX_BATCH = 16      # UNet rows (branches x prompts) up to which a forward is launch-bound and replayed as a hipGraph
 
-    def __init__(self, unet, scheduler, variant: str = "threshold_time", vae=None, use_graphs: Optional[bool] = None):
+    def __init__(self, unet, scheduler, variant: str = "threshold_time", vae=None, use_graphs: Optional[bool] = None,
+                 text_encoder=None, tokenizer=None):
         if variant not in VARIANTS:
             raise KeyError(f"unknown variant {variant}; have {sorted(VARIANTS)}")
         self.unet, self.scheduler, self.variant, self.vae = unet, scheduler, variant, vae
         self.use_graphs = use_graphs          # None = automatic: on for small batches (the reference's one-prompt calls)
+        # optional front end: safe_denoiser_amd.clip.CLIPTextModel + the caller's CLIPTokenizer
+        self.text_encoder, self.tokenizer = text_encoder, tokenizer
         self.vae_scale_factor = 8
         self.last_stats = {}
 
@@ -62,8 +65,10 @@ class SafeDenoiserPipeline:
                  return_latents: bool = True, noise_fn: Optional[Callable] = None, output_type: str = "pil", **kwargs):
         _lib.require_gpu()
         if prompt_embeddings is None:
-            raise NotImplementedError("the CLIP text encoder is outside the hot path (SURVEY.md section 8f row 4): pass "
-                                      "`prompt_embeddings` ([2P,77,768]) instead of `prompt` strings")
+            if prompt is None or self.text_encoder is None or self.tokenizer is None:
+                raise NotImplementedError("pass `prompt_embeddings` ([2P,77,768]), or construct the pipeline with text_encoder= "
+                                          "(safe_denoiser_amd.clip.CLIPTextModel) and tokenizer= and pass `prompt` strings")
+            prompt_embeddings = self.encode_prompt(prompt, kwargs.get("negative_prompt"))
         if not return_latents:
             if self.vae is None:
                 raise NotImplementedError("no VAE decoder attached: construct the pipeline with vae=AutoencoderKL(...) or "
@@ -201,6 +206,23 @@ class SafeDenoiserPipeline:
         if return_latents:
             return lat
         return self.decode_latents(lat, output_type)
+
+    def encode_prompt(self, prompt, negative_prompt=None) -> torch.Tensor:
+        """_encode_prompt of the reference (...threshold_time.py:262-349) without the SAFREE token masking: tokenise with
+        padding="max_length" / truncation, encode, and stack [unconditional | text] rows for classifier-free guidance."""
+        prompts = [prompt] if isinstance(prompt, str) else list(prompt)
+        neg = [""] * len(prompts) if negative_prompt is None else (
+            [negative_prompt] * len(prompts) if isinstance(negative_prompt, str) else list(negative_prompt))
+        if len(neg) != len(prompts):
+            raise _lib.SdnError("negative_prompt must match the number of prompts")
+        n = self.text_encoder.config.max_position_embeddings
+        dev = torch.device("cuda", torch.cuda.current_device())
+
+        def ids_of(texts):
+            t = self.tokenizer(texts, padding="max_length", max_length=n, truncation=True, return_tensors="pt")
+            return (t.input_ids if hasattr(t, "input_ids") else t["input_ids"]).to(dev)
+
+        return torch.cat([self.text_encoder(ids_of(neg))[0], self.text_encoder(ids_of(prompts))[0]])
 
     def decode_latents(self, latents: torch.Tensor, output_type: str = "np"):
         """Steps 8-10 of the reference's __call__ (...threshold_time.py:588-596)."""
