@@ -1,0 +1,81 @@
+"""Prompt-table dialects of the reference's drivers (the data format on the input side of the loop).
+
+`read_cases` turns a CSV / DataFrame into the per-prompt records the drivers build inline:
+run_nudity.py:373-408 (`valid_case_numbers` slicing; `adv_prompt` (MMA-diffusion), `sensitive prompt` (concept removal),
+`prompt` + `case_number` (i2p / RECE tables); `guidance` column or the CLI default; `evaluation_seed` else `sd_seed` else
+42; `categories` split on ", " else "nudity"; rows whose prompt is not a string or whose seed is not an int are skipped,
+:411-413) and run_copro.py:436-448 (`unsafe_prompt` + `idx`).  `batches` groups them for the batched engine loop: prompts
+of one batch share the guidance scale (it is a scalar of sdn_cfg_combine) and each keeps its own seed -> generator.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional
+
+_PROMPT_COLUMNS = (("adv_prompt", None), ("sensitive prompt", None), ("prompt", "case_number"), ("unsafe_prompt", "idx"))
+
+
+def _is_int(v) -> bool:
+    import numbers
+    return isinstance(v, numbers.Integral) and not isinstance(v, bool)
+
+
+def read_cases(table, valid_case_numbers: str = "0,100000", default_guidance: float = 7.5) -> List[dict]:
+    """`table`: path to a CSV or a pandas DataFrame.  Returns [{prompt, case_number, seed, guidance, categories, row}]."""
+    import pandas as pd
+    df = pd.read_csv(table) if isinstance(table, (str, bytes)) or hasattr(table, "__fspath__") else table
+    vstart, vend = (int(x) for x in valid_case_numbers.split(","))
+    df = df[vstart:][:vend]                                        # the reference's two-step slice (:373-375)
+    out = []
+    for it, data in df.iterrows():
+        prompt = case = None
+        for col, case_col in _PROMPT_COLUMNS:
+            if col in data:
+                prompt = data[col]
+                case = it if case_col is None else data[case_col]
+                break
+        if prompt is None:
+            continue
+        guidance = data["guidance"] if "guidance" in data else default_guidance
+        if "evaluation_seed" in data:
+            seed = data["evaluation_seed"]
+        elif "sd_seed" in data:
+            seed = data["sd_seed"]
+        else:
+            seed = 42
+        cats = data["categories"].split(", ") if "categories" in data and isinstance(data["categories"], str) else "nudity"
+        if hasattr(seed, "item"):
+            seed = seed.item()
+        if hasattr(guidance, "item"):
+            guidance = guidance.item()
+        if hasattr(case, "item"):
+            case = case.item()
+        if not isinstance(prompt, str) or not _is_int(seed) or not isinstance(guidance, (int, float)):
+            continue                                               # "check if data is broken" (:411-413)
+        out.append(dict(prompt=prompt, case_number=case, seed=int(seed), guidance=float(guidance), categories=cats, row=it))
+    return out
+
+
+def image_name(case: dict) -> str:
+    """File name of the drivers' outputs: `{case_num}_{'-'.join(categories)}.png` (run_nudity.py:485-504)."""
+    cats = case["categories"]
+    return f"{case['case_number']}_{'-'.join(cats)}.png"           # a plain string joins its characters, as the reference does
+
+
+def batches(cases: Iterable[dict], prompts_per_batch: int, rank: int = 0, world: int = 1) -> List[List[dict]]:
+    """This rank's cases (`rank::world`, as dist.shard_indices) cut into batches of at most `prompts_per_batch` prompts that
+    share one guidance scale; order inside a guidance group follows the table."""
+    mine = list(cases)[rank::world]
+    groups: dict = {}
+    for c in mine:
+        groups.setdefault(c["guidance"], []).append(c)
+    out = []
+    for g in groups.values():
+        for i in range(0, len(g), prompts_per_batch):
+            out.append(g[i:i + prompts_per_batch])
+    return out
+
+
+def generators(batch: List[dict], device="cuda"):
+    """One torch.Generator per prompt, seeded like `gen.manual_seed(seed)` (run_nudity.py:448)."""
+    import torch
+    return [torch.Generator(device=device).manual_seed(c["seed"]) for c in batch]
