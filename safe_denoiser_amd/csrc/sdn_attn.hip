@@ -79,7 +79,7 @@ __device__ __forceinline__ const unsigned short* row_ptr(const unsigned short* p
 
 // MASK (CLIP text encoder): causal mask (key <= query) and an optional per-sample key-padding mask; a separate
 // instantiation so that the UNet / MMDiT kernels carry no trace of it.
-template <typename T, int HD, bool SEG, bool MASK = false>
+template <typename T, int HD, bool SEG, bool MASK = false, bool DMA = !SEG>
 __global__ void __launch_bounds__(THREADS)
 k_attn(const AttnArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -92,8 +92,8 @@ k_attn(const AttnArgs a) {
   // piece per wave-instruction): no staging registers, no ds_write pass.  A DMA piece cannot skip bytes, so the tiles
   // hold ONLY the HD data columns; the zero padding of the head dim and the ones column live once in a 32-byte static
   // block that the padding lanes of the fragment reads point at instead (their contents do not depend on the key).
-  // Two-segment inputs (SEG, MMDiT) keep register staging: the two streams have different base pointers.
-  constexpr bool DMA = !SEG;
+  // Two-segment inputs (SEG, MMDiT): the streams have different base pointers, so DMA needs every 64-key tile to lie in
+  // ONE stream (n1 % 64 == 0) and both streams to share the row strides; otherwise the register-staged path runs.
 #ifndef SDN_ATTN_VCH40
 #define SDN_ATTN_VCH40 5
 #endif
@@ -216,7 +216,6 @@ k_attn(const AttnArgs a) {
   // bank-pad chunks (offset 2^31) fail the range check and are written as zeros.
   constexpr int NPIECE = (KCH + VCH + 3) / 4;                  // pieces per wave per tile (4 waves)
   unsigned dma_off[NPIECE];
-  const long kv_bytes_k = ((long)(a.nk - 1) * a.ldk + a.heads * HD) * 2, kv_bytes_v = ((long)(a.nk - 1) * a.ldv + a.heads * HD) * 2;
   if constexpr (DMA) {
 #pragma unroll
     for (int i = 0; i < NPIECE; ++i) {
@@ -230,9 +229,17 @@ k_attn(const AttnArgs a) {
   }
   auto dma_issue = [&](int buf, int t) {
     const long k0 = (long)t * KV;
-    const unsigned short* kb_ = a.k + ((long)b * a.nk + k0) * a.ldk;
-    const unsigned short* vb_ = a.v + ((long)b * a.nk + k0) * a.ldv;
-    const long rk = kv_bytes_k - k0 * a.ldk * 2, rv = kv_bytes_v - k0 * a.ldv * 2;
+    const unsigned short *kb_, *vb_;
+    long rk, rv;
+    if (SEG && k0 >= a.n1) {                      // tile inside the second stream (host guarantees n1 % KV == 0, equal strides)
+      const long kk = k0 - a.n1, n2 = a.nk - a.n1;
+      kb_ = a.k2 + ((long)b * n2 + kk) * a.ldk2; vb_ = a.v2 + ((long)b * n2 + kk) * a.ldv2;
+      rk = ((n2 - kk - 1) * a.ldk2 + a.heads * HD) * 2; rv = ((n2 - kk - 1) * a.ldv2 + a.heads * HD) * 2;
+    } else {
+      const long n1 = SEG ? a.n1 : a.nk;
+      kb_ = a.k + ((long)b * n1 + k0) * a.ldk; vb_ = a.v + ((long)b * n1 + k0) * a.ldv;
+      rk = ((n1 - k0 - 1) * a.ldk + a.heads * HD) * 2; rv = ((n1 - k0 - 1) * a.ldv + a.heads * HD) * 2;
+    }
     const __amdgpu_buffer_rsrc_t rs_k = make_rsrc(kb_, (unsigned)(rk > 0 ? rk : 0));
     const __amdgpu_buffer_rsrc_t rs_v = make_rsrc(vb_, (unsigned)(rv > 0 ? rv : 0));
 #pragma unroll
@@ -464,8 +471,17 @@ int launch(const AttnArgs& a, int batch, int heads, hipStream_t st) {
       return SDN_E_INVALID;                     // masked attention is instantiated for d = 64 (CLIP) only
     }
   }
-  if (a.q2) hipLaunchKernelGGL((k_attn<T, HD, true>), dim3(a.nqb * a.npairs), dim3(THREADS), 0, st, a);
-  else hipLaunchKernelGGL((k_attn<T, HD, false>), dim3(a.nqb * a.npairs), dim3(THREADS), 0, st, a);
+  if (a.q2) {
+    if constexpr (HD == 64) {                     // MMDiT head dim: LDS-DMA variant when no tile straddles the two streams
+      if (a.n1 % KV == 0 && a.ldk == a.ldk2 && a.ldv == a.ldv2) {
+        hipLaunchKernelGGL((k_attn<T, HD, true, false, true>), dim3(a.nqb * a.npairs), dim3(THREADS), 0, st, a);
+        return sdn_launch_status();
+      }
+    }
+    hipLaunchKernelGGL((k_attn<T, HD, true>), dim3(a.nqb * a.npairs), dim3(THREADS), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((k_attn<T, HD, false>), dim3(a.nqb * a.npairs), dim3(THREADS), 0, st, a);
+  }
   return sdn_launch_status();
 }
 
