@@ -403,7 +403,7 @@ int sdn_gemm_pick_tile(int M, int N, int K, int act) {
     const int big = (N % 320 == 0) ? 10 : ((N % 256 == 0) ? 8 : 0);
     // ... and only for long k loops: with one block per CU nothing hides a tile's prologue/epilogue, so short-K
     // projections (K = 320 .. 1280) stay on the 2-blocks-per-CU tile (measured: tools/bench_gemm.py, VARIANTS=0,3)
-    const bool long_k = K >= 2048 || (K >= 1280 && act == SDN_ACT_GEGLU) || (K >= 1536 && act == SDN_ACT_NONE);
+    const bool long_k = K >= 2048 || (K >= 1280 && act == SDN_ACT_GEGLU) || (K >= 1536 && (act == SDN_ACT_NONE || act == SDN_ACT_GELU_TANH));
     if (big && long_k) {
       const long tiles = (long)((M + 255) / 256) * (N / (32 * big));
       if (tiles >= 192) return big;
