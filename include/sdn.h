@@ -195,6 +195,7 @@ typedef struct sdn_gemm_desc {
   int32_t ldc;              /* leading dimension of out/residual (0 = natural)                 */
   int32_t asym_pad;         /* CONV3X3, stride 2 only: 1 = zero padding (0,1,0,1) (right/bottom only: the VAE encoder's
                                Downsample2D(padding=0) + F.pad) instead of 1 on every side             */
+  int32_t split_k;          /* number of k-loop slices for sdn_gemm_splitk_* (0 / 1 = none); plain sdn_gemm_* rejects > 1 */
 } sdn_gemm_desc;
 
 /* out = act((A.W^T + bias[n] + rowbias[b(m), n]) * rowgate[b(m), n] + residual[m, n])   (rowgate NULL = 1).
@@ -353,6 +354,16 @@ int sdn_mmdit_forward(sdn_unet* m, const void* weights, const float* latents, fl
                       const void* pooled, float* out, int32_t batch, void* workspace, size_t workspace_bytes,
                       void* stream);
 
+/* Split-K form for small M / long K (one-prompt batches: 8-20 tiles for 256 CUs): the k loop is cut into desc->split_k
+ * slices, each writes an fp32 partial [M, N] into `partials` (>= split_k * M * N * 4 bytes), and a second kernel sums
+ * them in a fixed order and applies the epilogue.  16-bit outputs, any activation but GEGLU, n_valid == N. */
+int sdn_gemm_splitk_bf16(const sdn_gemm_desc* d, const void* a, const void* a2, const void* w, const float* bias,
+                         const float* rowbias, const float* rowgate, const void* residual, void* out, void* partials,
+                         size_t partial_bytes, void* stream);
+int sdn_gemm_splitk_f16(const sdn_gemm_desc* d, const void* a, const void* a2, const void* w, const float* bias,
+                        const float* rowbias, const float* rowgate, const void* residual, void* out, void* partials,
+                        size_t partial_bytes, void* stream);
+
 /* out[k * bytes + i] = in[i], k < rep (device-side `torch.cat([x] * rep)`; bytes % 16 == 0) */
 int sdn_repeat(const void* in, size_t bytes, int32_t rep, void* out, void* stream);
 
@@ -433,6 +444,11 @@ int sdn_masked_attention(int32_t dtype, const void* q, const void* k, const void
  * of the timestep.  Results are identical.  Off by default; a forward issued while the caller's stream is itself being
  * captured, or a profiled forward, always launches op by op.  Keeps up to 16 instantiated graphs per handle. */
 void sdn_unet_set_graph_mode(sdn_unet* u, int32_t on);
+/* Small-batch option: GEMMs of the plan whose tile grid would leave most CUs idle (M <= ~2048 with a long k loop: the
+ * 8x8 / 16x16-level convs of a one-prompt batch) run as sdn_gemm_splitk_*.  Off by default because the fp32 summation
+ * order then depends on the batch size (without it a sample's output is bit-identical at every batch size).  Changing it
+ * rebuilds the plans: query sdn_unet_workspace_bytes again. */
+void sdn_unet_set_split_k(sdn_unet* u, int32_t on);
 
 /* ---- opt-in measurement: HIP events around every launch of ONE forward, on the forward's own stream ---- */
 typedef struct sdn_profile_row {

@@ -35,7 +35,7 @@ class RepelParams(C.Structure):
 class GemmDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("M", "N", "K", "a_mode", "K1", "Hs", "Ws", "Cin", "Ho", "Wo", "stride",
                                          "upsample", "act", "out_kind", "rows_per_batch", "ld_rowbias", "ld_rowgate",
-                                         "residual_bcast", "n_valid", "ldc", "asym_pad")]
+                                         "residual_bcast", "n_valid", "ldc", "asym_pad", "split_k")]
 
 
 class UnetConfig(C.Structure):
@@ -97,6 +97,8 @@ SIGNATURES = {
     "sdn_flow_renoise": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp, _vp]),
     "sdn_gemm_bf16": (C.c_int, [C.POINTER(GemmDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sdn_gemm_f16": (C.c_int, [C.POINTER(GemmDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sdn_gemm_splitk_bf16": (C.c_int, [C.POINTER(GemmDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sdn_gemm_splitk_f16": (C.c_int, [C.POINTER(GemmDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sdn_groupnorm_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "sdn_groupnorm_f16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "sdn_layernorm_f16": (C.c_int, [_vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp]),
@@ -142,6 +144,7 @@ SIGNATURES = {
     "sdn_masked_attention": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                        _f32, _vp]),
     "sdn_unet_set_graph_mode": (None, [_vp, _i32]),
+    "sdn_unet_set_split_k": (None, [_vp, _i32]),
     "sdn_unet_profile_next": (None, [_vp]),
     "sdn_unet_profile_read": (C.c_int, [_vp, C.POINTER(ProfileRow), _i32]),
 }

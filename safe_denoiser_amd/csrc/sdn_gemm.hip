@@ -40,6 +40,8 @@ struct GemmArgs {
   int a_mode, Hs, Ws, Cin, Ho, Wo, stride, upsample, conv_off;
   int act, out_kind, rows_per_batch, ld_rowbias, ld_rowgate, residual_bcast, n_valid, ldc;
   int tiles_m, tiles_n;
+  int kt_per_split;          // split-K: k-tiles per blockIdx.y slice (0 = no split); each slice writes its own fp32 partial
+  long split_stride;         // bytes between the partial outputs of consecutive slices
   int res_lds;               // residual goes through the LDS staging slab (16-bit staged output, offsets fit 31 bits)
   unsigned res_bytes;        // buffer size of the residual for the DMA's bounds check
   unsigned long long* stamps; // diagnostics: 8 s_memtime stamp slots per workgroup (tools/gemm_stamps.py); nullptr in production
@@ -188,7 +190,9 @@ k_gemm_dma(const GemmArgs g) {
   const __amdgpu_buffer_rsrc_t rs_a2 = make_rsrc(g.a2 ? g.a2 : g.a, (unsigned)(g.a2 ? a_rows * ld2 * 2 : 0));
 
   // k-tile cursor (issue() is always called for consecutive k-tiles)
-  int cur_k0 = 0, cur_c0 = 0, cur_ty = 0, cur_tx = 0, w_k0 = 0;
+  // split-K: this workgroup's slice of the k loop starts at k-tile kt0 (k order of a conv = channel chunk outer, tap inner)
+  const int kt0 = g.kt_per_split > 0 ? (int)blockIdx.y * g.kt_per_split : 0;
+  int cur_k0 = kt0 * BK, cur_c0 = (kt0 / 9) * BK, cur_ty = (kt0 % 9) / 3, cur_tx = kt0 % 3, w_k0 = 0;
   auto issue = [&](int buf) {
     unsigned char* sa = smem + buf * STAGE;
     unsigned char* sw = sa + BM * 128;
@@ -267,7 +271,7 @@ k_gemm_dma(const GemmArgs g) {
     }
   }
 
-  const int nk = g.K / BK;
+  const int nk = g.kt_per_split > 0 ? min(g.kt_per_split, g.K / BK - kt0) : g.K / BK;
   if constexpr (NSTAGE == 2) {
     issue(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -352,10 +356,63 @@ k_gemm_dma(const GemmArgs g) {
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
+
+// ---- split-K (small M, long K: the 8x8 / 16x16-level convs of a one-prompt batch have 8-20 tiles for 256 CUs and a
+// 180..360-tile k loop each).  The k loop is cut into slices (grid.y); every slice writes its fp32 partial tile and this
+// kernel sums them in a fixed order (deterministic) and applies the epilogue the unsplit kernel would have applied.
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_splitk_reduce(const float* __restrict__ part, int splits, long slice, int M, int N, const float* __restrict__ bias,
+                const float* __restrict__ rowbias, int ld_rowbias, const float* __restrict__ rowgate, int ld_rowgate,
+                int rows_per_batch, const unsigned short* __restrict__ residual, int residual_bcast, int ldc, int act,
+                unsigned short* __restrict__ out) {
+  const int nq = N / 4;
+  const long total = (long)M * nq;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int m = (int)(e / nq), n = (int)(e - (long)m * nq) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(part + (long)m * N + n);
+    for (int s = 1; s < splits; ++s) v += *reinterpret_cast<const f32x4*>(part + (long)s * slice + (long)m * N + n);
+    if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
+    const int b = rows_per_batch > 0 ? m / rows_per_batch : 0;
+    if (rowbias) v += *reinterpret_cast<const f32x4*>(rowbias + (long)b * ld_rowbias + n);
+    if (rowgate) v *= *reinterpret_cast<const f32x4*>(rowgate + (long)b * ld_rowgate + n);
+    if (residual) {
+      const long rrow = residual_bcast ? (long)(m - b * rows_per_batch) : (long)m;
+      const uint2 rr = *reinterpret_cast<const uint2*>(residual + rrow * ldc + n);
+      v[0] += T::to_f(rr.x & 0xffff); v[1] += T::to_f(rr.x >> 16); v[2] += T::to_f(rr.y & 0xffff); v[3] += T::to_f(rr.y >> 16);
+    }
+    if (act == 1) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+    if (act == 3) { v[0] = gelu_tanh(v[0]); v[1] = gelu_tanh(v[1]); v[2] = gelu_tanh(v[2]); v[3] = gelu_tanh(v[3]); }
+    if (act == 4) { v[0] = quick_gelu(v[0]); v[1] = quick_gelu(v[1]); v[2] = quick_gelu(v[2]); v[3] = quick_gelu(v[3]); }
+    uint2 pk; pk.x = T::pack2(v[0], v[1]); pk.y = T::pack2(v[2], v[3]);
+    *reinterpret_cast<uint2*>(out + (long)m * ldc + n) = pk;
+  }
+}
+
+}  // namespace sdn_gemm_detail
+
+// Slices worth cutting the k loop into (1 = do not split): only when the tile grid leaves most CUs idle and the k loop
+// is long enough for a slice to amortise its prologue; the plan builder sizes the partial buffer from this.
+int sdn_gemm_pick_split(int M, int N, int K, int act, int out_kind) {
+  if (out_kind != SDN_OUT_BF16 || act == SDN_ACT_GEGLU || (N & 3)) return 1;
+  const int nrep = sdn_gemm_pick_tile(M, N, K, act);
+  const int bm = nrep >= 8 ? 256 : 128;
+  const long tiles = (long)((M + bm - 1) / bm) * (N / (32 * nrep));
+  const int nk = K / 64;
+  if (tiles >= 96 || nk < 16) return 1;
+  int s = (int)(256 / tiles);
+  if (s > nk / 8) s = nk / 8;
+  if (s > 16) s = 16;
+  return s < 2 ? 1 : s;
+}
+
+namespace sdn_gemm_detail {
+
 template <typename T, int NREP, int WGM, int NSTAGE = 2>
 int launch_dma(const GemmArgs& ga, hipStream_t st) {
   const int grid = ga.tiles_m * ga.tiles_n;
-  hipLaunchKernelGGL((k_gemm_dma<T, NREP, WGM, NSTAGE>), dim3(grid), dim3(128 * WGM), 0, st, ga);
+  const int splits = ga.kt_per_split > 0 ? (ga.K / BK + ga.kt_per_split - 1) / ga.kt_per_split : 1;
+  hipLaunchKernelGGL((k_gemm_dma<T, NREP, WGM, NSTAGE>), dim3(grid, splits), dim3(128 * WGM), 0, st, ga);
   return sdn_launch_status();
 }
 
@@ -366,7 +423,7 @@ int dispatch_dma(int nrep, const GemmArgs& g, hipStream_t st) {
     case 8: return launch_dma<T, 8, 4>(g, st);
     case 5:
       // at most one workgroup per CU and a long k loop: the deep ring (see NSTAGE) instead of a second resident workgroup
-      if (g.tiles_m * g.tiles_n <= 256 && g.K >= 8 * BK && g_gemm_variant != 5) return launch_dma<T, 5, 2, 4>(g, st);
+      if (g.tiles_m * g.tiles_n <= 256 && g.K >= 8 * BK && g.kt_per_split == 0 && g_gemm_variant != 5) return launch_dma<T, 5, 2, 4>(g, st);
       return launch_dma<T, 5, 2>(g, st);
     case 4: return launch_dma<T, 4, 2>(g, st);
     case 2: return launch_dma<T, 2, 2>(g, st);
@@ -416,7 +473,7 @@ int sdn_gemm_pick_tile(int M, int N, int K, int act) {
 
 static int sdn_gemm_impl(int dtype, const sdn_gemm_desc* d, const void* a, const void* a2, const void* w,
                          const float* bias, const float* rowbias, const float* rowgate, const void* residual, void* out,
-                         void* stream) {
+                         void* stream, void* partials = nullptr, size_t partial_bytes = 0) {
   if (!d || !a || !w || !out) return SDN_E_INVALID;
   if (d->M < 0 || d->N <= 0 || d->K <= 0 || (d->K % BK) != 0) return SDN_E_INVALID;
   if (d->M == 0) return SDN_OK;
@@ -474,6 +531,34 @@ static int sdn_gemm_impl(int dtype, const sdn_gemm_desc* d, const void* a, const
   const long a_rows = d->a_mode == SDN_A_CONV3X3 ? (long)(d->M / (d->Ho * d->Wo)) * d->Hs * d->Ws : (long)d->M;
   if (a_rows * (long)(d->a_mode == SDN_A_CONV3X3 ? d->Cin : d->K) * 2 >= (1L << 31) || (long)d->N * d->K * 2 >= (1L << 31))
     return SDN_E_INVALID;
+  if (d->split_k > 1) {
+    // split-K: fp32 partials per k slice, then one deterministic reduce + epilogue pass
+    const int nk = d->K / BK;
+    if (!partials || d->out_kind != SDN_OUT_BF16 || d->act == SDN_ACT_GEGLU || n_valid != d->N || (d->N & 3) || d->split_k > nk ||
+        (reinterpret_cast<uintptr_t>(partials) & 15))
+      return SDN_E_INVALID;
+    const int per = (nk + d->split_k - 1) / d->split_k, splits = (nk + per - 1) / per;
+    const long slice = (long)d->M * d->N;
+    if (partial_bytes < (size_t)splits * slice * 4) return SDN_E_WORKSPACE;
+    GemmArgs gp = g;
+    gp.bias = nullptr; gp.rowbias = nullptr; gp.rowgate = nullptr; gp.residual = nullptr; gp.res_lds = 0; gp.res_bytes = 0;
+    gp.act = 0; gp.out_kind = SDN_OUT_F32; gp.out = partials; gp.ldc = d->N; gp.n_valid = d->N;
+    gp.kt_per_split = per; gp.split_stride = slice * 4;
+    const int rc = dtype == 0 ? dispatch_dma<SdnBF16>(nrep, gp, st) : dispatch_dma<SdnF16>(nrep, gp, st);
+    if (rc != SDN_OK) return rc;
+    const long total = slice / 4;
+    long grid = (total + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    if (dtype == 0)
+      hipLaunchKernelGGL((k_splitk_reduce<SdnBF16>), dim3((unsigned)grid), dim3(256), 0, st, (const float*)partials, splits, slice,
+                         d->M, d->N, bias, rowbias, d->ld_rowbias, rowgate, d->ld_rowgate, d->rows_per_batch,
+                         (const unsigned short*)residual, d->residual_bcast, g.ldc, d->act, (unsigned short*)out);
+    else
+      hipLaunchKernelGGL((k_splitk_reduce<SdnF16>), dim3((unsigned)grid), dim3(256), 0, st, (const float*)partials, splits, slice,
+                         d->M, d->N, bias, rowbias, d->ld_rowbias, rowgate, d->ld_rowgate, d->rows_per_batch,
+                         (const unsigned short*)residual, d->residual_bcast, g.ldc, d->act, (unsigned short*)out);
+    return sdn_launch_status();
+  }
   return dtype == 0 ? dispatch_dma<SdnBF16>(nrep, g, st) : dispatch_dma<SdnF16>(nrep, g, st);
 }
 
@@ -484,4 +569,15 @@ extern "C" int sdn_gemm_bf16(const sdn_gemm_desc* d, const void* a, const void* 
 extern "C" int sdn_gemm_f16(const sdn_gemm_desc* d, const void* a, const void* a2, const void* w, const float* bias,
                             const float* rowbias, const float* rowgate, const void* residual, void* out, void* stream) {
   return sdn_gemm_impl(1, d, a, a2, w, bias, rowbias, rowgate, residual, out, stream);
+}
+
+extern "C" int sdn_gemm_splitk_bf16(const sdn_gemm_desc* d, const void* a, const void* a2, const void* w, const float* bias,
+                                    const float* rowbias, const float* rowgate, const void* residual, void* out, void* partials,
+                                    size_t partial_bytes, void* stream) {
+  return sdn_gemm_impl(0, d, a, a2, w, bias, rowbias, rowgate, residual, out, stream, partials, partial_bytes);
+}
+extern "C" int sdn_gemm_splitk_f16(const sdn_gemm_desc* d, const void* a, const void* a2, const void* w, const float* bias,
+                                   const float* rowbias, const float* rowgate, const void* residual, void* out, void* partials,
+                                   size_t partial_bytes, void* stream) {
+  return sdn_gemm_impl(1, d, a, a2, w, bias, rowbias, rowgate, residual, out, stream, partials, partial_bytes);
 }

@@ -9,3 +9,6 @@ int sdn_gemm_pick_tile(int M, int N, int K, int act);
 // graph mode of the plan runner: the step's timestep lives in device memory so that a captured forward can be replayed
 int sdn_temb_from_device(int dtype, const float* t_dev, int batch, int dim, void* out, void* stream);
 int sdn_set_scalar(float* dst, float v, void* stream);
+
+// k-loop slices the split-K form should use for this shape (1 = do not split)
+int sdn_gemm_pick_split(int M, int N, int K, int act, int out_kind);

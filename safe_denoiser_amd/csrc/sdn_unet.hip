@@ -134,6 +134,9 @@ struct sdn_unet {
   bool profile_next = false;
   // graph mode (sdn_unet_set_graph_mode): one captured hipGraph per (batch, operand addresses); replays cost one launch
   bool use_graph = false;
+  bool split_k = false;                 // sdn_unet_set_split_k: small-M GEMMs of the plan take the split-K form (off by
+                                        // default: it changes fp32 summation order with the batch size, and batch rows are
+                                        // otherwise bit-identical whatever the batch)
   struct GraphKey {
     int batch; const void *w, *lat, *text, *pooled, *out, *ws;
     bool operator<(const GraphKey& o) const {
@@ -209,6 +212,20 @@ struct Builder {
     o.flops = 2.0 * (double)M * (double)(n_valid > 0 ? n_valid : N) * (double)K;
     o.bytes = 2.0 * ((double)M * K + (double)N * K + (double)M * (act_ == SDN_ACT_GEGLU ? N / 2 : N));
     snprintf(o.label, sizeof(o.label), "k_gemm<%d>", sdn_gemm_pick_tile((int)M, N, K, act_));
+    push_gemm(o);
+  }
+  // Small-M / long-K GEMMs (one-prompt batches) run in split-K form: the partial buffer lives only for this op.
+  void push_gemm(Op& o) {
+    const int nv = o.gd.n_valid > 0 ? o.gd.n_valid : o.gd.N;
+    const int split = (!u->split_k || nv != o.gd.N) ? 1 : sdn_gemm_pick_split(o.gd.M, o.gd.N, o.gd.K, o.gd.act, o.gd.out_kind);
+    if (split > 1) {
+      const int64_t bytes = (int64_t)split * o.gd.M * o.gd.N * 4;
+      const int64_t off = arena.alloc(bytes);
+      o.gd.split_k = split; o.aux = Ref{SP_WS, off}; o.rows = bytes;
+      arena.release(off, bytes);                              // stream order: the next op may reuse it
+      const size_t L = strlen(o.label);
+      if (L + 3 < sizeof(o.label)) snprintf(o.label + L, sizeof(o.label) - L, "/s%d", split);
+    }
     plan->ops.push_back(o);
     plan->flops += o.flops;
   }
@@ -225,8 +242,7 @@ struct Builder {
     o.flops = 2.0 * (double)o.gd.M * (double)cout * (double)o.gd.K;
     o.bytes = 2.0 * ((double)B * in.side * in.side * in.C + (double)n_pad * o.gd.K + (double)o.gd.M * cout);
     snprintf(o.label, sizeof(o.label), "k_gemm<%d>", sdn_gemm_pick_tile(o.gd.M, n_pad, o.gd.K, SDN_ACT_NONE));
-    plan->ops.push_back(o);
-    plan->flops += o.flops;
+    push_gemm(o);
   }
   void groupnorm(const Act& x, const Act* x2, float eps, int silu, Ref gamma, Ref beta, const Act& out) {
     Op o; o.kind = OP_GN; o.a = R(x); if (x2) o.a2 = R(*x2);
@@ -403,8 +419,7 @@ struct Builder {
     o.flops = 2.0 * (double)M * N * K;
     o.bytes = 2.0 * ((double)M * K + (double)N * K + (double)M * N);
     snprintf(o.label, sizeof(o.label), "k_gemm<%d>", sdn_gemm_pick_tile((int)M, N, K, act_));
-    plan->ops.push_back(o);
-    plan->flops += o.flops;
+    push_gemm(o);
   }
   void ln_mod(const Act& x, int64_t rows, int rows_per_batch, Ref scale, Ref shift, int ld, const Act& out) {
     Op o; o.kind = OP_LN; o.a = R(x); o.rows = rows; o.c1 = x.C; o.eps = 1e-6f; o.w = scale; o.bias = shift; o.out = R(out);
@@ -1225,6 +1240,12 @@ static int launch_ops(sdn_unet* u, Plan* p, const char* W, const char* WS, const
                               (void*)P(o.out), stream);
         break;
       case OP_GEMM:
+        if (o.gd.split_k > 1) {
+          rc = (f16 ? sdn_gemm_splitk_f16 : sdn_gemm_splitk_bf16)(&o.gd, P(o.a), P(o.a2), P(o.w), (const float*)P(o.bias),
+                                                                  (const float*)P(o.rowbias), (const float*)P(o.rowgate), P(o.residual),
+                                                                  (void*)P(o.out), (void*)P(o.aux), (size_t)o.rows, stream);
+          break;
+        }
         rc = (f16 ? sdn_gemm_f16 : sdn_gemm_bf16)(&o.gd, P(o.a), P(o.a2), P(o.w), (const float*)P(o.bias), (const float*)P(o.rowbias),
                            (const float*)P(o.rowgate), P(o.residual), (void*)P(o.out), stream);
         break;
@@ -1340,6 +1361,14 @@ static int run_plan(sdn_unet* u, const void* weights, const float* latents, floa
 }
 
 void sdn_unet_profile_next(sdn_unet* u) { if (u) u->profile_next = true; }
+
+void sdn_unet_set_split_k(sdn_unet* u, int32_t on) {
+  if (!u || u->split_k == (on != 0)) return;
+  u->split_k = on != 0;
+  u->plans.clear();                                            // plans are rebuilt with / without partial buffers
+  for (auto& kv : u->graphs) (void)hipGraphExecDestroy(kv.second);
+  u->graphs.clear();
+}
 
 void sdn_unet_set_graph_mode(sdn_unet* u, int32_t on) {
   if (!u) return;

@@ -41,13 +41,16 @@ class SafeDenoiserPipeline:
     GRAPH_MAX_BATCH = 16      # UNet rows (branches x prompts) up to which a forward is launch-bound and replayed as a hipGraph
 
     def __init__(self, unet, scheduler, variant: str = "threshold_time", vae=None, use_graphs: Optional[bool] = None,
-                 text_encoder=None, tokenizer=None):
+                 text_encoder=None, tokenizer=None, split_k: bool = False):
         if variant not in VARIANTS:
             raise KeyError(f"unknown variant {variant}; have {sorted(VARIANTS)}")
         self.unet, self.scheduler, self.variant, self.vae = unet, scheduler, variant, vae
         self.use_graphs = use_graphs          # None = automatic: on for small batches (the reference's one-prompt calls)
         # optional front end: safe_denoiser_amd.clip.CLIPTextModel + the caller's CLIPTokenizer
         self.text_encoder, self.tokenizer = text_encoder, tokenizer
+        # split_k=True: small batches additionally run their long, thin GEMMs in split-K form (lower single-prompt latency;
+        # a prompt's result then depends, in the last fp32 bits, on how many prompts share its batch)
+        self.split_k = split_k
         self.vae_scale_factor = 8
         self.last_stats = {}
 
@@ -137,7 +140,10 @@ class SafeDenoiserPipeline:
             raise _lib.SdnError(f"unet.latent_repeat = {rep} but this call runs {nb} guidance branches")
         shared_latents = rep == nb
         if hasattr(self.unet, "set_graph_mode"):
-            self.unet.set_graph_mode(nb * P <= self.GRAPH_MAX_BATCH if self.use_graphs is None else bool(self.use_graphs))
+            small = nb * P <= self.GRAPH_MAX_BATCH if self.use_graphs is None else bool(self.use_graphs)
+            self.unet.set_graph_mode(small)
+            if hasattr(self.unet, "set_split_k"):
+                self.unet.set_split_k(bool(self.split_k) and small)
         x_in = None if shared_latents else torch.empty((nb * P, C_, s, s), dtype=torch.float32, device=dev)
         model_out = torch.empty((nb * P, C_, s, s), dtype=torch.float32, device=dev)
         eps = torch.empty((P, C_, s, s), dtype=torch.float32, device=dev)

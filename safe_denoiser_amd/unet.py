@@ -187,6 +187,13 @@ class UNet2DConditionModel:
         _lib.lib().sdn_unet_set_graph_mode(self._h, 1 if on else 0)
         return self
 
+    def set_split_k(self, on: bool = True):
+        """Small-batch option (sdn_unet_set_split_k): under-filled GEMMs run in split-K form.  Rebuilds the plans, so the
+        cached workspaces are dropped.  Off by default (keeps outputs bit-identical across batch sizes)."""
+        _lib.lib().sdn_unet_set_split_k(self._h, 1 if on else 0)
+        self._ws = {}
+        return self
+
     def profile_next(self):
         """Arm HIP-event profiling of the next forward (diagnostics; see sdn_unet_profile_next)."""
         _lib.lib().sdn_unet_profile_next(self._h)

@@ -127,6 +127,47 @@ def test_conv3x3_stride2_with_right_bottom_padding(B, H, Cin, Cout):
         ops.gemm(xn, wn, bias=bias.cuda(), conv=dict(Hs=H, Ws=H, Cin=Cin, Ho=H, Wo=H, stride=1, asym_pad=1))
 
 
+@pytest.mark.parametrize("split", [2, 5, 16])
+def test_split_k_matches_unsplit_gemm_and_conv(split):
+    """sdn_gemm_splitk_*: the k loop cut into slices + a deterministic reduce pass gives the unsplit result up to fp32
+    summation order (checked against the unsplit kernel at 2e-3 and against torch at the usual one-rounding bound)."""
+    # plain GEMM with bias, per-sample row bias, residual and SiLU; M tail not a multiple of the tile
+    M, N, K = 200, 320, 2048
+    a, w = rnd(M, K, seed=51), rnd(N, K, seed=52, scale=K ** -0.5)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(53))
+    rb = torch.randn(2, N, generator=torch.Generator().manual_seed(54))
+    res = rnd(M, N, seed=55)
+    args = dict(bias=bias.cuda(), rowbias=rb.cuda(), residual=res.cuda(), rows_per_batch=100, act=1)
+    o_ref = ops.gemm(a.cuda(), w.cuda(), **args)
+    o_spl = ops.gemm(a.cuda(), w.cuda(), split_k=split, **args)
+    assert rel_l2(o_spl, o_ref) <= 2e-3
+    lin = a.float() @ w.float().t() + bias + rb.repeat_interleave(100, 0)
+    check_bf16(o_spl, F.silu(lin + res.float()))
+    # 3x3 conv (k order = channel chunk outer, tap inner: a slice may start mid-chunk)
+    B, H, Cin, Cout = 2, 8, 320, 320
+    x = rnd(B, Cin, H, H, seed=56); wc = rnd(Cout, Cin, 3, 3, seed=57, scale=(9 * Cin) ** -0.5)
+    xn = x.permute(0, 2, 3, 1).contiguous().cuda(); wn = wc.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().cuda()
+    cv = dict(Hs=H, Ws=H, Cin=Cin, Ho=H, Wo=H)
+    o_spl = ops.gemm(xn, wn, bias=bias.cuda(), conv=cv, split_k=split)
+    check_bf16(o_spl.reshape(B, H, H, Cout).permute(0, 3, 1, 2), F.conv2d(x.float(), wc.float(), bias, padding=1))
+    # two-source A (skip concat) with the seam inside a slice
+    a1, a2 = rnd(M, 640, seed=58), rnd(M, 1280, seed=59)
+    w2 = rnd(N, 1920, seed=60, scale=1920 ** -0.5)
+    o_spl = ops.gemm(a1.cuda(), w2.cuda(), a2=a2.cuda(), split_k=split)
+    check_bf16(o_spl, torch.cat([a1, a2], 1).float() @ w2.float().t())
+
+
+def test_split_k_rejects_what_it_cannot_do():
+    a, w = rnd(64, 1024).cuda(), rnd(64, 1024).cuda()
+    with pytest.raises(sda.SdnError):
+        ops.gemm(a, w, split_k=32)                                   # more slices than k-tiles
+    with pytest.raises(sda.SdnError):
+        ops.gemm(a, w, split_k=2, out_kind=1)                        # fp32 output
+    d = _lib.GemmDesc(); d.M, d.N, d.K, d.split_k = 64, 64, 1024, 2
+    o = torch.empty(64, 64, dtype=BF, device="cuda")
+    assert sda.lib().sdn_gemm_bf16(C.byref(d), a.data_ptr(), None, w.data_ptr(), None, None, None, None, o.data_ptr(), _lib.stream_ptr()) != 0
+
+
 def test_conv_out_padded_n_to_f32_nchw():
     B, H, Cin, Cout = 2, 16, 320, 4
     x = rnd(B, Cin, H, H, seed=18)

@@ -146,6 +146,28 @@ def test_graph_mode_replays_are_bit_identical():
     torch.cuda.synchronize()
 
 
+def test_split_k_plan_matches_plain_plan_and_oracle():
+    """sdn_unet_set_split_k (single-prompt latency option): same network, under-filled GEMMs in split-K form.  Not
+    bit-identical to the plain plan (fp32 summation order), but inside the same oracle tolerance."""
+    u = UNet2DConditionModel(text_len=77, **SMALL)
+    sd = u.synthetic_state_dict(7)
+    u.load_state_dict(sd)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1, 4, 16, 16, generator=g); e = torch.randn(1, 77, 768, generator=g)
+    y_plain = u(x.cuda(), 781.0, encoder_hidden_states=e.cuda()).sample
+    ws_plain = u._ws[1].numel()
+    u.set_split_k(True)
+    y_split = u(x.cuda(), 781.0, encoder_hidden_states=e.cuda()).sample
+    assert u._ws[1].numel() >= ws_plain                              # the plan was rebuilt with partial buffers
+    u.profile_next(); u(x.cuda(), 781.0, encoder_hidden_states=e.cuda())
+    assert any("/s" in r["kernel"] for r in u.profile_read())        # some GEMMs really ran split
+    ref = OracleUNet(sd, SMALL_O, act_dtype=torch.bfloat16)(x, 781.0, e)
+    print(f"split-K plan: rel L2 vs plain plan {rel_l2(y_split, y_plain):.3e}, vs oracle {rel_l2(y_split, ref):.3e}")
+    assert rel_l2(y_split, y_plain) <= 1.5e-2 and rel_l2(y_split, ref) <= 2.5e-2
+    u.set_split_k(False)
+    torch.testing.assert_close(u(x.cuda(), 781.0, encoder_hidden_states=e.cuda()).sample, y_plain, rtol=0, atol=0)
+
+
 def test_small_unet_fp16_storage_meets_fp16_tolerance():
     """fp16 storage (the reference's SD-v3 dtype; north-star "within fp16 tolerance"): rel L2 <= 4e-3 vs the fp32
     oracle and vs the fp16-emulating oracle (the oracle itself: fp16 emulation vs fp32 = 1.4e-3)."""

@@ -15,7 +15,7 @@ def _fn(base: str, t: torch.Tensor):
 
 
 def gemm(a, w, *, bias=None, rowbias=None, residual=None, a2=None, conv=None, act=0, out_kind=0, n_valid=0,
-         rows_per_batch=0, rowgate=None, residual_bcast=0):
+         rows_per_batch=0, rowgate=None, residual_bcast=0, split_k=0):
     """a [M,K] bf16 (or NHWC map for conv=dict(Hs,Ws,Cin,Ho,Wo,stride,upsample)), w [N,K] bf16."""
     N, K = w.shape
     d = _lib.GemmDesc()
@@ -45,6 +45,12 @@ def gemm(a, w, *, bias=None, rowbias=None, residual=None, a2=None, conv=None, ac
     else:
         out = torch.empty((M // rows_per_batch, nv, rows_per_batch), dtype=torch.float32, device=a.device)
     p = lambda t: None if t is None else t.data_ptr()
+    if split_k > 1:
+        d.split_k = split_k
+        part = torch.empty(split_k * M * N, dtype=torch.float32, device=a.device)
+        _lib.check(_fn("gemm_splitk", a)(C.byref(d), p(a), p(a2), p(w), p(bias), p(rowbias), p(rowgate), p(residual), p(out),
+                                                  part.data_ptr(), part.numel() * 4, _lib.stream_ptr()), "sdn_gemm_splitk")
+        return out
     _lib.check(_fn("gemm", a)(C.byref(d), p(a), p(a2), p(w), p(bias), p(rowbias), p(rowgate), p(residual), p(out),
                                        _lib.stream_ptr()), "sdn_gemm_bf16")
     return out
