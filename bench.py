@@ -233,7 +233,7 @@ def main():
                                f"sigma 3.15, scale .33, margin 1.6, window 780<=t<=1000), {args.total_prompts}-prompt job "
                                f"sharded r::{world}, CFG 7.5 (2 branches), {args.scheduler.upper()} {args.inference_steps} "
                                f"steps, 64x64x4 latents",
-                   "prompts_per_batch": P, "images_timed": n_img, "beta_threshold": beta,
+                   "prompts_per_batch": P, "latent_repeat": unet.latent_repeat, "images_timed": n_img, "beta_threshold": beta,
                    "renoise_draws_rank0": renoise, "parallelism": f"prompt-shard x{world}"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,

@@ -24,6 +24,8 @@ for p in u.manifest:
         t = ((torch.rand(n, generator=g, device="cuda") * 2 - 1) * (3.0 / max(p["cols"], 1)) ** 0.5).bfloat16()
         buf[p["offset"]:p["offset"] + 2 * n] = t.view(torch.uint8)
 u._weights = buf
+if os.environ.get("SPLIT_K"):
+    u.set_split_k(True)
 if os.environ.get("SUBBATCH") is not None:
     sda.lib().sdn_debug_set_subbatch_bytes(u._h, C.c_longlong(int(os.environ["SUBBATCH"])))
 x = torch.randn(B, 4, 64, 64, device="cuda")
