@@ -66,6 +66,7 @@ struct AttnArgs {
   // in its own buffer -> the concatenated sequence is never materialised)
   const unsigned short* q2; const unsigned short* k2; const unsigned short* v2; unsigned short* out2;
   int n1, ldq2, ldk2, ldv2, ldo2;
+  int head_inner;                    // block order for short key sets, see the block-index decode
   int causal; const int* kmask;      // MASK instantiation only: key <= query; kmask [B, nk] (0 = padded key), nullable
 };
 
@@ -120,7 +121,15 @@ k_attn(const AttnArgs a) {
   int pair, qblk;
   {
     const int nqb = a.nqb, npairs = a.npairs, id = blockIdx.x;
-    if ((npairs & 7) == 0) {
+    if (a.head_inner) {
+      // short key sets (cross-attention): K/V locality is irrelevant (77 rows), what matters is that the 8 heads of one
+      // query block -- 80-byte slices of the SAME 640-byte Q / O rows -- run back to back on ONE XCD, so those lines are
+      // fetched into / merged in one L2 instead of eight.  XCD x takes the samples b = x (mod 8); heads innermost.
+      const int x = id & 7, j = id >> 3;
+      const int hh = j % a.heads, rest = j / a.heads;
+      qblk = rest % nqb;
+      pair = ((rest / nqb) * 8 + x) * a.heads + hh;
+    } else if ((npairs & 7) == 0) {
       const int x = id & 7, j = id >> 3;
       pair = (j / nqb) * 8 + x; qblk = j - (j / nqb) * nqb;
     } else {
@@ -485,6 +494,8 @@ int launch(const AttnArgs& a, int batch, int heads, hipStream_t st) {
   return sdn_launch_status();
 }
 
+static int g_attn_head_inner = 1;    // debug A/B switch (sdn_debug_set_attn_head_inner)
+
 template <typename T>
 int run(const void* q, const void* k, const void* v, void* out, int32_t batch, int32_t heads, int32_t nq, int32_t nk,
         int32_t head_dim, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo, float scale, void* stream,
@@ -498,7 +509,8 @@ int run(const void* q, const void* k, const void* v, void* out, int32_t batch, i
   if (batch == 0) return SDN_OK;
   AttnArgs a{(const unsigned short*)q, (const unsigned short*)k, (const unsigned short*)v, (unsigned short*)out,
              nq, nk, ldq, ldk, ldv, ldo, scale * 1.4426950408889634f, heads, (nq + QB - 1) / QB, batch * heads,
-             nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, causal, kmask};
+             nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, causal, kmask};
+  if (!s2 && nk <= 2 * KV && (batch & 7) == 0 && g_attn_head_inner) a.head_inner = 1;
   if (causal && nq != nk) return SDN_E_INVALID;
   if (s2) {                                                  // joint attention over two token streams (nq == nk)
     if (!s2->q2 || !s2->k2 || !s2->v2 || !s2->out2 || s2->n1 <= 0 || s2->n1 >= nq || nq != nk) return SDN_E_INVALID;
@@ -558,3 +570,5 @@ extern "C" int sdn_masked_attention(int32_t dtype, const void* q, const void* k,
   return sdn_attn_detail::run<SdnBF16>(q, k, v, out, batch, heads, n, n, head_dim, ldq, ldk, ldv, ldo, scale, stream, nullptr,
                                        causal ? 1 : 0, key_mask);
 }
+
+extern "C" void sdn_debug_set_attn_head_inner(int on) { sdn_attn_detail::g_attn_head_inner = on; }

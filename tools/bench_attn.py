@@ -8,7 +8,11 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests_support import ops  # noqa: E402
 
+import safe_denoiser_amd as sda  # noqa: E402
+
 B = int(os.environ.get("B", "32"))
+if os.environ.get("HEAD_INNER") is not None:
+    sda.lib().sdn_debug_set_attn_head_inner(int(os.environ["HEAD_INNER"]))
 for name, nq, nk, d in [("self 64x64 d40", 4096, 4096, 40), ("self 32x32 d80", 1024, 1024, 80),
                         ("self 16x16 d160", 256, 256, 160), ("self 8x8 d160", 64, 64, 160),
                         ("cross 64x64 d40", 4096, 77, 40), ("cross 32x32 d80", 1024, 77, 80)]:
