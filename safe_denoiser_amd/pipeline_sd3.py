@@ -26,8 +26,8 @@ from . import _lib
 
 
 class SD3SafeDenoiserPipeline:
-    def __init__(self, transformer, scheduler):
-        self.transformer, self.scheduler = transformer, scheduler
+    def __init__(self, transformer, scheduler, vae=None):
+        self.transformer, self.scheduler, self.vae = transformer, scheduler, vae
         self.vae_scale_factor = 8
         self.last_stats = {}
 
@@ -41,8 +41,12 @@ class SD3SafeDenoiserPipeline:
         if prompt_embeds is None or pooled_prompt_embeds is None:
             raise NotImplementedError("text encoders are outside the hot path: pass prompt_embeds [2P,T,4096] and "
                                       "pooled_prompt_embeds [2P,2048] ([P negative | P positive])")
+        output_type = kwargs.get("output_type", "pil")
         if not return_latents:
-            raise NotImplementedError("the VAE decoder is outside the hot path: use return_latents=True")
+            if self.vae is None:
+                raise NotImplementedError("no VAE attached: construct with vae=AutoencoderKL(**SD3_VAE_CONFIG) or use return_latents=True")
+            if output_type not in ("pil", "np", "uint8"):
+                raise _lib.SdnError("output_type must be 'pil', 'np' or 'uint8'")
         hi = kwargs.get("negation_warmup_start", 1000)
         lo = kwargs.get("negation_warmup_end", 780)
         dev = torch.device("cuda", torch.cuda.current_device())
@@ -108,4 +112,14 @@ class SD3SafeDenoiserPipeline:
             lat = rq(nxt).contiguous()
             nxt = torch.empty_like(lat)
         self.last_stats = {"window_steps": n_win, "prompts": P}
-        return lat.to(latents_dtype)
+        if return_latents:
+            return lat.to(latents_dtype)
+        # safe_denoiser_pipeline.py:1195-1199: latents / scaling_factor + shift_factor -> vae.decode -> postprocess
+        lat = lat.to(latents_dtype).float()
+        if output_type == "uint8":
+            return self.vae.decode_latents_uint8(lat)
+        image = self.vae.decode_latents(lat)
+        if output_type == "pil":
+            from PIL import Image
+            return [Image.fromarray(im) for im in (image * 255).round().astype("uint8")]
+        return image

@@ -22,7 +22,11 @@ from . import _lib
 from .unet import UNet2DConditionModel
 
 SD14_VAE_CONFIG = dict(in_channels=3, out_channels=3, latent_channels=4, block_out_channels=(128, 256, 512, 512),
-                       layers_per_block=2, norm_num_groups=32, sample_size=512, scaling_factor=0.18215)
+                       layers_per_block=2, norm_num_groups=32, sample_size=512, scaling_factor=0.18215, shift_factor=0.0,
+                       use_quant_conv=True, use_post_quant_conv=True)
+# SD-v3's 16-channel VAE (models/sdv3/safe_denoiser_pipeline.py:1196: latents / scaling_factor + shift_factor; no quant convs)
+SD3_VAE_CONFIG = dict(SD14_VAE_CONFIG, latent_channels=16, scaling_factor=1.5305, shift_factor=0.0609, use_quant_conv=False,
+                      use_post_quant_conv=False)
 
 _DEPRECATED_ATTN = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}
 
@@ -151,6 +155,12 @@ class AutoencoderKL(UNet2DConditionModel):
     def pack_state_dict(self, sd: dict) -> torch.Tensor:
         sd = self._canonical(sd)
         sd = dict(sd)
+        # VAEs without (post_)quant_conv (SD-v3): the plan's 1x1 mixing stage gets the identity
+        L = self.config.latent_channels
+        if self._role == "decoder" and not self.config.use_post_quant_conv:
+            sd["post_quant_conv.weight"], sd["post_quant_conv.bias"] = torch.eye(L).reshape(L, L, 1, 1), torch.zeros(L)
+        if self._role == "encoder" and not self.config.use_quant_conv:
+            sd["quant_conv.weight"], sd["quant_conv.bias"] = torch.eye(2 * L).reshape(2 * L, 2 * L, 1, 1), torch.zeros(2 * L)
         qk = "quant_conv.weight" if self._role == "encoder" else "post_quant_conv.weight"
         sd[qk] = sd[qk].reshape(-1)                                                   # [C, C, 1, 1] -> fp32 vector
         for k in list(sd):                                                            # deprecated linears stored as 1x1 convs
@@ -159,7 +169,12 @@ class AutoencoderKL(UNet2DConditionModel):
         return super().pack_state_dict(sd)
 
     def load_state_dict(self, sd: dict, device="cuda"):
-        sd = self._canonical(sd)
+        sd = dict(self._canonical(sd))
+        L = self.config.latent_channels
+        if self._role == "decoder" and not self.config.use_post_quant_conv:
+            sd.setdefault("post_quant_conv.weight", torch.eye(L).reshape(L, L, 1, 1)); sd.setdefault("post_quant_conv.bias", torch.zeros(L))
+        if self._role == "encoder" and not self.config.use_quant_conv:
+            sd.setdefault("quant_conv.weight", torch.eye(2 * L).reshape(2 * L, 2 * L, 1, 1)); sd.setdefault("quant_conv.bias", torch.zeros(2 * L))
         if self._role == "decoder" and "encoder.conv_in.weight" in sd:
             self._encoder().load_state_dict(sd, device)
         return super().load_state_dict(sd, device)
@@ -232,14 +247,20 @@ class AutoencoderKL(UNet2DConditionModel):
                    "sdn_image_postprocess")
         return out
 
+    def _unscale(self, latents: torch.Tensor) -> torch.Tensor:
+        """latents / scaling_factor + shift_factor (SD-v3, safe_denoiser_pipeline.py:1196); the division alone is folded
+        into the plan's first kernel, a non-zero shift is applied here."""
+        sh = getattr(self.config, "shift_factor", 0.0) or 0.0
+        return latents if sh == 0.0 else latents.float() + sh * self.config.scaling_factor      # (z + sh*s)/s = z/s + sh
+
     def decode_latents(self, latents: torch.Tensor):
         """The reference pipelines' decode_latents: NHWC float32 numpy in [0, 1]."""
-        image = self.decode(latents, latent_scale=1.0 / self.config.scaling_factor).sample
+        image = self.decode(self._unscale(latents), latent_scale=1.0 / self.config.scaling_factor).sample
         return self.postprocess(image).cpu().numpy()
 
     def decode_latents_uint8(self, latents: torch.Tensor) -> torch.Tensor:
         """decode_latents + numpy_to_pil's uint8 conversion, left on the device: [B, H, W, 3] uint8."""
-        image = self.decode(latents, latent_scale=1.0 / self.config.scaling_factor).sample
+        image = self.decode(self._unscale(latents), latent_scale=1.0 / self.config.scaling_factor).sample
         return self.postprocess(image, uint8=True)
 
     def __call__(self, *a, **k):

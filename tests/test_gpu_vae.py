@@ -209,3 +209,19 @@ def test_proj_ref_builder_runs_on_the_engine(tmp_path):
     e1 = v.embed_fn(torch.Generator(device="cuda").manual_seed(3))(imgs)
     e2 = v.embed_fn(torch.Generator(device="cuda").manual_seed(3))(imgs)
     torch.testing.assert_close(e1, e2, rtol=0, atol=0)
+
+
+def test_sd3_style_vae_without_quant_convs_and_with_shift():
+    """SD-v3's VAE: 16 latent channels, no (post_)quant_conv, decode(latents / scaling_factor + shift_factor)
+    (models/sdv3/safe_denoiser_pipeline.py:1196)."""
+    from safe_denoiser_amd.vae import SD3_VAE_CONFIG
+    cfg = dict(SD3_VAE_CONFIG, block_out_channels=(64, 128), layers_per_block=1, sample_size=16)
+    v = AutoencoderKL(**cfg)
+    sd = {k: t for k, t in v.synthetic_state_dict(9).items() if not k.startswith("post_quant_conv")}     # the checkpoint has none
+    v.load_state_dict(sd)
+    lat = torch.randn(2, 16, 8, 8, generator=torch.Generator().manual_seed(4)) * 1.5
+    got = torch.from_numpy(v.decode_latents(lat.cuda()))
+    osd = dict(sd); osd["post_quant_conv.weight"] = torch.eye(16).reshape(16, 16, 1, 1); osd["post_quant_conv.bias"] = torch.zeros(16)
+    o = OracleVAEDecoder(osd, dict(latent_channels=16, block_out_channels=(64, 128), layers_per_block=1), act_dtype=torch.bfloat16)
+    ref = (o.decode(lat / 1.5305 + 0.0609) / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1)
+    assert got.shape == (2, 16, 16, 3) and float((got - ref).abs().mean()) <= 5e-3
