@@ -408,7 +408,7 @@ int sdn_image_postprocess(const float* image_nchw, int32_t batch, int32_t channe
  * out[b, co, p] = bias[co] + sum_ci w[co, ci] * in_scale * z[b, ci, p]   (1x1 conv on an fp32 NCHW map, C <= 16) */
 int sdn_latent_mix(const float* z, const float* w, const float* bias, int32_t batch, int32_t channels, int32_t hw,
                    float in_scale, float* out, void* stream);
-/* out[r, :] = softmax(scale * scores[r, :n]) as 16-bit (dtype 0 bf16 / 1 fp16); n % 4 == 0, n <= 4096 */
+/* out[r, :] = softmax(scale * scores[r, :n]) as 16-bit (dtype 0 bf16 / 1 fp16); n % 4 == 0, n <= 16384 */
 int sdn_softmax_rows(int32_t dtype, const float* scores, int64_t ld_scores, int64_t rows, int32_t n, float scale,
                      void* out, int64_t ld_out, void* stream);
 /* out[c, r] = in[r, c] for a 16-bit [rows, cols] matrix */

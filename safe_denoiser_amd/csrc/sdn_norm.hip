@@ -235,7 +235,8 @@ k_layernorm(const unsigned short* __restrict__ x, long rows, int C, float eps, c
 template <typename T>
 __global__ void __launch_bounds__(THREADS)
 k_conv_in(const float* __restrict__ lat, const unsigned short* __restrict__ w, const float* __restrict__ bias,
-          int B, int cin, int H, int W, int cout, unsigned short* __restrict__ out) {
+          int B, int cin, int H, int W, int cout, int ldo, unsigned short* __restrict__ out) {
+  // cout = the channels THIS launch computes (w / bias / out already point at its first channel); ldo = channels per pixel
   extern __shared__ float wl[];                   // [9*cin][2 halves][cout/8 chunks][4] as f32: consecutive lanes
   const int kk = 9 * cin;                         // (channel chunks) read consecutive 16-B slots -> conflict-free b128
   for (int i = threadIdx.x; i < cout * kk; i += THREADS) {
@@ -272,7 +273,7 @@ k_conv_in(const float* __restrict__ lat, const unsigned short* __restrict__ w, c
         acc[6] = fmaf(v[tap], w1.z, acc[6]); acc[7] = fmaf(v[tap], w1.w, acc[7]);
       }
     }
-    *reinterpret_cast<u32x4*>(out + pix * cout + cc * 8) = pack8<T>(acc);
+    *reinterpret_cast<u32x4*>(out + pix * ldo + cc * 8) = pack8<T>(acc);
   }
 }
 
@@ -397,21 +398,21 @@ int conv_in_impl(const float* lat, const void* w, const float* bias, int32_t bat
       (cout & 7) || !al16(out))
     return SDN_E_INVALID;
   if (batch == 0) return SDN_OK;
-  const size_t lds = (size_t)cout * 9 * cin * sizeof(float);
-  if (lds > 160 * 1024) return SDN_E_INVALID;
-  if (lds > 64 * 1024) {                      // VAE decoder conv_in (4 -> 512): 72 KB of weights; opt in to > 64 KB once
-    static bool raised = false;
-    if (!raised) {
-      if (hipFuncSetAttribute((const void*)k_conv_in<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-        return SDN_E_LAUNCH;
-      raised = true;
-    }
+  // the weights of one launch live in LDS as f32 (<= 64 KB): wide layers (VAE: 4 -> 512, SD-v3 VAE: 16 -> 512) are cut
+  // into channel chunks, each launch writing its slice of the NHWC rows
+  int chunk = (int)((64 * 1024) / ((size_t)9 * cin * sizeof(float))) & ~7;
+  if (chunk < 8) return SDN_E_INVALID;
+  if (chunk > cout) chunk = cout;
+  for (int co0 = 0; co0 < cout; co0 += chunk) {
+    const int cc = cout - co0 < chunk ? cout - co0 : chunk;
+    const size_t lds = (size_t)cc * 9 * cin * sizeof(float);
+    const long total = (long)batch * h * wd * (cc / 8);
+    long grid = (total + THREADS - 1) / THREADS;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL((k_conv_in<T>), dim3((unsigned)grid), dim3(THREADS), lds, (hipStream_t)stream, lat,
+                       (const unsigned short*)w + (size_t)co0 * 9 * cin, bias + co0, batch, cin, h, wd, cc, cout,
+                       (unsigned short*)out + co0);
   }
-  const long total = (long)batch * h * wd * (cout / 8);
-  long grid = (total + THREADS - 1) / THREADS;
-  if (grid > 2048) grid = 2048;
-  hipLaunchKernelGGL((k_conv_in<T>), dim3((unsigned)grid), dim3(THREADS), lds, (hipStream_t)stream, lat,
-                     (const unsigned short*)w, bias, batch, cin, h, wd, cout, (unsigned short*)out);
   return sdn_launch_status();
 }
 

@@ -816,31 +816,37 @@ struct Builder {
     gemm(rows, C, C, R(gn), vw, vb, R(v));
     drop(gn);
     Act at = act(rows, C, hw, x.side);
-    Act sc = act(hw, hw, 0, 0, 4);                 // fp32 scores of ONE image, reused image after image (stream order)
-    Act pr = act(hw, hw);
+    // fp32 scores of ONE image -- of one block of at most 4096 queries when the image has more tokens (1024 x 1024:
+    // 16384) -- reused block after block (stream order)
+    const int qrows = hw > 4096 ? 4096 : hw;
+    Act sc = act(qrows, hw, 0, 0, 4);
+    Act pr = act(qrows, hw);
     Act vt = act(C, hw);
     const float scale = 1.0f / sqrtf((float)C);
     for (int b = 0; b < B; ++b) {
       const int64_t img = (int64_t)b * hw * C * 2;
-      { // S = Q K^T : A = Q rows of this image, "weight" operand = its K rows
-        Op o; o.kind = OP_GEMM; memset(&o.gd, 0, sizeof(o.gd));
-        o.gd.M = hw; o.gd.N = hw; o.gd.K = C; o.gd.a_mode = SDN_A_PLAIN; o.gd.out_kind = SDN_OUT_F32;
-        o.a = Ref{SP_WS, q.off + img}; o.w = Ref{SP_WS, k.off + img}; o.out = R(sc);
-        o.flops = 2.0 * hw * (double)hw * C; o.bytes = 2.0 * 2.0 * hw * C + 4.0 * hw * (double)hw;
-        snprintf(o.label, sizeof(o.label), "k_gemm<%d>", sdn_gemm_pick_tile(hw, hw, C, SDN_ACT_NONE));
-        plan->ops.push_back(o); plan->flops += o.flops; plan->attn_flops += o.flops;
-      }
-      { Op o; o.kind = OP_SOFTMAX; o.a = R(sc); o.out = R(pr); o.rows = hw; o.c1 = hw; o.scale = scale;
-        o.bytes = 6.0 * hw * (double)hw; snprintf(o.label, sizeof(o.label), "k_softmax_rows"); plan->ops.push_back(o); }
       { Op o; o.kind = OP_TRANSPOSE; o.a = Ref{SP_WS, v.off + img}; o.out = R(vt); o.rows = hw; o.c1 = C; o.ldq = C;
         o.ldo = hw; o.bytes = 4.0 * hw * C; snprintf(o.label, sizeof(o.label), "k_transpose16"); plan->ops.push_back(o); }
-      { // O = P V : A = P [hw, hw], "weight" = V^T [C, hw]
-        Op o; o.kind = OP_GEMM; memset(&o.gd, 0, sizeof(o.gd));
-        o.gd.M = hw; o.gd.N = C; o.gd.K = hw; o.gd.a_mode = SDN_A_PLAIN; o.gd.out_kind = SDN_OUT_BF16;
-        o.a = R(pr); o.w = R(vt); o.out = Ref{SP_WS, at.off + (int64_t)b * hw * C * 2};
-        o.flops = 2.0 * hw * (double)hw * C; o.bytes = 2.0 * (hw * (double)hw + 2.0 * hw * C);
-        snprintf(o.label, sizeof(o.label), "k_gemm<%d>", sdn_gemm_pick_tile(hw, C, hw, SDN_ACT_NONE));
-        plan->ops.push_back(o); plan->flops += o.flops; plan->attn_flops += o.flops;
+      for (int r0 = 0; r0 < hw; r0 += qrows) {
+        const int64_t rowoff = (int64_t)r0 * C * 2;
+        { // S = Q K^T : A = this block's Q rows, "weight" operand = the image's K rows
+          Op o; o.kind = OP_GEMM; memset(&o.gd, 0, sizeof(o.gd));
+          o.gd.M = qrows; o.gd.N = hw; o.gd.K = C; o.gd.a_mode = SDN_A_PLAIN; o.gd.out_kind = SDN_OUT_F32;
+          o.a = Ref{SP_WS, q.off + img + rowoff}; o.w = Ref{SP_WS, k.off + img}; o.out = R(sc);
+          o.flops = 2.0 * qrows * (double)hw * C; o.bytes = 2.0 * (qrows + (double)hw) * C + 4.0 * qrows * (double)hw;
+          snprintf(o.label, sizeof(o.label), "k_gemm<%d>", sdn_gemm_pick_tile(qrows, hw, C, SDN_ACT_NONE));
+          plan->ops.push_back(o); plan->flops += o.flops; plan->attn_flops += o.flops;
+        }
+        { Op o; o.kind = OP_SOFTMAX; o.a = R(sc); o.out = R(pr); o.rows = qrows; o.c1 = hw; o.scale = scale;
+          o.bytes = 6.0 * qrows * (double)hw; snprintf(o.label, sizeof(o.label), "k_softmax_rows"); plan->ops.push_back(o); }
+        { // O = P V : A = P [qrows, hw], "weight" = V^T [C, hw]
+          Op o; o.kind = OP_GEMM; memset(&o.gd, 0, sizeof(o.gd));
+          o.gd.M = qrows; o.gd.N = C; o.gd.K = hw; o.gd.a_mode = SDN_A_PLAIN; o.gd.out_kind = SDN_OUT_BF16;
+          o.a = R(pr); o.w = R(vt); o.out = Ref{SP_WS, at.off + img + rowoff};
+          o.flops = 2.0 * qrows * (double)hw * C; o.bytes = 2.0 * (qrows * (double)hw + (qrows + (double)hw) * C);
+          snprintf(o.label, sizeof(o.label), "k_gemm<%d>", sdn_gemm_pick_tile(qrows, C, hw, SDN_ACT_NONE));
+          plan->ops.push_back(o); plan->flops += o.flops; plan->attn_flops += o.flops;
+        }
       }
     }
     drop(sc); drop(pr); drop(vt); drop(q); drop(k); drop(v);
@@ -1102,7 +1108,7 @@ int sdn_vae_decoder_create(const sdn_vae_config* cfg, sdn_unet** out) {
     if (c <= 0 || c % 64 != 0 || c % cfg->norm_groups != 0 || sdn_gemm_pick_nrep(c, SDN_ACT_NONE) == 0) return SDN_E_INVALID;
   }
   const int hw = cfg->sample_size * cfg->sample_size;         // tokens of the mid-block attention
-  if (hw % 64 != 0 || hw > 4096 || sdn_gemm_pick_nrep(hw, SDN_ACT_NONE) == 0) return SDN_E_INVALID;
+  if (hw % 64 != 0 || hw > 16384 || (hw > 4096 && hw % 4096 != 0) || sdn_gemm_pick_nrep(hw, SDN_ACT_NONE) == 0) return SDN_E_INVALID;
   sdn_unet* u = new sdn_unet();
   memset(&u->cfg, 0, sizeof(u->cfg));
   u->cfg.norm_groups = cfg->norm_groups;

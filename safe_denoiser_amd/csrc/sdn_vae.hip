@@ -30,18 +30,18 @@ k_latent_mix(const float* __restrict__ z, const float* __restrict__ w, const flo
   }
 }
 
-// One workgroup per row; the row (n <= 16 * THREADS floats) is held in registers between the three sweeps.
-template <typename T>
+// One workgroup per row; the row (n <= 4 * NV * THREADS floats) is held in registers between the three sweeps.
+template <typename T, int NV>
 __global__ void __launch_bounds__(THREADS)
 k_softmax_rows(const float* __restrict__ s, long ld_s, int n, float scale_log2e, unsigned short* __restrict__ out, long ld_o) {
   __shared__ float red[THREADS / 64];
   const float* row = s + (long)blockIdx.x * ld_s;
   unsigned short* orow = out + (long)blockIdx.x * ld_o;
   const int nv = n / 4;                                     // float4 groups
-  float4 v[4];
+  float4 v[NV];
   float mx = -3.0e38f;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < NV; ++q) {
     const int i = threadIdx.x + q * THREADS;
     if (i < nv) {
       v[q] = *reinterpret_cast<const float4*>(row + 4 * i);
@@ -55,7 +55,7 @@ k_softmax_rows(const float* __restrict__ s, long ld_s, int n, float scale_log2e,
   const float off = mx * scale_log2e;
   float sum = 0.f;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < NV; ++q) {
     const int i = threadIdx.x + q * THREADS;
     if (i < nv) {
       v[q].x = exp2f(fmaf(v[q].x, scale_log2e, -off)); v[q].y = exp2f(fmaf(v[q].y, scale_log2e, -off));
@@ -66,7 +66,7 @@ k_softmax_rows(const float* __restrict__ s, long ld_s, int n, float scale_log2e,
   sum = block_sum<THREADS / 64>(sum, red);
   const float inv = 1.f / sum;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < NV; ++q) {
     const int i = threadIdx.x + q * THREADS;
     if (i < nv) {
       uint2 pk;
@@ -159,18 +159,18 @@ extern "C" int sdn_latent_mix(const float* z, const float* w, const float* bias,
 
 extern "C" int sdn_softmax_rows(int32_t dtype, const float* scores, int64_t ld_scores, int64_t rows, int32_t n, float scale,
                                 void* out, int64_t ld_out, void* stream) {
-  if (!scores || !out || rows < 0 || n <= 0 || (n & 3) || n > 16 * THREADS || ld_scores < n || ld_out < n ||
+  if (!scores || !out || rows < 0 || n <= 0 || (n & 3) || n > 64 * THREADS || ld_scores < n || ld_out < n ||
       (ld_scores & 3) || (ld_out & 3) || (reinterpret_cast<uintptr_t>(scores) & 15) ||
       (reinterpret_cast<uintptr_t>(out) & 7) || dtype < 0 || dtype > 1 || rows > 0x7fffffffL)
     return SDN_E_INVALID;
   if (rows == 0) return SDN_OK;
   const float sl = scale * 1.4426950408889634f;
-  if (dtype == 1)
-    hipLaunchKernelGGL((k_softmax_rows<SdnF16>), dim3((unsigned)rows), dim3(THREADS), 0, (hipStream_t)stream, scores,
-                       (long)ld_scores, n, sl, (unsigned short*)out, (long)ld_out);
-  else
-    hipLaunchKernelGGL((k_softmax_rows<SdnBF16>), dim3((unsigned)rows), dim3(THREADS), 0, (hipStream_t)stream, scores,
-                       (long)ld_scores, n, sl, (unsigned short*)out, (long)ld_out);
+#define SDN_SM_LAUNCH(TT, NV)                                                                                              \
+  hipLaunchKernelGGL((k_softmax_rows<TT, NV>), dim3((unsigned)rows), dim3(THREADS), 0, (hipStream_t)stream, scores,           \
+                     (long)ld_scores, n, sl, (unsigned short*)out, (long)ld_out)
+  if (n <= 16 * THREADS) { if (dtype == 1) SDN_SM_LAUNCH(SdnF16, 4); else SDN_SM_LAUNCH(SdnBF16, 4); }
+  else { if (dtype == 1) SDN_SM_LAUNCH(SdnF16, 16); else SDN_SM_LAUNCH(SdnBF16, 16); }
+#undef SDN_SM_LAUNCH
   return sdn_launch_status();
 }
 

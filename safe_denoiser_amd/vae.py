@@ -97,6 +97,8 @@ class AutoencoderKL(UNet2DConditionModel):
         if cfg["sample_size"] % self.up_factor:
             raise _lib.SdnError("sample_size must be a multiple of 2**(levels-1)")
         self.latent_size = cfg["sample_size"] // self.up_factor
+        # images per plan invocation: the C side bounds batch * side^2 * max(channels) * 2 bytes by 2^32 (DMA offsets)
+        self.MAX_CHUNK = max(1, min(8, (2 ** 32 - 1) // (cfg["sample_size"] ** 2 * max(boc) * 2)))
         c = _lib.VaeConfig(latent_channels=cfg["latent_channels"], out_channels=cfg["out_channels"],
                            sample_size=self.latent_size, n_levels=n,
                            block_out_channels=(C.c_int32 * 4)(*(boc + [0] * (4 - n))),

@@ -225,3 +225,18 @@ def test_sd3_style_vae_without_quant_convs_and_with_shift():
     o = OracleVAEDecoder(osd, dict(latent_channels=16, block_out_channels=(64, 128), layers_per_block=1), act_dtype=torch.bfloat16)
     ref = (o.decode(lat / 1.5305 + 0.0609) / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1)
     assert got.shape == (2, 16, 16, 3) and float((got - ref).abs().mean()) <= 5e-3
+
+
+def test_decoder_with_more_than_4096_attention_tokens():
+    """1024 x 1024 images give the mid-block attention 16384 tokens: the score matrix is processed in blocks of 4096
+    queries (sdn_softmax_rows with n = 16384).  Small channel counts keep the CPU oracle affordable."""
+    cfg = dict(block_out_channels=(64, 64), layers_per_block=1, sample_size=256)         # latent side 128 -> 16384 tokens
+    v = AutoencoderKL(**cfg)
+    sd = v.synthetic_state_dict(5)
+    v.load_state_dict(sd)
+    z = torch.randn(1, 4, 128, 128, generator=torch.Generator().manual_seed(2))
+    img = v.decode(z.cuda()).sample
+    ref = OracleVAEDecoder(sd, dict(block_out_channels=(64, 64), layers_per_block=1), act_dtype=torch.bfloat16).decode(z)
+    r = rel_l2(img, ref)
+    print(f"VAE decoder with 16384 attention tokens: rel L2 vs bf16-emulating oracle {r:.3e}")
+    assert img.shape == (1, 3, 256, 256) and r <= 2.5e-2
