@@ -149,29 +149,47 @@ k_gemm_dma(const GemmArgs g) {
                                     // CONV: bits 0-8 = tap t reads inside the (virtual) input map, bit 9/10 = parity
                                     //       of the output row / column (nearest-2x upsample)
   const int ld1 = g.a_mode == 1 ? g.Cin : g.K1, ld2 = g.K - g.K1;
+  // (this setup runs before the first DMA can be issued -- in-kernel stamps put it at 2-7 k cycles, 4-11 % of a tile -- so
+  //  it is kept short: the pieces of a lane are rows m, m+8, m+16, ...: ONE division pair, then increments; the 9-tap halo
+  //  mask is an outer product of 3 row bits and 3 column bits)
+  if (g.a_mode == 1) {
+    const int hw = g.Ho * g.Wo;
+    const int Hi = g.upsample ? g.Hs * 2 : g.Hs, Wi = g.upsample ? g.Ws * 2 : g.Ws;
+    const int mb = m0 + wid * A_PIECES * 8 + lrow;
+    const int mm0 = mb < g.M ? mb : 0;
+    int bb = mm0 / hw;
+    int oy, ox;
+    { const int p = mm0 - bb * hw; oy = p / g.Wo; ox = p - oy * g.Wo; }
 #pragma unroll
-  for (int i = 0; i < A_PIECES; ++i) {
-    const int m = m0 + (wid * A_PIECES + i) * 8 + lrow;
-    const bool ok = m < g.M;
-    a_aux[i] = OOB;
-    if (g.a_mode == 1) {
-      const int mm = ok ? m : 0;
-      const int hw = g.Ho * g.Wo;
-      const int bb = mm / hw, p = mm - bb * hw;
-      const int oy = p / g.Wo, ox = p - oy * g.Wo;
-      const int Hi = g.upsample ? g.Hs * 2 : g.Hs, Wi = g.upsample ? g.Ws * 2 : g.Ws;
+    for (int i = 0; i < A_PIECES; ++i) {
+      const int m = mb + i * 8;
+      const bool ok = m < g.M;
+      if (i > 0) {
+        if (g.Wo >= 8) {                                     // rows advance by 8: at most one wrap per level
+          ox += 8;
+          if (ox >= g.Wo) { ox -= g.Wo; if (++oy >= g.Ho) { oy = 0; ++bb; } }
+        } else {
+          const int mm = ok ? m : 0;
+          bb = mm / hw;
+          const int p = mm - bb * hw;
+          oy = p / g.Wo; ox = p - oy * g.Wo;
+        }
+      }
       const int cy = oy * g.stride + g.conv_off, cx = ox * g.stride + g.conv_off;   // centre in the virtual (upsampled) input
                                                                  // (conv_off = 1: padding (0,1,0,1), taps start at 2*o)
-      unsigned mask = 0;
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int iy = cy + t / 3 - 1, ix = cx + t % 3 - 1;
-        if (ok && iy >= 0 && iy < Hi && ix >= 0 && ix < Wi) mask |= 1u << t;
-      }
+      const unsigned rb = (cy >= 1 ? 1u : 0u) | (cy < Hi ? 2u : 0u) | (cy + 1 < Hi ? 4u : 0u);
+      const unsigned cb = (cx >= 1 ? 1u : 0u) | (cx < Wi ? 2u : 0u) | (cx + 1 < Wi ? 4u : 0u);
+      unsigned mask = ((rb & 1u) ? cb : 0u) | ((rb & 2u) ? cb << 3 : 0u) | ((rb & 4u) ? cb << 6 : 0u);
+      if (!ok) mask = 0u;
       a_aux[i] = mask | ((unsigned)(cy & 1) << 9) | ((unsigned)(cx & 1) << 10);
       const int sy = g.upsample ? cy >> 1 : cy, sx = g.upsample ? cx >> 1 : cx;
-      a_base[i] = (unsigned)((((bb * g.Hs + sy) * g.Ws + sx) * g.Cin + lchunk * 8) * 2);
-    } else {
+      a_base[i] = ok ? (unsigned)((((bb * g.Hs + sy) * g.Ws + sx) * g.Cin + lchunk * 8) * 2) : 0u;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < A_PIECES; ++i) {
+      const int m = m0 + (wid * A_PIECES + i) * 8 + lrow;
+      const bool ok = m < g.M;
       a_base[i] = ok ? (unsigned)(((long)m * ld1 + lchunk * 8) * 2) : OOB;
       a_aux[i] = (g.a2 && ok) ? (unsigned)(((long)m * ld2 + lchunk * 8) * 2) : OOB;
     }
@@ -242,6 +260,11 @@ k_gemm_dma(const GemmArgs g) {
   };
 
   const int fr = lane & 15, fq = lane >> 4;
+  const int nk = g.kt_per_split > 0 ? min(g.kt_per_split, g.K / BK - kt0) : g.K / BK;
+  SDN_STAMP(7)
+  // 2-stage form: the first k-tile's DMA goes out BEFORE the bias loads, which then ride in its shadow (the vmcnt(0)
+  // below covers both).  The 4-stage form waits with counted vmcnt, so its bias loads stay ahead of the DMA queue.
+  if constexpr (NSTAGE == 2) issue(0);
   // Accumulators start at bias (+ the per-sample row bias): the loads overlap the first k-tile's DMA instead of sitting,
   // one L2 round trip per fragment, in the epilogue (in-kernel stamps: the epilogue was 26-61 % of a workgroup's life).
   // acc[i][j][e] <-> row m0 + wm*64 + i*16 + fr, column n0 + wn*16*NREP + j*16 + fq*4 + e.
@@ -271,9 +294,7 @@ k_gemm_dma(const GemmArgs g) {
     }
   }
 
-  const int nk = g.kt_per_split > 0 ? min(g.kt_per_split, g.K / BK - kt0) : g.K / BK;
   if constexpr (NSTAGE == 2) {
-    issue(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   } else {                                                   // host guarantees nk >= NSTAGE

@@ -96,7 +96,8 @@ def test_gemm_geglu(C):
 
 @pytest.mark.parametrize("B,H,Cin,Cout,stride,ups", [(2, 16, 320, 320, 1, 0), (1, 16, 640, 320, 2, 0),
                                                      (2, 8, 320, 640, 1, 1), (3, 8, 64, 160, 1, 0),
-                                                     (1, 64, 320, 320, 1, 0)])
+                                                     (1, 64, 320, 320, 1, 0), (5, 4, 64, 64, 1, 0), (3, 8, 64, 64, 2, 0),
+                                                     (2, 4, 64, 96, 1, 1)])   # output maps narrower than 8: per-piece decode
 def test_conv3x3_implicit_gemm(B, H, Cin, Cout, stride, ups):
     x = rnd(B, Cin, H, H, seed=15)
     w = rnd(Cout, Cin, 3, 3, seed=16, scale=(9 * Cin) ** -0.5)

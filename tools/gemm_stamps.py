@@ -44,5 +44,6 @@ for name, M, N, K, conv, res in [("proj 320", B * 4096, 320, 320, None, True), (
     print(f"{name:16s} blocks {len(s):5d}  prologue+first DMA {d[:,0].median():8.0f}  k-loop {d[:,1].median():8.0f}  epilogue {d[:,2].median():8.0f}"
           f"  block total {tot.median():8.0f}")
     e = s8.double()
+    print(f"{'':16s} prologue: index math {(e[:,7]-e[:,0]).median():7.0f}  first DMA issue+wait {(e[:,1]-e[:,7]).median():7.0f}")
     print(f"{'':16s} epilogue pass 0: acc->LDS {(e[:,4]-e[:,2]).median():7.0f}  barrier {(e[:,5]-e[:,4]).median():7.0f}  store loop {(e[:,6]-e[:,5]).median():7.0f}"
           f"  rest (pass 1 / tail) {(e[:,3]-e[:,6]).median():7.0f}   [s_memtime ticks]")
