@@ -68,6 +68,14 @@ def build_engine(args, rank, world, dev):
     return unet, pipe, proc, beta
 
 
+def _attn_pad(label: str) -> float:
+    """issued / algorithmic MFMA work of k_attn<d>: (ceil16(d) + ceil32(d + (d % 32 != 0))) / (2 d)."""
+    d = int(label[label.index("<") + 1:label.index(">")])
+    qk = -(-d // 16) * 16
+    pv = -(-(d + (1 if d % 32 else 0)) // 32) * 32
+    return (qk + pv) / (2.0 * d)
+
+
 def cpu_baseline(args):
     """The CPU oracle (a port of the reference loop, fp32 torch ops) on the host cores: ONE of the 50 denoising
     iterations of ONE prompt at the full SD-v1.4 size, inside the repellency window, extrapolated x50."""
@@ -242,6 +250,11 @@ def main():
                      "share_of_unet_time": d["ms"] / 3 / unet_ms},
         "attention_roofline": {"achieved": attn_tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": attn_tf / PEAK_BF16_TFLOPS,
+                               # diagnostic only: MFMA work actually ISSUED by the flash kernel, which pads the head dim to
+                               # the 32x32x16 tile (QK^T: d -> 16-multiple, PV: d + ones column -> 32-multiple); `achieved`
+                               # above counts the algorithmic 4*B*H*Nq*Nk*d only
+                               "mfma_issued_tflops": {k_: (v["flops"] / (v["ms"] * 1e-3) / 1e12) * _attn_pad(k_)
+                                                      for k_, v in attn.items()},
                                "kernels": {k_: {"avg_launch_us": v["ms"] / v["launches"] * 1e3,
                                                 "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12} for k_, v in attn.items()}},
         "unet": {"ms_per_forward": unet_ms, "batch": 2 * P, "tflops": total_f / (unet_ms * 1e-3) / 1e12,
