@@ -35,7 +35,8 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 // Diagnostics build (-DSDN_ATTN_STAMPS, tools/attn_stamps.py): per-wave cycle sums of the main loop's phases.
 #ifdef SDN_ATTN_STAMPS
-#define SDN_ATS_DECL unsigned long long ats_prev = 0, ats_sum[5] = {0, 0, 0, 0, 0};
+#define SDN_ATS_DECL unsigned long long ats_prev = 0, ats_sum[7] = {0, 0, 0, 0, 0, 0, 0};
+#define SDN_ATS_T0 unsigned long long ats_t0; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ats_t0)::"memory");
 #define SDN_ATS_MARK(I)                                                                         \
   {                                                                                             \
     unsigned long long t_;                                                                      \
@@ -45,10 +46,13 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
   }
 #define SDN_ATS_FLUSH                                                                           \
   if (g_attn_stamps && lane == 0)                                                               \
-    for (int i_ = 0; i_ < 5; ++i_) g_attn_stamps[((long)blockIdx.x * 4 + wid) * 5 + i_] = ats_sum[i_];
+    for (int i_ = 0; i_ < 7; ++i_) g_attn_stamps[((long)blockIdx.x * 4 + wid) * 7 + i_] = ats_sum[i_];
 __device__ unsigned long long* g_attn_stamps = nullptr;
+#define SDN_ATS_PRO ats_sum[5] = ats_prev - ats_t0;       /* kernel start -> main loop (Q load, LDS init, first K/V tile) */
 #else
 #define SDN_ATS_DECL
+#define SDN_ATS_T0
+#define SDN_ATS_PRO
 #define SDN_ATS_MARK(I)
 #define SDN_ATS_FLUSH
 #endif
@@ -84,6 +88,7 @@ template <typename T, int HD, bool SEG, bool MASK = false, bool DMA = !SEG>
 __global__ void __launch_bounds__(THREADS)
 k_attn(const AttnArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  SDN_ATS_T0
   constexpr int KQ = (HD + 15) / 16;          // 16-deep k-steps of Q K^T
   constexpr int NDB = (HD + 31) / 32;         // 32-row blocks of O^T
   constexpr bool ONES = (HD % 32) != 0;       // a free padding column exists -> row sums via MFMA
@@ -285,6 +290,7 @@ k_attn(const AttnArgs a) {
 
   SDN_ATS_DECL
   SDN_ATS_MARK(-1)
+  SDN_ATS_PRO
   for (int t = 0; t < ntiles; ++t) {
     const int buf = t & 1;
     const unsigned char* sK = smem + buf * STAGE;
@@ -438,8 +444,6 @@ k_attn(const AttnArgs a) {
     __syncthreads();
     SDN_ATS_MARK(4)                               // barrier
   }
-  SDN_ATS_FLUSH
-
   // ---- epilogue: normalise by the row sum ----
   float l_tot;
   if (ONES) {
@@ -466,6 +470,8 @@ k_attn(const AttnArgs a) {
         }
       }
   }
+  SDN_ATS_MARK(6)                                 // epilogue: normalise + store
+  SDN_ATS_FLUSH
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
