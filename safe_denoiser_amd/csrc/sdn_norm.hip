@@ -244,36 +244,58 @@ k_conv_in(const float* __restrict__ lat, const unsigned short* __restrict__ w, c
     wl[((k * 2 + ((co >> 2) & 1)) * (cout / 8) + (co >> 3)) * 4 + (co & 3)] = T::to_f(w[i]);
   }
   __syncthreads();
+  // One thread = PX = 4 horizontally adjacent pixels x 8 output channels: the 3 x 6 input window and every weight read
+  // from LDS are reused for the four pixels (index math, global loads and LDS reads per FMA drop 4x); lanes run over the
+  // channel chunks of a pixel group, so a wave's stores are whole contiguous rows.  32-bit index math throughout (the
+  // host checks the range): the 64-bit divisions this loop used to do per output chunk cost more than its FMAs.
+  constexpr int PX = 4;
   const int cchunks = cout / 8;
-  const long total = (long)B * H * W * cchunks;
-  for (long e = (long)blockIdx.x * THREADS + threadIdx.x; e < total; e += (long)gridDim.x * THREADS) {
-    const int cc = (int)(e % cchunks);
-    const long pix = e / cchunks;
-    const int xw = (int)(pix % W), yh = (int)((pix / W) % H), b = (int)(pix / ((long)W * H));
-    float acc[8];
+  const int WQ = (W + PX - 1) / PX;
+  const int total = B * H * WQ * cchunks;
+  const int HWQ = H * WQ;
+  for (int e = blockIdx.x * THREADS + threadIdx.x; e < total; e += gridDim.x * THREADS) {
+    const int pq = e / cchunks, cc = e - pq * cchunks;
+    const int b = pq / HWQ, rem = pq - b * HWQ;
+    const int yh = rem / WQ, x0 = (rem - yh * WQ) * PX;
+    float acc[PX][8];
+    {
+      const float4 b0 = *reinterpret_cast<const float4*>(bias + cc * 8), b1 = *reinterpret_cast<const float4*>(bias + cc * 8 + 4);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] = bias[cc * 8 + k];
+      for (int p = 0; p < PX; ++p) {
+        acc[p][0] = b0.x; acc[p][1] = b0.y; acc[p][2] = b0.z; acc[p][3] = b0.w;
+        acc[p][4] = b1.x; acc[p][5] = b1.y; acc[p][6] = b1.z; acc[p][7] = b1.w;
+      }
+    }
     const float* lb = lat + (long)b * cin * H * W;
     for (int c = 0; c < cin; ++c) {
-      float v[9];                                 // the 3x3 window: clamped (always valid) loads, zeroed by select
+      float v[3][PX + 2];                         // rows yh-1..yh+1, columns x0-1..x0+PX: clamped loads, zeroed by select
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int iy = yh + tap / 3 - 1, ix = xw + tap % 3 - 1;
-        const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
-        const float t = lb[((long)c * H + min(max(iy, 0), H - 1)) * W + min(max(ix, 0), W - 1)];
-        v[tap] = ok ? t : 0.f;
-      }
+      for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < PX + 2; ++tx) {
+          const int iy = yh + ty - 1, ix = x0 + tx - 1;
+          const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+          const float t = lb[((long)c * H + min(max(iy, 0), H - 1)) * W + min(max(ix, 0), W - 1)];
+          v[ty][tx] = ok ? t : 0.f;
+        }
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const float4 w0 = *reinterpret_cast<const float4*>(&wl[(((tap * cin + c) * 2 + 0) * cchunks + cc) * 4]);
         const float4 w1 = *reinterpret_cast<const float4*>(&wl[(((tap * cin + c) * 2 + 1) * cchunks + cc) * 4]);
-        acc[0] = fmaf(v[tap], w0.x, acc[0]); acc[1] = fmaf(v[tap], w0.y, acc[1]);
-        acc[2] = fmaf(v[tap], w0.z, acc[2]); acc[3] = fmaf(v[tap], w0.w, acc[3]);
-        acc[4] = fmaf(v[tap], w1.x, acc[4]); acc[5] = fmaf(v[tap], w1.y, acc[5]);
-        acc[6] = fmaf(v[tap], w1.z, acc[6]); acc[7] = fmaf(v[tap], w1.w, acc[7]);
+#pragma unroll
+        for (int p = 0; p < PX; ++p) {
+          const float x = v[tap / 3][tap % 3 + p];
+          acc[p][0] = fmaf(x, w0.x, acc[p][0]); acc[p][1] = fmaf(x, w0.y, acc[p][1]);
+          acc[p][2] = fmaf(x, w0.z, acc[p][2]); acc[p][3] = fmaf(x, w0.w, acc[p][3]);
+          acc[p][4] = fmaf(x, w1.x, acc[p][4]); acc[p][5] = fmaf(x, w1.y, acc[p][5]);
+          acc[p][6] = fmaf(x, w1.z, acc[p][6]); acc[p][7] = fmaf(x, w1.w, acc[p][7]);
+        }
       }
     }
-    *reinterpret_cast<u32x4*>(out + pix * ldo + cc * 8) = pack8<T>(acc);
+    const long pix0 = ((long)b * H + yh) * W + x0;
+#pragma unroll
+    for (int p = 0; p < PX; ++p)
+      if (x0 + p < W) *reinterpret_cast<u32x4*>(out + (pix0 + p) * ldo + cc * 8) = pack8<T>(acc[p]);
   }
 }
 
@@ -403,12 +425,13 @@ int conv_in_impl(const float* lat, const void* w, const float* bias, int32_t bat
   int chunk = (int)((64 * 1024) / ((size_t)9 * cin * sizeof(float))) & ~7;
   if (chunk < 8) return SDN_E_INVALID;
   if (chunk > cout) chunk = cout;
+  if ((long)batch * h * wd * (chunk / 8) >= (1L << 31)) return SDN_E_INVALID;
   for (int co0 = 0; co0 < cout; co0 += chunk) {
     const int cc = cout - co0 < chunk ? cout - co0 : chunk;
     const size_t lds = (size_t)cc * 9 * cin * sizeof(float);
-    const long total = (long)batch * h * wd * (cc / 8);
+    const long total = (long)batch * h * ((wd + 3) / 4) * (cc / 8);
     long grid = (total + THREADS - 1) / THREADS;
-    if (grid > 2048) grid = 2048;
+    if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL((k_conv_in<T>), dim3((unsigned)grid), dim3(THREADS), lds, (hipStream_t)stream, lat,
                        (const unsigned short*)w + (size_t)co0 * 9 * cin, bias + co0, batch, cin, h, wd, cc, cout,
                        (unsigned short*)out + co0);

@@ -287,6 +287,17 @@ def test_conv_in_and_timestep_embedding():
                                           out.data_ptr(), _lib.stream_ptr()), "conv_in")
     torch.cuda.synchronize()
     check_bf16(out, ref)
+    # odd sizes: width not a multiple of the 4-pixel thread tile, 3 input channels, few output channels
+    for (B2, cin, H2, W2, cout) in ((1, 3, 5, 7, 16), (2, 16, 9, 13, 40)):
+        lat2 = torch.randn(B2, cin, H2, W2, generator=torch.Generator().manual_seed(35))
+        w2 = rnd(cout, cin, 3, 3, seed=36, scale=(9 * cin) ** -0.5)
+        b2 = torch.randn(cout, generator=torch.Generator().manual_seed(37))
+        ref2 = F.conv2d(lat2, w2.float(), b2, padding=1).permute(0, 2, 3, 1)
+        o2 = torch.empty(B2, H2, W2, cout, dtype=BF, device="cuda")
+        wn2, lg2, bg2 = w2.permute(0, 2, 3, 1).contiguous().cuda(), lat2.cuda(), b2.cuda()
+        _lib.check(sda.lib().sdn_conv_in_bf16(lg2.data_ptr(), wn2.data_ptr(), bg2.data_ptr(), B2, cin, H2, W2, cout,
+                                              o2.data_ptr(), _lib.stream_ptr()), "conv_in")
+        check_bf16(o2, ref2)
     from oracle.unet import OracleUNet
     for t in (981.0, 1.0, 500.0):
         te = torch.empty(3, 320, dtype=BF, device="cuda")
