@@ -310,6 +310,8 @@ typedef struct sdn_unet sdn_unet;   /* opaque: op plan + parameter manifest (hos
 #define SDN_P_GEGLU_MAT   3   /* [2F,in] -> bf16, rows interleaved value/gate in blocks of 16  */
 #define SDN_P_GEGLU_VEC   4   /* [2F] -> f32, interleaved the same way                         */
 #define SDN_P_POS_CROP    5   /* [1, max*max, C] -> 16-bit [h*w, C], centre crop (MMDiT pos_embed) */
+#define SDN_P_DERIVED     6   /* not a state_dict tensor: `rows` BYTES the engine fills itself from other entries
+                                 (LayerNorm-folded weights); loaders skip it and call sdn_unet_prepare afterwards */
 
 typedef struct sdn_param_info {
   char     name[128];       /* diffusers state_dict key                                          */
@@ -354,6 +356,24 @@ int sdn_mmdit_forward(sdn_unet* m, const void* weights, const float* latents, fl
                       const void* pooled, float* out, int32_t batch, void* workspace, size_t workspace_bytes,
                       void* stream);
 
+/* LayerNorm folded into the GEMM that consumes it (BasicTransformerBlock: norm1 -> to_q/k/v, norm2 -> attn2.to_q, norm3 ->
+ * GEGLU proj; models/transformer_2d.py:239-359): out = LayerNorm_eps(A; gamma, beta) . W^T + bias [GEGLU], computed as
+ * rstd[m] * (A . W'^T - mean[m] * c[n]) + d[n] with W' = W * gamma (per input channel, 16-bit), c[n] = sum_k W'[n,k],
+ * d[n] = sum_k beta[k] W[n,k] + bias[n] -- the three produced ONCE per weight set by sdn_ln_fold (bias may be NULL; GEGLU
+ * weights / biases in their interleaved layout).  The kernel takes the row sums from the A fragments it feeds the MFMAs
+ * anyway (row_stats NULL; meant for narrow N -- every n-tile repeats that work), or reads (mean, rstd) per row from
+ * row_stats [M][2], written by the read-only pre-pass sdn_row_stats_* (wide N); the normalised activation never exists in
+ * HBM.  16-bit output, act NONE or GEGLU; N a multiple of 160 or 64 without row_stats, of 160 / 128 / 64 with. */
+int sdn_ln_fold(int32_t dtype, const void* w, const float* gamma, const float* beta, const float* bias, int32_t rows,
+                int32_t cols, void* w_folded, float* c, float* d, void* stream);
+int sdn_gemm_ln_bf16(const sdn_gemm_desc* desc, const void* a, const void* w_folded, const float* c, const float* d, float eps,
+                     const float* row_stats, void* out, void* stream);
+int sdn_gemm_ln_f16(const sdn_gemm_desc* desc, const void* a, const void* w_folded, const float* c, const float* d, float eps,
+                    const float* row_stats, void* out, void* stream);
+/* out[m] = (mean, 1 / sqrt(var + eps)) of row m of the 16-bit [rows, c] matrix x */
+int sdn_row_stats_bf16(const void* x, int64_t rows, int32_t c, float eps, float* out, void* stream);
+int sdn_row_stats_f16(const void* x, int64_t rows, int32_t c, float eps, float* out, void* stream);
+
 /* Split-K form for small M / long K (one-prompt batches: 8-20 tiles for 256 CUs): the k loop is cut into desc->split_k
  * slices, each writes an fp32 partial [M, N] into `partials` (>= split_k * M * N * 4 bytes), and a second kernel sums
  * them in a fixed order and applies the epilogue.  16-bit outputs, any activation but GEGLU, n_valid == N. */
@@ -366,6 +386,10 @@ int sdn_gemm_splitk_f16(const sdn_gemm_desc* d, const void* a, const void* a2, c
 
 /* out[k * bytes + i] = in[i], k < rep (device-side `torch.cat([x] * rep)`; bytes % 16 == 0) */
 int sdn_repeat(const void* in, size_t bytes, int32_t rep, void* out, void* stream);
+
+/* Fills the SDN_P_DERIVED regions of a freshly uploaded weight buffer (LayerNorm-folded projections: sdn_ln_fold over the
+ * packed tensors).  Call once after every upload / change of the weights, on the stream that will run the forwards. */
+int sdn_unet_prepare(sdn_unet* u, void* weights, void* stream);
 
 /* ---- AutoencoderKL decoder (the "next" row after the denoising loop) ------------------------------
  * Replaces `self.vae.decode(latents / scaling_factor)` inside StableDiffusionPipeline.decode_latents, called at

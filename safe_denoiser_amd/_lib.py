@@ -97,6 +97,11 @@ SIGNATURES = {
     "sdn_flow_renoise": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp, _vp]),
     "sdn_gemm_bf16": (C.c_int, [C.POINTER(GemmDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sdn_gemm_f16": (C.c_int, [C.POINTER(GemmDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sdn_ln_fold": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "sdn_gemm_ln_bf16": (C.c_int, [C.POINTER(GemmDesc), _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp]),
+    "sdn_gemm_ln_f16": (C.c_int, [C.POINTER(GemmDesc), _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp]),
+    "sdn_row_stats_bf16": (C.c_int, [_vp, _i64, _i32, _f32, _vp, _vp]),
+    "sdn_row_stats_f16": (C.c_int, [_vp, _i64, _i32, _f32, _vp, _vp]),
     "sdn_gemm_splitk_bf16": (C.c_int, [C.POINTER(GemmDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sdn_gemm_splitk_f16": (C.c_int, [C.POINTER(GemmDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sdn_groupnorm_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),
@@ -143,6 +148,7 @@ SIGNATURES = {
     "sdn_clip_embed": (C.c_int, [_i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "sdn_masked_attention": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                        _f32, _vp]),
+    "sdn_unet_prepare": (C.c_int, [_vp, _vp, _vp]),
     "sdn_unet_set_graph_mode": (None, [_vp, _i32]),
     "sdn_unet_set_split_k": (None, [_vp, _i32]),
     "sdn_unet_profile_next": (None, [_vp]),

@@ -46,13 +46,7 @@ class CLIPTextModel(UNet2DConditionModel):
         self._h = h
         self._weights = None
         self._ws = {}
-        self.manifest = []
-        info = _lib.ParamInfo()
-        for i in range(_lib.lib().sdn_unet_param_count(h)):
-            _lib.check(_lib.lib().sdn_unet_param_info(h, i, C.byref(info)), "sdn_unet_param_info")
-            self.manifest.append(dict(name=info.name.decode(), kind=info.kind, rows=info.rows, cols=info.cols,
-                                      rows_padded=info.rows_padded, offset=info.offset))
-        self.weight_bytes = _lib.lib().sdn_unet_weight_bytes(h)
+        self._read_manifest()
 
     def state_dict_shapes(self) -> dict:
         return {p["name"]: ((p["rows"],) if p["cols"] == 0 else (p["rows"], p["cols"])) for p in self.manifest}

@@ -54,6 +54,22 @@ struct SdnBF16 {
   static __device__ __forceinline__ sdn_f32x4 mfma16(v8 a, v8 b, sdn_f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
   }
+  // acc + sum(v) / acc + sum(v * v) over the 8 elements (v_dot2c_f32_bf16)
+  static __device__ __forceinline__ float dot_self(v8 v, float acc) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 v2;
+    const v2* p = reinterpret_cast<const v2*>(&v);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_fdot2_f32_bf16(p[i], p[i], acc, false);
+    return acc;
+  }
+  static __device__ __forceinline__ float dot_ones(v8 v, float acc) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 v2;
+    const v2* p = reinterpret_cast<const v2*>(&v);
+    const v2 one = {(__bf16)1.0f, (__bf16)1.0f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_fdot2_f32_bf16(p[i], one, acc, false);
+    return acc;
+  }
   static __device__ __forceinline__ sdn_f32x16 mfma32(v8 a, v8 b, sdn_f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
   }
@@ -72,6 +88,21 @@ struct SdnF16 {
   }
   static __device__ __forceinline__ sdn_f32x4 mfma16(v8 a, v8 b, sdn_f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ float dot_self(v8 v, float acc) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 v2;
+    const v2* p = reinterpret_cast<const v2*>(&v);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_fdot2(p[i], p[i], acc, false);
+    return acc;
+  }
+  static __device__ __forceinline__ float dot_ones(v8 v, float acc) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 v2;
+    const v2* p = reinterpret_cast<const v2*>(&v);
+    const v2 one = {(_Float16)1.0f, (_Float16)1.0f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_fdot2(p[i], one, acc, false);
+    return acc;
   }
   static __device__ __forceinline__ sdn_f32x16 mfma32(v8 a, v8 b, sdn_f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);

@@ -40,6 +40,7 @@ struct GemmArgs {
   int a_mode, Hs, Ws, Cin, Ho, Wo, stride, upsample, conv_off;
   int act, out_kind, rows_per_batch, ld_rowbias, ld_rowgate, residual_bcast, n_valid, ldc;
   int tiles_m, tiles_n;
+  const float* ln_c; const float* ln_d; float ln_eps; const float* ln_stats;   // LNF kernels: LayerNorm folded into this GEMM (see k_gemm_dma)
   int kt_per_split;          // split-K: k-tiles per blockIdx.y slice (0 = no split); each slice writes its own fp32 partial
   long split_stride;         // bytes between the partial outputs of consecutive slices
   int res_lds;               // residual goes through the LDS staging slab (16-bit staged output, offsets fit 31 bits)
@@ -107,7 +108,14 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
     g.stamps[(long)blockIdx.x * 8 + (IDX)] = t_;                                                         \
   }
 
-template <typename T, int NREP, int WGM, int NSTAGE>
+// LNF: out = LayerNorm(A) . W^T + b with the LayerNorm folded in: the caller passes W' = W * gamma (per input channel,
+// rounded to 16 bit), c[n] = sum_k W'[n,k] and d[n] = sum_k beta[k] W[n,k] + b[n]; the kernel accumulates each row's sum
+// and sum of squares from the A fragments it feeds the MFMAs anyway (v_dot2c), and the epilogue applies
+// rstd * (acc - mean * c[n]) + d[n].  The normalised activation is never written to or re-read from HBM.
+// LNF = 1: row statistics from the fragments (right for narrow N: every n-tile repeats that VALU work -- at N = 8C it
+// costs more than the LayerNorm kernel it replaces); LNF = 2: statistics read from g.ln_stats [M][2] = (mean, rstd),
+// written by a read-only pre-pass (sdn_row_stats_*), for wide N.
+template <typename T, int NREP, int WGM, int NSTAGE, int LNF = 0>
 __global__ void __launch_bounds__(128 * WGM, NSTAGE > 2 ? 1 : 2)
 k_gemm_dma(const GemmArgs g) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -305,6 +313,16 @@ k_gemm_dma(const GemmArgs g) {
   }
   SDN_STAMP(1)
 
+  [[maybe_unused]] float ln_s1[4] = {0.f, 0.f, 0.f, 0.f}, ln_s2[4] = {0.f, 0.f, 0.f, 0.f};   // LNF 1: per-row sum / sum of squares
+  [[maybe_unused]] float ln_mu[4], ln_rs[4];
+  if constexpr (LNF == 2) {                                  // pre-pass statistics: fetched under the k loop
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wm * 64 + i * 16 + fr;
+      const float2 st2 = *reinterpret_cast<const float2*>(g.ln_stats + 2 * (long)(m < g.M ? m : 0));
+      ln_mu[i] = st2.x; ln_rs[i] = st2.y;
+    }
+  }
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & (NSTAGE - 1);
     if (kt + NSTAGE - 1 < nk && !(g.dbg & 2)) issue((kt + NSTAGE - 1) & (NSTAGE - 1));
@@ -316,6 +334,10 @@ k_gemm_dma(const GemmArgs g) {
       typename T::v8 fa[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const typename T::v8*>(sa + lds_off(i * 16 + fr, ks * 4 + fq));
+      if constexpr (LNF == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ln_s1[i] = T::dot_ones(fa[i], ln_s1[i]); ln_s2[i] = T::dot_self(fa[i], ln_s2[i]); }
+      }
       // (macro, not a lambda: the column-block offset must be a compile-time constant or acc[][] goes to scratch)
 #define SDN_MMA_PART(J0)                                                                                              \
       {                                                                                                                \
@@ -345,6 +367,19 @@ k_gemm_dma(const GemmArgs g) {
   }
 
   SDN_STAMP(2)
+  if constexpr (LNF == 1) {
+    // a lane holds the k-chunks fq, fq+4 of rows i*16+fr: the other three lane groups (lane ^ 16, ^ 32) hold the rest
+    const float invk = 1.0f / (float)g.K;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float a1 = ln_s1[i], a2 = ln_s2[i];
+      a1 += __shfl_xor(a1, 16, 64); a2 += __shfl_xor(a2, 16, 64);
+      a1 += __shfl_xor(a1, 32, 64); a2 += __shfl_xor(a2, 32, 64);
+      const float mu = a1 * invk;
+      const float var = fmaxf(a2 * invk - mu * mu, 0.f);
+      ln_mu[i] = mu; ln_rs[i] = __builtin_amdgcn_rsqf(var + g.ln_eps);
+    }
+  }
   // ---- epilogue ----
   // 16-bit outputs are staged through LDS (free after the k loop) so that HBM sees whole 16-byte-per-lane, row-
   // contiguous stores instead of 8-byte fragments at a row stride (guide T21: "widen the epilogue stores").
@@ -429,16 +464,31 @@ int sdn_gemm_pick_split(int M, int N, int K, int act, int out_kind) {
 
 namespace sdn_gemm_detail {
 
-template <typename T, int NREP, int WGM, int NSTAGE = 2>
+template <typename T, int NREP, int WGM, int NSTAGE = 2, int LNF = 0>
 int launch_dma(const GemmArgs& ga, hipStream_t st) {
   const int grid = ga.tiles_m * ga.tiles_n;
   const int splits = ga.kt_per_split > 0 ? (ga.K / BK + ga.kt_per_split - 1) / ga.kt_per_split : 1;
-  hipLaunchKernelGGL((k_gemm_dma<T, NREP, WGM, NSTAGE>), dim3(grid, splits), dim3(128 * WGM), 0, st, ga);
+  hipLaunchKernelGGL((k_gemm_dma<T, NREP, WGM, NSTAGE, LNF>), dim3(grid, splits), dim3(128 * WGM), 0, st, ga);
   return sdn_launch_status();
 }
 
 template <typename T>
 int dispatch_dma(int nrep, const GemmArgs& g, hipStream_t st) {
+  if (g.ln_c && g.ln_stats) {                                // LayerNorm-folded form, row statistics from the pre-pass
+    switch (nrep) {
+      case 5: return launch_dma<T, 5, 2, 2, 2>(g, st);
+      case 4: return launch_dma<T, 4, 2, 2, 2>(g, st);
+      case 2: return launch_dma<T, 2, 2, 2, 2>(g, st);
+      default: return SDN_E_INVALID;
+    }
+  }
+  if (g.ln_c) {                                              // ... statistics from the A fragments (narrow N)
+    switch (nrep) {
+      case 5: return launch_dma<T, 5, 2, 2, 1>(g, st);
+      case 2: return launch_dma<T, 2, 2, 2, 1>(g, st);
+      default: return SDN_E_INVALID;
+    }
+  }
   switch (nrep) {
     case 10: return launch_dma<T, 10, 4>(g, st);
     case 8: return launch_dma<T, 8, 4>(g, st);
@@ -494,7 +544,8 @@ int sdn_gemm_pick_tile(int M, int N, int K, int act) {
 
 static int sdn_gemm_impl(int dtype, const sdn_gemm_desc* d, const void* a, const void* a2, const void* w,
                          const float* bias, const float* rowbias, const float* rowgate, const void* residual, void* out,
-                         void* stream, void* partials = nullptr, size_t partial_bytes = 0) {
+                         void* stream, void* partials = nullptr, size_t partial_bytes = 0, const float* ln_c = nullptr,
+                         const float* ln_d = nullptr, float ln_eps = 0.f, const float* ln_stats = nullptr) {
   if (!d || !a || !w || !out) return SDN_E_INVALID;
   if (d->M < 0 || d->N <= 0 || d->K <= 0 || (d->K % BK) != 0) return SDN_E_INVALID;
   if (d->M == 0) return SDN_OK;
@@ -544,6 +595,14 @@ static int sdn_gemm_impl(int dtype, const sdn_gemm_desc* d, const void* a, const
     const long res_bytes = res_rows * g.ldc * 2;
     g.res_lds = residual != nullptr && al16(residual) && res_bytes < (1L << 31) && g_gemm_variant != 4;   // variant 4: per-fragment loads (A/B)
     g.res_bytes = g.res_lds ? (unsigned)res_bytes : 0u;
+  }
+  if (ln_c || ln_d) {                                          // LayerNorm-folded form (sdn_gemm_ln_*)
+    if (!ln_c || !ln_d || !al16(ln_c) || !al16(ln_d) || d->a_mode != SDN_A_PLAIN || g.K1 != d->K || bias || rowbias || rowgate ||
+        residual || d->out_kind != SDN_OUT_BF16 || n_valid != d->N || d->split_k > 1 ||
+        (d->act != SDN_ACT_NONE && d->act != SDN_ACT_GEGLU) || (ln_stats && (reinterpret_cast<uintptr_t>(ln_stats) & 7)) ||
+        (ln_stats ? (nrep != 5 && nrep != 4 && nrep != 2) : (nrep != 5 && nrep != 2)))
+      return SDN_E_INVALID;
+    g.ln_c = ln_c; g.ln_d = ln_d; g.ln_eps = ln_eps; g.ln_stats = ln_stats;
   }
   g.dbg = g_gemm_variant >= 16 ? (g_gemm_variant >> 4) : 0;
   g.stamps = g_gemm_stamps;
@@ -601,4 +660,49 @@ extern "C" int sdn_gemm_splitk_f16(const sdn_gemm_desc* d, const void* a, const 
                                    const float* rowbias, const float* rowgate, const void* residual, void* out, void* partials,
                                    size_t partial_bytes, void* stream) {
   return sdn_gemm_impl(1, d, a, a2, w, bias, rowbias, rowgate, residual, out, stream, partials, partial_bytes);
+}
+
+// LayerNorm folded into the GEMM: see k_gemm_dma (LNF).  w_folded = W * gamma per input channel (16 bit), c[n] = sum_k
+// w_folded[n, k], d[n] = sum_k beta[k] W[n, k] + bias[n]  (produced once per weight set by sdn_ln_fold_*).
+extern "C" int sdn_gemm_ln_bf16(const sdn_gemm_desc* d, const void* a, const void* w_folded, const float* c, const float* dvec,
+                                float eps, const float* row_stats, void* out, void* stream) {
+  return sdn_gemm_impl(0, d, a, nullptr, w_folded, nullptr, nullptr, nullptr, nullptr, out, stream, nullptr, 0, c, dvec, eps, row_stats);
+}
+extern "C" int sdn_gemm_ln_f16(const sdn_gemm_desc* d, const void* a, const void* w_folded, const float* c, const float* dvec,
+                               float eps, const float* row_stats, void* out, void* stream) {
+  return sdn_gemm_impl(1, d, a, nullptr, w_folded, nullptr, nullptr, nullptr, nullptr, out, stream, nullptr, 0, c, dvec, eps, row_stats);
+}
+
+// ---- the fold itself: one workgroup per output row n ----
+namespace {
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_ln_fold(const unsigned short* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ beta,
+          const float* __restrict__ bias, int K, unsigned short* __restrict__ wf, float* __restrict__ c, float* __restrict__ dvec) {
+  __shared__ float red[8];
+  const long n = blockIdx.x;
+  float sc = 0.f, sd = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    const float wv = T::to_f(w[n * K + k]);
+    const unsigned r = T::pack2(wv * gamma[k], 0.f) & 0xffffu;        // the rounded value is what the MFMA will see
+    wf[n * K + k] = (unsigned short)r;
+    sc += T::to_f(r);
+    sd = fmaf(beta[k], wv, sd);
+  }
+  sc = block_sum<4>(sc, red);
+  sd = block_sum<4>(sd, red + 4);
+  if (threadIdx.x == 0) { c[n] = sc; dvec[n] = sd + (bias ? bias[n] : 0.f); }
+}
+}  // namespace
+
+extern "C" int sdn_ln_fold(int32_t dtype, const void* w, const float* gamma, const float* beta, const float* bias, int32_t rows,
+                           int32_t cols, void* w_folded, float* c, float* dvec, void* stream) {
+  if (!w || !gamma || !beta || !w_folded || !c || !dvec || rows <= 0 || cols <= 0 || dtype < 0 || dtype > 1) return SDN_E_INVALID;
+  if (dtype == 1)
+    hipLaunchKernelGGL((k_ln_fold<SdnF16>), dim3(rows), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)w, gamma, beta,
+                       bias, cols, (unsigned short*)w_folded, c, dvec);
+  else
+    hipLaunchKernelGGL((k_ln_fold<SdnBF16>), dim3(rows), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)w, gamma, beta,
+                       bias, cols, (unsigned short*)w_folded, c, dvec);
+  return sdn_launch_status();
 }

@@ -229,6 +229,54 @@ k_layernorm(const unsigned short* __restrict__ x, long rows, int C, float eps, c
   }
 }
 
+// Row statistics only (mean, rstd) for the LayerNorm-folded GEMM with wide N: a read-only pass, two-pass variance from
+// registers like k_layernorm.  out [rows][2] f32.
+template <typename T, int NQ, int R>
+__global__ void __launch_bounds__(THREADS)
+k_row_stats(const unsigned short* __restrict__ x, long rows, int C, float eps, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+  if (row0 >= rows) return;
+  const int cchunks = C / 8;
+  float f[R][NQ][8];
+  float s[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    s[r] = 0.f;
+    const long row = row0 + r < rows ? row0 + r : rows - 1;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int cc = lane + q * 64;
+      if (cc < cchunks) {
+        unpack8<T>(*reinterpret_cast<const u32x4*>(x + row * C + cc * 8), f[r][q]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[r] += f[r][q][k];
+      }
+    }
+  }
+  float mean[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) mean[r] = wave_sum(s[r]) / (float)C;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    float ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int cc = lane + q * 64;
+      if (cc < cchunks) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const float d = f[r][q][k] - mean[r]; ss = fmaf(d, d, ss); }
+      }
+    }
+    s[r] = ss;
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const float rstd = rsqrtf(wave_sum(s[r]) / (float)C + eps);
+    if (lane == 0 && row0 + r < rows) *reinterpret_cast<float2*>(out + 2 * (row0 + r)) = make_float2(mean[r], rstd);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // conv_in: direct 3x3 conv, fp32 NCHW latent -> NHWC bf16.  One thread = one pixel x 8 output channels.
 // ------------------------------------------------------------------------------------------------
@@ -449,6 +497,20 @@ int temb_impl(float timestep, int32_t batch, int32_t dim, void* out, void* strea
   return sdn_launch_status();
 }
 
+template <typename T>
+int row_stats_impl(const void* x, int64_t rows, int32_t c, float eps, float* out, void* stream) {
+  if (!x || !out || rows < 0 || c <= 0 || (c & 7) || c > 2048 || !al16(x) || (reinterpret_cast<uintptr_t>(out) & 7)) return SDN_E_INVALID;
+  if (rows == 0) return SDN_OK;
+#define SDN_RS_LAUNCH(NQ, R)                                                                                          \
+  hipLaunchKernelGGL((k_row_stats<T, NQ, R>), dim3((unsigned)((rows + 4 * (R) - 1) / (4 * (R)))), dim3(THREADS), 0,      \
+                     (hipStream_t)stream, (const unsigned short*)x, (long)rows, c, eps, out)
+  if (c <= 512) SDN_RS_LAUNCH(1, 4);
+  else if (c <= 1024) SDN_RS_LAUNCH(2, 2);
+  else SDN_RS_LAUNCH(4, 1);
+#undef SDN_RS_LAUNCH
+  return sdn_launch_status();
+}
+
 }  // namespace sdn_norm_detail
 
 // internal (sdn_ops.h): timestep features with the timestep read from device memory; a one-float store
@@ -493,6 +555,13 @@ using namespace sdn_norm_detail;
   }
 SDN_NORM_ENTRY(bf16, SdnBF16)
 SDN_NORM_ENTRY(f16, SdnF16)
+
+extern "C" int sdn_row_stats_bf16(const void* x, int64_t rows, int32_t c, float eps, float* out, void* stream) {
+  return sdn_norm_detail::row_stats_impl<SdnBF16>(x, rows, c, eps, out, stream);
+}
+extern "C" int sdn_row_stats_f16(const void* x, int64_t rows, int32_t c, float eps, float* out, void* stream) {
+  return sdn_norm_detail::row_stats_impl<SdnF16>(x, rows, c, eps, out, stream);
+}
 
 extern "C" int sdn_unpatchify_f32(const float* tok, int32_t B, int32_t C, int32_t H, int32_t W, int32_t p, float* out,
                                   void* stream) {

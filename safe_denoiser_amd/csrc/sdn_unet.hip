@@ -37,13 +37,15 @@ enum Space { SP_NONE = 0, SP_W = 1, SP_WS = 2, SP_LATENTS = 3, SP_TEXT = 4, SP_O
 struct Ref { int space = SP_NONE; int64_t off = 0; };
 
 enum OpKind { OP_TEMB, OP_CONV_IN, OP_GEMM, OP_GN, OP_LN, OP_ATTN, OP_PATCHIFY, OP_UNPATCHIFY, OP_LATENT_MIX, OP_SOFTMAX,
-              OP_TRANSPOSE, OP_GAUSS, OP_REPEAT, OP_CLIP_EMBED, OP_MATTN };
+              OP_TRANSPOSE, OP_GAUSS, OP_REPEAT, OP_CLIP_EMBED, OP_MATTN, OP_ROWSTATS };
 
 struct Op {
   int kind;
   sdn_gemm_desc gd;
   Ref a, a2, w, bias, rowbias, rowgate, residual, out, aux;
   Ref q2, k2, v2, out2;      // joint attention: second token stream
+  Ref ln_c, ln_d, ln_stats;  // GEMM with LayerNorm folded in (sdn_gemm_ln_*); ln_stats unset = statistics inside the kernel
+  int ln = 0;
   int n1 = 0, mod = 0, ld_mod = 0, patch = 0;
   // GN / LN / conv_in / attention scalars
   int batch = 0, hw = 0, c1 = 0, c2 = 0, groups = 0, silu = 0;
@@ -134,6 +136,9 @@ struct sdn_unet {
   bool profile_next = false;
   // graph mode (sdn_unet_set_graph_mode): one captured hipGraph per (batch, operand addresses); replays cost one launch
   bool use_graph = false;
+  bool ln_fold = true;                  // BasicTransformerBlock LayerNorms folded into their consumer GEMMs where it pays
+  struct FoldJob { int64_t w, gamma, beta, bias, wf, c, d; int rows, cols; };
+  std::vector<FoldJob> fold_jobs;       // what sdn_unet_prepare has to compute into the SDN_P_DERIVED regions
   bool split_k = false;                 // sdn_unet_set_split_k: small-M GEMMs of the plan take the split-K form (off by
                                         // default: it changes fp32 summation order with the batch size, and batch rows are
                                         // otherwise bit-identical whatever the batch)
@@ -259,6 +264,42 @@ struct Builder {
     snprintf(o.label, sizeof(o.label), "k_layernorm");
     plan->ops.push_back(o);
   }
+  // LayerNorm(x; gamma, beta) -> GEMM(W, bias) with the norm folded into the GEMM (sdn_gemm_ln_*).  Registers the derived
+  // weight regions once; `prepass` = row statistics from a read-only pass instead of inside the kernel (wide N).
+  Ref derived(const std::string& name, int64_t bytes) {
+    auto it = u->param_index.find(name);
+    if (it != u->param_index.end()) return Ref{SP_W, u->params[it->second].offset};
+    sdn_param_info pi; memset(&pi, 0, sizeof(pi));
+    snprintf(pi.name, sizeof(pi.name), "%s", name.c_str());
+    pi.kind = SDN_P_DERIVED; pi.rows = (int)bytes; pi.cols = 0; pi.rows_padded = (int)bytes;
+    pi.offset = u->weight_bytes;
+    u->weight_bytes += (bytes + 255) & ~(int64_t)255;
+    u->param_index[name] = (int)u->params.size();
+    u->params.push_back(pi);
+    return Ref{SP_W, pi.offset};
+  }
+  void gemm_ln(const Act& x, int64_t rows, int N, int K, const std::string& wname, Ref w, Ref gamma, Ref beta, Ref bias,
+               Ref out, int act_, bool prepass) {
+    const bool fresh = u->param_index.find(wname + "#ln") == u->param_index.end();
+    Ref wf = derived(wname + "#ln", (int64_t)N * K * 2), c = derived(wname + "#ln_c", (int64_t)N * 4), d = derived(wname + "#ln_d", (int64_t)N * 4);
+    if (fresh) u->fold_jobs.push_back({w.off, gamma.off, beta.off, bias.space == SP_NONE ? -1 : bias.off, wf.off, c.off, d.off, N, K});
+    Act st;
+    if (prepass) {
+      st = act(rows, 2, 0, 0, 4);
+      Op o; o.kind = OP_ROWSTATS; o.a = R(x); o.rows = rows; o.c1 = K; o.eps = 1e-5f; o.out = R(st);
+      o.bytes = 2.0 * rows * K; snprintf(o.label, sizeof(o.label), "k_row_stats"); plan->ops.push_back(o);
+    }
+    Op o; o.kind = OP_GEMM; memset(&o.gd, 0, sizeof(o.gd));
+    o.gd.M = (int)rows; o.gd.N = N; o.gd.K = K; o.gd.a_mode = SDN_A_PLAIN; o.gd.act = act_; o.gd.out_kind = SDN_OUT_BF16;
+    o.a = R(x); o.w = wf; o.out = out; o.ln = 1; o.ln_c = c; o.ln_d = d; o.eps = 1e-5f;
+    if (prepass) o.ln_stats = R(st);
+    o.flops = 2.0 * (double)rows * N * K;
+    o.bytes = 2.0 * ((double)rows * K + (double)N * K + (double)rows * (act_ == SDN_ACT_GEGLU ? N / 2 : N));
+    snprintf(o.label, sizeof(o.label), "k_gemm<%d>/ln", sdn_gemm_pick_tile((int)rows, N, K, act_));
+    plan->ops.push_back(o);
+    plan->flops += o.flops;
+    if (prepass) drop(st);
+  }
   void repeat(const Act& in, const Act& out, int rep) {          // out = cat([in] * rep) along the batch
     Op o; o.kind = OP_REPEAT; o.a = R(in); o.out = R(out); o.rows = in.bytes; o.c1 = rep;
     o.bytes = (double)in.bytes * (1 + rep);
@@ -359,11 +400,20 @@ struct Builder {
     Act h = act(rows, C, hw, x.side);
     gemm(rows, C, C, R(gn), piw, pib, R(h));
     drop(gn);
+    // LayerNorm folding (gemm_ln): measured per shape (tools/bench_lnfold.py) -- it pays at C = 320 / 640 for the
+    // attention projections (statistics inside the kernel while N <= 960, from a read-only pre-pass above) and at
+    // C = 320 for the GEGLU projection; the wide, MFMA-bound projections of the lower levels keep the LayerNorm kernel.
+    const bool fold12 = u->ln_fold && C <= 640, fold3 = u->ln_fold && C == 320;
     // self-attention
-    Act ln = act(rows, C, hw, x.side);
-    layernorm(h, l1g, l1b, ln);
+    Act ln;
+    if (!fold12 || !fold3) ln = act(rows, C, hw, x.side);
     Act qkvb = act(rows, 3 * C, hw, x.side);
-    gemm(rows, 3 * C, C, R(ln), qkv, Ref(), R(qkvb));
+    if (fold12) {
+      gemm_ln(h, rows, 3 * C, C, tb + ".attn1.to_q.weight", qkv, l1g, l1b, Ref(), R(qkvb), SDN_ACT_NONE, 3 * C > 960);
+    } else {
+      layernorm(h, l1g, l1b, ln);
+      gemm(rows, 3 * C, C, R(ln), qkv, Ref(), R(qkvb));
+    }
     Act at = act(rows, C, hw, x.side);
     attention(R(qkvb), Ref{SP_WS, qkvb.off + (int64_t)C * 2}, Ref{SP_WS, qkvb.off + (int64_t)2 * C * 2}, R(at), hw, hw, C,
               3 * C, 3 * C, 3 * C);
@@ -372,17 +422,23 @@ struct Builder {
     gemm(rows, C, C, R(at), o1w, o1b, R(h2), SDN_ACT_NONE, R(h));
     drop(h);
     // cross-attention
-    layernorm(h2, l2g, l2b, ln);
     Act qb = act(rows, C, hw, x.side);
-    gemm(rows, C, C, R(ln), q2w, Ref(), R(qb));
+    if (fold12) {
+      gemm_ln(h2, rows, C, C, tb + ".attn2.to_q.weight", q2w, l2g, l2b, Ref(), R(qb), SDN_ACT_NONE, false);
+    } else {
+      layernorm(h2, l2g, l2b, ln);
+      gemm(rows, C, C, R(ln), q2w, Ref(), R(qb));
+    }
     if (rep > 1) {                                 // from here on the branches differ (their text does)
-      drop(ln); drop(at);
+      if (ln.off >= 0) drop(ln);
+      drop(at);
       B = Bfull; rows = (int64_t)B * hw;
       Act h2f = act(rows, C, hw, x.side), qbf = act(rows, C, hw, x.side);
       repeat(h2, h2f, rep); repeat(qb, qbf, rep);
       drop(h2); drop(qb);
       h2 = h2f; qb = qbf;
-      ln = act(rows, C, hw, x.side); at = act(rows, C, hw, x.side);
+      if (!fold3) ln = act(rows, C, hw, x.side);
+      at = act(rows, C, hw, x.side);
     }
     Act kvb = act((int64_t)B * T, 2 * C);
     gemm((int64_t)B * T, 2 * C, X, Ref{SP_TEXT, text_off}, kv2, Ref(), R(kvb));
@@ -392,10 +448,14 @@ struct Builder {
     gemm(rows, C, C, R(at), o2w, o2b, R(h3), SDN_ACT_NONE, R(h2));
     drop(h2); drop(at);
     // GEGLU feed-forward
-    layernorm(h3, l3g, l3b, ln);
     Act ff = act(rows, 4 * C, hw, x.side);
-    gemm(rows, 8 * C, C, R(ln), f1w, f1b, R(ff), SDN_ACT_GEGLU);
-    drop(ln);
+    if (fold3) {
+      gemm_ln(h3, rows, 8 * C, C, tb + ".ff.net.0.proj.weight", f1w, l3g, l3b, f1b, R(ff), SDN_ACT_GEGLU, true);
+    } else {
+      layernorm(h3, l3g, l3b, ln);
+      gemm(rows, 8 * C, C, R(ln), f1w, f1b, R(ff), SDN_ACT_GEGLU);
+    }
+    if (ln.off >= 0) drop(ln);
     Act h4 = act(rows, C, hw, x.side);
     gemm(rows, C, 4 * C, R(ff), f2w, f2b, R(h4), SDN_ACT_NONE, R(h3));
     drop(ff); drop(h3);
@@ -1153,6 +1213,19 @@ int sdn_clip_create(const sdn_clip_config* cfg, sdn_unet** out) {
 int sdn_clip_forward(sdn_unet* m, const void* weights, const int32_t* input_ids, const int32_t* attention_mask,
                      void* last_hidden_state, int32_t batch, void* workspace, size_t workspace_bytes, void* stream);
 
+int sdn_unet_prepare(sdn_unet* u, void* weights, void* stream) {
+  if (!u || !weights) return SDN_E_INVALID;
+  char* W = (char*)weights;
+  const int dt = (u->is_mmdit ? u->mcfg.dtype : u->cfg.dtype) == 1 ? 1 : 0;
+  for (const auto& j : u->fold_jobs) {
+    const int rc = sdn_ln_fold(dt, W + j.w, (const float*)(W + j.gamma), (const float*)(W + j.beta),
+                               j.bias >= 0 ? (const float*)(W + j.bias) : nullptr, j.rows, j.cols, W + j.wf, (float*)(W + j.c),
+                               (float*)(W + j.d), stream);
+    if (rc != SDN_OK) return rc;
+  }
+  return SDN_OK;
+}
+
 void sdn_unet_destroy(sdn_unet* u) { delete u; }
 
 int sdn_unet_param_count(const sdn_unet* u) { return u ? (int)u->params.size() : 0; }
@@ -1245,7 +1318,15 @@ static int launch_ops(sdn_unet* u, Plan* p, const char* W, const char* WS, const
         rc = (f16 ? sdn_conv_in_f16 : sdn_conv_in_bf16)((const float*)P(o.a), P(o.w), (const float*)P(o.bias), o.batch, o.c1, o.hw, o.hw, o.c2,
                               (void*)P(o.out), stream);
         break;
+      case OP_ROWSTATS:
+        rc = (f16 ? sdn_row_stats_f16 : sdn_row_stats_bf16)(P(o.a), o.rows, o.c1, o.eps, (float*)P(o.out), stream);
+        break;
       case OP_GEMM:
+        if (o.ln) {
+          rc = (f16 ? sdn_gemm_ln_f16 : sdn_gemm_ln_bf16)(&o.gd, P(o.a), P(o.w), (const float*)P(o.ln_c), (const float*)P(o.ln_d), o.eps,
+                                                          (const float*)P(o.ln_stats), (void*)P(o.out), stream);
+          break;
+        }
         if (o.gd.split_k > 1) {
           rc = (f16 ? sdn_gemm_splitk_f16 : sdn_gemm_splitk_bf16)(&o.gd, P(o.a), P(o.a2), P(o.w), (const float*)P(o.bias),
                                                                   (const float*)P(o.rowbias), (const float*)P(o.rowgate), P(o.residual),
@@ -1383,6 +1464,15 @@ void sdn_unet_set_graph_mode(sdn_unet* u, int32_t on) {
 }
 
 // Undeclared tuning hook (tools/): size threshold of the transformer sub-batching; rebuilds the plans.
+// Undeclared A/B hook: run the BasicTransformerBlock LayerNorms as separate kernels again (the derived regions stay).
+extern "C" void sdn_debug_set_ln_fold(sdn_unet* u, int on) {
+  if (!u) return;
+  u->ln_fold = on != 0;
+  u->plans.clear();
+  for (auto& kv : u->graphs) (void)hipGraphExecDestroy(kv.second);
+  u->graphs.clear();
+}
+
 extern "C" void sdn_debug_set_subbatch_bytes(sdn_unet* u, long long bytes) {
   if (!u || u->is_mmdit) return;
   u->subbatch_bytes = bytes;

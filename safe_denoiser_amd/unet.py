@@ -22,6 +22,7 @@ SD14_CONFIG = dict(in_channels=4, out_channels=4, sample_size=64, block_out_chan
                    layers_per_block=2, attention_head_dim=8, cross_attention_dim=768, norm_num_groups=32)
 
 P_VEC_F32, P_MAT, P_CONV3X3, P_GEGLU_MAT, P_GEGLU_VEC = 0, 1, 2, 3, 4
+P_DERIVED = 6      # regions the engine fills itself (sdn_unet_prepare): not state_dict tensors
 
 
 class UNetOutput:
@@ -69,13 +70,25 @@ class UNet2DConditionModel:
         self._h = h
         self._weights = None
         self._ws = {}
+        self._read_manifest()
+
+    def _read_manifest(self):
+        """diffusers-keyed tensors -> self.manifest; engine-derived regions (SDN_P_DERIVED) are left to _prepare()."""
+        h = self._h
         self.manifest = []
         info = _lib.ParamInfo()
         for i in range(_lib.lib().sdn_unet_param_count(h)):
             _lib.check(_lib.lib().sdn_unet_param_info(h, i, C.byref(info)), "sdn_unet_param_info")
+            if info.kind == P_DERIVED:
+                continue
             self.manifest.append(dict(name=info.name.decode(), kind=info.kind, rows=info.rows, cols=info.cols,
                                       rows_padded=info.rows_padded, offset=info.offset))
         self.weight_bytes = _lib.lib().sdn_unet_weight_bytes(h)
+
+    def _prepare(self):
+        """Let the engine fill its derived weight regions (LayerNorm-folded projections) from the uploaded tensors."""
+        _lib.check(_lib.lib().sdn_unet_prepare(self._h, _lib.dptr(self._weights), _lib.stream_ptr()), "sdn_unet_prepare")
+        return self
 
     def __del__(self):
         try:
@@ -152,7 +165,7 @@ class UNet2DConditionModel:
             raise KeyError(f"state_dict lacks {len(missing)} keys, e.g. {missing[:3]}")
         _lib.require_gpu()
         self._weights = self.pack_state_dict(sd).to(device)
-        return self
+        return self._prepare()
 
     def load_synthetic_on_device(self, seed: int = 1234, device="cuda"):
         """Random weights generated DIRECTLY in the packed engine layout on the GPU (benchmarks: no checkpoints exist
@@ -173,7 +186,7 @@ class UNet2DConditionModel:
                 t = ((torch.rand(n, generator=g, device=device) * 2 - 1) * (3.0 / max(p["cols"], 1)) ** 0.5).to(self.dtype)
                 buf[p["offset"]:p["offset"] + 2 * n] = t.view(torch.uint8)
         self._weights = buf
-        return self
+        return self._prepare()
 
     # ---- forward --------------------------------------------------------------------------------------
     def flops(self, batch: int):

@@ -169,6 +169,32 @@ def test_split_k_rejects_what_it_cannot_do():
     assert sda.lib().sdn_gemm_bf16(C.byref(d), a.data_ptr(), None, w.data_ptr(), None, None, None, None, o.data_ptr(), _lib.stream_ptr()) != 0
 
 
+@pytest.mark.parametrize("M,N,K,geglu", [(300, 320, 320, False), (1000, 960, 640, False), (4096, 3840, 1280, False),
+                                         (520, 2560, 320, True), (2048, 5120, 640, True), (64, 640, 640, False)])
+def test_layernorm_folded_into_gemm(M, N, K, geglu):
+    """sdn_ln_fold + sdn_gemm_ln_*: LayerNorm never materialised.  Reference = torch layer_norm (fp32) then the linear
+    with the 16-bit weights; rows get a large common offset to exercise the mean cancellation."""
+    g = torch.Generator().manual_seed(70)
+    x = (rnd(M, K, seed=71) * 1.5 + torch.randn(M, 1, generator=g) * 2.0).to(BF)
+    w = rnd(N, K, seed=72, scale=K ** -0.5)
+    gamma = 1 + 0.2 * torch.randn(K, generator=g); beta = 0.3 * torch.randn(K, generator=g)
+    bias = torch.randn(N, generator=g)
+    y = F.linear(F.layer_norm(x.float(), (K,), gamma, beta, 1e-5), w.float(), bias)
+    if geglu:
+        from safe_denoiser_amd.unet import _interleave16
+        ref = y[:, :N // 2] * F.gelu(y[:, N // 2:])
+        out = ops.gemm_ln(x.cuda(), _interleave16(w).contiguous().cuda(), gamma.cuda(), beta.cuda(),
+                          _interleave16(bias).contiguous().cuda(), act=2, prepass=True)
+    else:
+        ref = y
+        out = ops.gemm_ln(x.cuda(), w.cuda(), gamma.cuda(), beta.cuda(), bias.cuda(), prepass=N > 640)
+        check_bf16(ops.gemm_ln(x.cuda(), w.cuda(), gamma.cuda(), beta.cuda(), bias.cuda(), prepass=True), ref, tol=6e-3)
+    check_bf16(out, ref, tol=6e-3)
+    if not geglu:                                                    # no bias: d = sum_k beta W only
+        out0 = ops.gemm_ln(x.cuda(), w.cuda(), gamma.cuda(), beta.cuda(), None, prepass=N > 640)
+        check_bf16(out0, y - bias, tol=6e-3)
+
+
 def test_conv_out_padded_n_to_f32_nchw():
     B, H, Cin, Cout = 2, 16, 320, 4
     x = rnd(B, Cin, H, H, seed=18)

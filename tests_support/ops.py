@@ -86,3 +86,24 @@ def attention(q, k, v, heads, scale=None):
                                             d, q.stride(1), k.stride(1), v.stride(1), c, scale, _lib.stream_ptr()),
                "sdn_attention_bf16")
     return out
+
+
+def gemm_ln(x, w, gamma, beta, bias=None, act=0, eps=1e-5, prepass=False):
+    """LayerNorm(x; gamma, beta) . w^T + bias [GEGLU] through sdn_ln_fold + sdn_gemm_ln_* (w [N, K] 16-bit, already in the
+    layout the kernel expects -- interleaved for GEGLU)."""
+    N, K = w.shape
+    M = x.shape[0]
+    code = 1 if x.dtype == torch.float16 else 0
+    wf = torch.empty_like(w)
+    c = torch.empty(N, dtype=torch.float32, device=x.device); dv = torch.empty_like(c)
+    p = lambda t: None if t is None else t.data_ptr()
+    _lib.check(sda.lib().sdn_ln_fold(code, p(w), p(gamma), p(beta), p(bias), N, K, p(wf), p(c), p(dv), _lib.stream_ptr()), "sdn_ln_fold")
+    d = _lib.GemmDesc()
+    d.M, d.N, d.K, d.act = M, N, K, act
+    out = torch.empty((M, N // 2 if act == 2 else N), dtype=x.dtype, device=x.device)
+    stats = None
+    if prepass:
+        stats = torch.empty(M, 2, dtype=torch.float32, device=x.device)
+        _lib.check(_fn("row_stats", x)(p(x), M, K, eps, p(stats), _lib.stream_ptr()), "sdn_row_stats")
+    _lib.check(_fn("gemm_ln", x)(C.byref(d), p(x), p(wf), p(c), p(dv), eps, p(stats), p(out), _lib.stream_ptr()), "sdn_gemm_ln")
+    return out

@@ -24,6 +24,9 @@ for p in u.manifest:
         t = ((torch.rand(n, generator=g, device="cuda") * 2 - 1) * (3.0 / max(p["cols"], 1)) ** 0.5).bfloat16()
         buf[p["offset"]:p["offset"] + 2 * n] = t.view(torch.uint8)
 u._weights = buf
+u._prepare()
+if os.environ.get("LN_FOLD") == "0":
+    sda.lib().sdn_debug_set_ln_fold(u._h, 0)
 if os.environ.get("SPLIT_K"):
     u.set_split_k(True)
 if os.environ.get("SUBBATCH") is not None:
