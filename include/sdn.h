@@ -374,6 +374,21 @@ int sdn_gemm_ln_f16(const sdn_gemm_desc* desc, const void* a, const void* w_fold
 int sdn_row_stats_bf16(const void* x, int64_t rows, int32_t c, float eps, float* out, void* stream);
 int sdn_row_stats_f16(const void* x, int64_t rows, int32_t c, float eps, float* out, void* stream);
 
+/* GroupNorm statistics without a pass over the tensor: the GEMM that PRODUCES a GroupNorm input also emits, per block of
+ * 128 output rows and per column, the (sum, sum of squares) of the 16-bit values it stores -- col_stats [ceil(M/128)][N][2]
+ * f32 (sdn_gemm_stats_*: 16-bit output, n_valid == N, no GEGLU, no rowgate) -- and sdn_groupnorm_cols_* reduces those
+ * instead of reading x (hw % 128 == 0; x2 / cols2 = the second tensor of a channel concat, each with its own partials). */
+int sdn_gemm_stats_bf16(const sdn_gemm_desc* desc, const void* a, const void* a2, const void* w, const float* bias,
+                        const float* rowbias, const void* residual, void* out, float* col_stats, void* stream);
+int sdn_gemm_stats_f16(const sdn_gemm_desc* desc, const void* a, const void* a2, const void* w, const float* bias,
+                       const float* rowbias, const void* residual, void* out, float* col_stats, void* stream);
+int sdn_groupnorm_cols_bf16(const void* x, const void* x2, int32_t batch, int32_t hw, int32_t c1, int32_t c2, int32_t groups,
+                            float eps, int32_t silu, const float* gamma, const float* beta, void* out, float* stats_ws,
+                            const float* cols1, const float* cols2, void* stream);
+int sdn_groupnorm_cols_f16(const void* x, const void* x2, int32_t batch, int32_t hw, int32_t c1, int32_t c2, int32_t groups,
+                           float eps, int32_t silu, const float* gamma, const float* beta, void* out, float* stats_ws,
+                           const float* cols1, const float* cols2, void* stream);
+
 /* Split-K form for small M / long K (one-prompt batches: 8-20 tiles for 256 CUs): the k loop is cut into desc->split_k
  * slices, each writes an fp32 partial [M, N] into `partials` (>= split_k * M * N * 4 bytes), and a second kernel sums
  * them in a fixed order and applies the epilogue.  16-bit outputs, any activation but GEGLU, n_valid == N. */

@@ -40,7 +40,9 @@ struct GemmArgs {
   int a_mode, Hs, Ws, Cin, Ho, Wo, stride, upsample, conv_off;
   int act, out_kind, rows_per_batch, ld_rowbias, ld_rowgate, residual_bcast, n_valid, ldc;
   int tiles_m, tiles_n;
-  const float* ln_c; const float* ln_d; float ln_eps; const float* ln_stats;   // LNF kernels: LayerNorm folded into this GEMM (see k_gemm_dma)
+  const float* ln_c; const float* ln_d; float ln_eps; const float* ln_stats;
+  float* col_stats;          // per 128-row block and output column: (sum, sum of squares) of the stored 16-bit values, for the
+                             // GroupNorm that consumes this tensor (sdn_gemm_stats_* / sdn_groupnorm_cols_*); nullptr = off   // LNF kernels: LayerNorm folded into this GEMM (see k_gemm_dma)
   int kt_per_split;          // split-K: k-tiles per blockIdx.y slice (0 = no split); each slice writes its own fp32 partial
   long split_stride;         // bytes between the partial outputs of consecutive slices
   int res_lds;               // residual goes through the LDS staging slab (16-bit staged output, offsets fit 31 bits)
@@ -545,7 +547,7 @@ int sdn_gemm_pick_tile(int M, int N, int K, int act) {
 static int sdn_gemm_impl(int dtype, const sdn_gemm_desc* d, const void* a, const void* a2, const void* w,
                          const float* bias, const float* rowbias, const float* rowgate, const void* residual, void* out,
                          void* stream, void* partials = nullptr, size_t partial_bytes = 0, const float* ln_c = nullptr,
-                         const float* ln_d = nullptr, float ln_eps = 0.f, const float* ln_stats = nullptr) {
+                         const float* ln_d = nullptr, float ln_eps = 0.f, const float* ln_stats = nullptr, float* col_stats = nullptr) {
   if (!d || !a || !w || !out) return SDN_E_INVALID;
   if (d->M < 0 || d->N <= 0 || d->K <= 0 || (d->K % BK) != 0) return SDN_E_INVALID;
   if (d->M == 0) return SDN_OK;
@@ -595,6 +597,12 @@ static int sdn_gemm_impl(int dtype, const sdn_gemm_desc* d, const void* a, const
     const long res_bytes = res_rows * g.ldc * 2;
     g.res_lds = residual != nullptr && al16(residual) && res_bytes < (1L << 31) && g_gemm_variant != 4;   // variant 4: per-fragment loads (A/B)
     g.res_bytes = g.res_lds ? (unsigned)res_bytes : 0u;
+  }
+  if (col_stats) {                                              // column statistics ride on the staged 16-bit tile
+    if (d->out_kind != SDN_OUT_BF16 || n_valid != d->N || d->act == SDN_ACT_GEGLU || d->split_k > 1 ||
+        (reinterpret_cast<uintptr_t>(col_stats) & 7))
+      return SDN_E_INVALID;
+    g.col_stats = col_stats;
   }
   if (ln_c || ln_d) {                                          // LayerNorm-folded form (sdn_gemm_ln_*)
     if (!ln_c || !ln_d || !al16(ln_c) || !al16(ln_d) || d->a_mode != SDN_A_PLAIN || g.K1 != d->K || bias || rowbias || rowgate ||
@@ -649,6 +657,20 @@ extern "C" int sdn_gemm_bf16(const sdn_gemm_desc* d, const void* a, const void* 
 extern "C" int sdn_gemm_f16(const sdn_gemm_desc* d, const void* a, const void* a2, const void* w, const float* bias,
                             const float* rowbias, const float* rowgate, const void* residual, void* out, void* stream) {
   return sdn_gemm_impl(1, d, a, a2, w, bias, rowbias, rowgate, residual, out, stream);
+}
+
+// GEMM that also emits, per block of 128 output rows and per column, the (sum, sum of squares) of the 16-bit values it
+// stores: col_stats [ceil(M / 128)][N][2] f32.  The GroupNorm over this tensor (sdn_groupnorm_cols_*) then needs no pass of
+// its own for the statistics.  16-bit output, n_valid == N, no GEGLU.
+extern "C" int sdn_gemm_stats_bf16(const sdn_gemm_desc* d, const void* a, const void* a2, const void* w, const float* bias,
+                                   const float* rowbias, const void* residual, void* out, float* col_stats, void* stream) {
+  if (!col_stats) return SDN_E_INVALID;
+  return sdn_gemm_impl(0, d, a, a2, w, bias, rowbias, nullptr, residual, out, stream, nullptr, 0, nullptr, nullptr, 0.f, nullptr, col_stats);
+}
+extern "C" int sdn_gemm_stats_f16(const sdn_gemm_desc* d, const void* a, const void* a2, const void* w, const float* bias,
+                                  const float* rowbias, const void* residual, void* out, float* col_stats, void* stream) {
+  if (!col_stats) return SDN_E_INVALID;
+  return sdn_gemm_impl(1, d, a, a2, w, bias, rowbias, nullptr, residual, out, stream, nullptr, 0, nullptr, nullptr, 0.f, nullptr, col_stats);
 }
 
 extern "C" int sdn_gemm_splitk_bf16(const sdn_gemm_desc* d, const void* a, const void* a2, const void* w, const float* bias,

@@ -109,6 +109,35 @@ k_gn_finalize(const float* __restrict__ partials, int ntiles, int groups, float 
   }
 }
 
+// Statistics from the per-column partials the producing GEMMs left behind (sdn_gemm_stats_*): cols [hw/128 blocks of the
+// sample][c][2] = (sum, sum of squares) per 128-row block.  One workgroup per sample: a thread sums one channel over the
+// sample's blocks, then the channels of a group are combined through LDS.  Same output as k_gn_finalize.
+__global__ void __launch_bounds__(512)
+k_gn_finalize_cols(const float* __restrict__ cols1, const float* __restrict__ cols2, int blocks_per_sample, int c1, int c2,
+                   int groups, float n, float eps, float* __restrict__ stats) {
+  extern __shared__ float shc[];                 // [C][2]
+  const int C = c1 + c2, b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += 512) {
+    const bool second = c >= c1;
+    const float* src = second ? cols2 : cols1;
+    const int cw = second ? c2 : c1, cc = second ? c - c1 : c;
+    const float* p = src + 2 * ((long)b * blocks_per_sample * cw + cc);
+    float s = 0.f, q = 0.f;
+    for (int t = 0; t < blocks_per_sample; ++t) { const float2 v = *reinterpret_cast<const float2*>(p + 2 * (long)t * cw); s += v.x; q += v.y; }
+    shc[2 * c] = s; shc[2 * c + 1] = q;
+  }
+  __syncthreads();
+  const int cpg = C / groups;
+  for (int gi = threadIdx.x; gi < groups; gi += 512) {
+    float s = 0.f, q = 0.f;
+    for (int k = 0; k < cpg; ++k) { s += shc[2 * (gi * cpg + k)]; q += shc[2 * (gi * cpg + k) + 1]; }
+    const float mean = s / n;
+    const float var = fmaxf(q / n - mean * mean, 0.f);
+    stats[((long)b * groups + gi) * 2 + 0] = mean;
+    stats[((long)b * groups + gi) * 2 + 1] = rsqrtf(var + eps);
+  }
+}
+
 // GroupNorm pass 2: normalise + affine (+SiLU), write the (concatenated) map.
 template <typename T>
 __global__ void __launch_bounds__(THREADS)
@@ -367,7 +396,7 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 template <typename T>
 int groupnorm_impl(const void* x, const void* x2, int32_t batch, int32_t hw, int32_t c1, int32_t c2, int32_t groups,
                    float eps, int32_t silu, const float* gamma, const float* beta, void* out, float* stats_ws,
-                   void* stream) {
+                   void* stream, const float* cols1 = nullptr, const float* cols2 = nullptr) {
   if (!x || !gamma || !beta || !out || !stats_ws || batch < 0 || hw <= 0 || c1 <= 0 || c2 < 0 || groups <= 0 ||
       groups > 64)
     return SDN_E_INVALID;
@@ -389,11 +418,17 @@ int groupnorm_impl(const void* x, const void* x2, int32_t batch, int32_t hw, int
   hipStream_t st = (hipStream_t)stream;
   const size_t lds = (size_t)rt * C * 2 * sizeof(float);
   if (lds > 64 * 1024) return SDN_E_INVALID;
-  float* partials = stats_ws + (size_t)batch * groups * 2;          // [B][ntiles][G][2] after the final stats
-  hipLaunchKernelGGL((k_gn_stats<T>), dim3(batch, ntiles), dim3(THREADS), lds, st, (const unsigned short*)x,
-                     (const unsigned short*)x2, hw, c1, c2, groups, rows_per_tile, ct, nch, partials);
-  hipLaunchKernelGGL(k_gn_finalize, dim3(batch), dim3(512), 0, st, partials, ntiles, groups,
-                     (float)hw * (float)(C / groups), eps, stats_ws);
+  if (cols1) {                                // statistics from the producers' column partials: no pass over x
+    if ((hw & 127) || (c2 > 0 && !cols2)) return SDN_E_INVALID;
+    hipLaunchKernelGGL(k_gn_finalize_cols, dim3(batch), dim3(512), (size_t)2 * C * sizeof(float), st, cols1, cols2, hw / 128, c1,
+                       c2, groups, (float)hw * (float)(C / groups), eps, stats_ws);
+  } else {
+    float* partials = stats_ws + (size_t)batch * groups * 2;          // [B][ntiles][G][2] after the final stats
+    hipLaunchKernelGGL((k_gn_stats<T>), dim3(batch, ntiles), dim3(THREADS), lds, st, (const unsigned short*)x,
+                       (const unsigned short*)x2, hw, c1, c2, groups, rows_per_tile, ct, nch, partials);
+    hipLaunchKernelGGL(k_gn_finalize, dim3(batch), dim3(512), 0, st, partials, ntiles, groups,
+                       (float)hw * (float)(C / groups), eps, stats_ws);
+  }
   int rows_per_block = (256 * 8 * 16) / C;    // ~16 chunks per thread (amortises the per-workgroup affine table)
   if (rows_per_block < 1) rows_per_block = 1;
   const int nblk = (hw + rows_per_block - 1) / rows_per_block;
@@ -532,6 +567,14 @@ using namespace sdn_norm_detail;
                                      int32_t groups, float eps, int32_t silu, const float* gamma, const float* beta,   \
                                      void* out, float* stats_ws, void* stream) {                                        \
     return groupnorm_impl<T>(x, x2, batch, hw, c1, c2, groups, eps, silu, gamma, beta, out, stats_ws, stream);         \
+  }                                                                                                                     \
+  extern "C" int sdn_groupnorm_cols_##SUF(const void* x, const void* x2, int32_t batch, int32_t hw, int32_t c1,         \
+                                          int32_t c2, int32_t groups, float eps, int32_t silu, const float* gamma,      \
+                                          const float* beta, void* out, float* stats_ws, const float* cols1,            \
+                                          const float* cols2, void* stream) {                                           \
+    if (!cols1) return SDN_E_INVALID;                                                                                   \
+    return groupnorm_impl<T>(x, x2, batch, hw, c1, c2, groups, eps, silu, gamma, beta, out, stats_ws, stream, cols1,    \
+                             cols2);                                                                                    \
   }                                                                                                                     \
   extern "C" int sdn_layernorm_##SUF(const void* x, int64_t rows, int32_t c, float eps, const float* gamma,            \
                                      const float* beta, void* out, void* stream) {                                      \

@@ -195,6 +195,50 @@ def test_layernorm_folded_into_gemm(M, N, K, geglu):
         check_bf16(out0, y - bias, tol=6e-3)
 
 
+def test_groupnorm_statistics_from_the_producing_gemms():
+    """sdn_gemm_stats_* + sdn_groupnorm_cols_*: the GEMMs that write a GroupNorm's inputs also leave per-128-row-block column
+    sums, and the GroupNorm reduces those instead of reading the tensors.  Checked on a channel concat of a conv output
+    (256-row tile, two staging passes) and a linear output with residual (128-row tile), against the plain GroupNorm of
+    the very same tensors (bit-for-bit inputs) and torch."""
+    B, H = 3, 16                                                      # hw = 256 = two 128-row blocks per sample
+    hw, M = H * H, B * H * H
+    x = rnd(B, 640, H, H, seed=81); wc = rnd(320, 640, 3, 3, seed=82, scale=(9 * 640) ** -0.5)
+    bias = torch.randn(320, generator=torch.Generator().manual_seed(83))
+    xn = x.permute(0, 2, 3, 1).contiguous().cuda(); wn = wc.permute(0, 2, 3, 1).reshape(320, 9 * 640).contiguous().cuda()
+    cols1 = torch.zeros(M // 128, 320, 2, device="cuda")
+    y1 = ops.gemm(xn, wn, bias=bias.cuda(), conv=dict(Hs=H, Ws=H, Cin=640, Ho=H, Wo=H), col_stats=cols1)
+    a = rnd(M, 320, seed=84); w2 = rnd(640, 320, seed=85, scale=320 ** -0.5); res = rnd(M, 640, seed=86)
+    cols2 = torch.zeros(M // 128, 640, 2, device="cuda")
+    y2 = ops.gemm(a.cuda(), w2.cuda(), residual=res.cuda(), col_stats=cols2)
+    # the partials are exactly the column sums of the stored values
+    ref1 = y1.float().reshape(M // 128, 128, 320)
+    torch.testing.assert_close(cols1[..., 0], ref1.sum(1), rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(cols1[..., 1], (ref1 * ref1).sum(1), rtol=1e-5, atol=1e-3)
+    gamma = (1 + 0.1 * torch.randn(960, generator=torch.Generator().manual_seed(87))).cuda()
+    beta = (0.1 * torch.randn(960, generator=torch.Generator().manual_seed(88))).cuda()
+    g_plain = ops.groupnorm(y1.reshape(B, hw, 320), y2.reshape(B, hw, 640), 32, 1e-5, 1, gamma, beta)
+    g_cols = ops.groupnorm(y1.reshape(B, hw, 320), y2.reshape(B, hw, 640), 32, 1e-5, 1, gamma, beta, cols1=cols1, cols2=cols2)
+    assert rel_l2(g_cols, g_plain) <= 1e-3
+    full = torch.cat([y1.reshape(B, hw, 320), y2.reshape(B, hw, 640)], 2).float().cpu().permute(0, 2, 1)
+    ref = F.silu(F.group_norm(full, 32, gamma.cpu(), beta.cpu(), 1e-5)).permute(0, 2, 1)
+    check_bf16(g_cols, ref)
+    # the 256 x 320 tile (two staging passes per workgroup; chosen for long k loops on big grids): partials vs the column
+    # sums of the tensor it stored, plus a ragged M tail
+    for Bb, Hh in ((48, 32), (47, 32)):
+        Mb = Bb * Hh * Hh
+        xb = torch.randn(Bb, Hh, Hh, 256, device="cuda").to(BF)
+        wb = (torch.randn(320, 9 * 256, device="cuda") * (9 * 256) ** -0.5).to(BF)
+        cb = torch.zeros((Mb + 127) // 128, 320, 2, device="cuda")
+        yb = ops.gemm(xb, wb, conv=dict(Hs=Hh, Ws=Hh, Cin=256, Ho=Hh, Wo=Hh), col_stats=cb)
+        yf = yb.float()
+        pad = (-Mb) % 128
+        if pad:
+            yf = torch.cat([yf, torch.zeros(pad, 320, device="cuda")])
+        yf = yf.reshape(-1, 128, 320)
+        torch.testing.assert_close(cb[..., 0], yf.sum(1), rtol=1e-5, atol=2e-3)
+        torch.testing.assert_close(cb[..., 1], (yf * yf).sum(1), rtol=1e-5, atol=2e-3)
+
+
 def test_conv_out_padded_n_to_f32_nchw():
     B, H, Cin, Cout = 2, 16, 320, 4
     x = rnd(B, Cin, H, H, seed=18)

@@ -15,7 +15,7 @@ def _fn(base: str, t: torch.Tensor):
 
 
 def gemm(a, w, *, bias=None, rowbias=None, residual=None, a2=None, conv=None, act=0, out_kind=0, n_valid=0,
-         rows_per_batch=0, rowgate=None, residual_bcast=0, split_k=0):
+         rows_per_batch=0, rowgate=None, residual_bcast=0, split_k=0, col_stats=None):
     """a [M,K] bf16 (or NHWC map for conv=dict(Hs,Ws,Cin,Ho,Wo,stride,upsample)), w [N,K] bf16."""
     N, K = w.shape
     d = _lib.GemmDesc()
@@ -45,6 +45,10 @@ def gemm(a, w, *, bias=None, rowbias=None, residual=None, a2=None, conv=None, ac
     else:
         out = torch.empty((M // rows_per_batch, nv, rows_per_batch), dtype=torch.float32, device=a.device)
     p = lambda t: None if t is None else t.data_ptr()
+    if col_stats is not None:
+        _lib.check(_fn("gemm_stats", a)(C.byref(d), p(a), p(a2), p(w), p(bias), p(rowbias), p(residual), p(out), p(col_stats),
+                                                 _lib.stream_ptr()), "sdn_gemm_stats")
+        return out
     if split_k > 1:
         d.split_k = split_k
         part = torch.empty(split_k * M * N, dtype=torch.float32, device=a.device)
@@ -56,11 +60,16 @@ def gemm(a, w, *, bias=None, rowbias=None, residual=None, a2=None, conv=None, ac
     return out
 
 
-def groupnorm(x, x2, groups, eps, silu, gamma, beta):
+def groupnorm(x, x2, groups, eps, silu, gamma, beta, cols1=None, cols2=None):
     B, hw, c1 = x.shape
     c2 = 0 if x2 is None else x2.shape[2]
     out = torch.empty((B, hw, c1 + c2), dtype=x.dtype, device=x.device)
     ws = torch.empty(B * 129 * groups * 2, dtype=torch.float32, device=x.device)
+    if cols1 is not None:
+        _lib.check(_fn("groupnorm_cols", x)(x.data_ptr(), None if x2 is None else x2.data_ptr(), B, hw, c1, c2, groups, eps, silu,
+                                                     gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), ws.data_ptr(), cols1.data_ptr(),
+                                                     None if cols2 is None else cols2.data_ptr(), _lib.stream_ptr()), "sdn_groupnorm_cols")
+        return out
     _lib.check(_fn("groupnorm", x)(x.data_ptr(), None if x2 is None else x2.data_ptr(), B, hw, c1, c2, groups,
                                             eps, silu, gamma.data_ptr(), beta.data_ptr(), out.data_ptr(),
                                             ws.data_ptr(), _lib.stream_ptr()), "sdn_groupnorm_bf16")
