@@ -110,27 +110,27 @@ k_gn_finalize(const float* __restrict__ partials, int ntiles, int groups, float 
 }
 
 // Statistics from the per-column partials the producing GEMMs left behind (sdn_gemm_stats_*): cols [hw/128 blocks of the
-// sample][c][2] = (sum, sum of squares) per 128-row block.  One workgroup per sample: a thread sums one channel over the
-// sample's blocks, then the channels of a group are combined through LDS.  Same output as k_gn_finalize.
-__global__ void __launch_bounds__(512)
+// sample][c][2] = (sum, sum of squares) per 128-row block.  One workgroup per (sample, group): its threads stride over the
+// group's channels x the sample's blocks (2048 blocks at 512 x 512), then a fixed-order workgroup reduction.  Same output
+// as k_gn_finalize; the summation order depends on neither the batch size nor the producer's tile.
+__global__ void __launch_bounds__(256)
 k_gn_finalize_cols(const float* __restrict__ cols1, const float* __restrict__ cols2, int blocks_per_sample, int c1, int c2,
                    int groups, float n, float eps, float* __restrict__ stats) {
-  extern __shared__ float shc[];                 // [C][2]
-  const int C = c1 + c2, b = blockIdx.x;
-  for (int c = threadIdx.x; c < C; c += 512) {
+  __shared__ float red[8];
+  const int C = c1 + c2, cpg = C / groups, b = blockIdx.x, gi = blockIdx.y;
+  const int total = blocks_per_sample * cpg;
+  float s = 0.f, q = 0.f;
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const int t = e / cpg, c = gi * cpg + (e - t * cpg);
     const bool second = c >= c1;
     const float* src = second ? cols2 : cols1;
     const int cw = second ? c2 : c1, cc = second ? c - c1 : c;
-    const float* p = src + 2 * ((long)b * blocks_per_sample * cw + cc);
-    float s = 0.f, q = 0.f;
-    for (int t = 0; t < blocks_per_sample; ++t) { const float2 v = *reinterpret_cast<const float2*>(p + 2 * (long)t * cw); s += v.x; q += v.y; }
-    shc[2 * c] = s; shc[2 * c + 1] = q;
+    const float2 v = *reinterpret_cast<const float2*>(src + 2 * (((long)b * blocks_per_sample + t) * cw + cc));
+    s += v.x; q += v.y;
   }
-  __syncthreads();
-  const int cpg = C / groups;
-  for (int gi = threadIdx.x; gi < groups; gi += 512) {
-    float s = 0.f, q = 0.f;
-    for (int k = 0; k < cpg; ++k) { s += shc[2 * (gi * cpg + k)]; q += shc[2 * (gi * cpg + k) + 1]; }
+  s = block_sum<4>(s, red);
+  q = block_sum<4>(q, red + 4);
+  if (threadIdx.x == 0) {
     const float mean = s / n;
     const float var = fmaxf(q / n - mean * mean, 0.f);
     stats[((long)b * groups + gi) * 2 + 0] = mean;
@@ -420,8 +420,8 @@ int groupnorm_impl(const void* x, const void* x2, int32_t batch, int32_t hw, int
   if (lds > 64 * 1024) return SDN_E_INVALID;
   if (cols1) {                                // statistics from the producers' column partials: no pass over x
     if ((hw & 127) || (c2 > 0 && !cols2)) return SDN_E_INVALID;
-    hipLaunchKernelGGL(k_gn_finalize_cols, dim3(batch), dim3(512), (size_t)2 * C * sizeof(float), st, cols1, cols2, hw / 128, c1,
-                       c2, groups, (float)hw * (float)(C / groups), eps, stats_ws);
+    hipLaunchKernelGGL(k_gn_finalize_cols, dim3(batch, groups), dim3(256), 0, st, cols1, cols2, hw / 128, c1, c2, groups,
+                       (float)hw * (float)(C / groups), eps, stats_ws);
   } else {
     float* partials = stats_ws + (size_t)batch * groups * 2;          // [B][ntiles][G][2] after the final stats
     hipLaunchKernelGGL((k_gn_stats<T>), dim3(batch, ntiles), dim3(THREADS), lds, st, (const unsigned short*)x,

@@ -44,6 +44,7 @@ struct Op {
   sdn_gemm_desc gd;
   Ref a, a2, w, bias, rowbias, rowgate, residual, out, aux;
   Ref q2, k2, v2, out2;      // joint attention: second token stream
+  Ref col, cols1, cols2;     // GEMM: column partials to emit; GroupNorm: partials of its input(s) to reduce instead of reading
   Ref ln_c, ln_d, ln_stats;  // GEMM with LayerNorm folded in (sdn_gemm_ln_*); ln_stats unset = statistics inside the kernel
   int ln = 0;
   int n1 = 0, mod = 0, ld_mod = 0, patch = 0;
@@ -103,6 +104,7 @@ struct Arena {                      // plan-time first-fit allocator with coales
 
 struct Act {                         // a bf16 [rows, C] activation living in the workspace
   int64_t off = -1, bytes = 0; int C = 0, hw = 0, side = 0;
+  int64_t st_off = -1, st_bytes = 0;   // column partials its producing GEMM leaves for the GroupNorm that reads it
 };
 
 struct Plan {
@@ -136,6 +138,7 @@ struct sdn_unet {
   bool profile_next = false;
   // graph mode (sdn_unet_set_graph_mode): one captured hipGraph per (batch, operand addresses); replays cost one launch
   bool use_graph = false;
+  bool gn_fuse = true;                  // GroupNorm statistics from the producing GEMMs' column partials (hw % 128 == 0)
   bool ln_fold = true;                  // BasicTransformerBlock LayerNorms folded into their consumer GEMMs where it pays
   struct FoldJob { int64_t w, gamma, beta, bias, wf, c, d; int rows, cols; };
   std::vector<FoldJob> fold_jobs;       // what sdn_unet_prepare has to compute into the SDN_P_DERIVED regions
@@ -203,7 +206,22 @@ struct Builder {
   Act act(int64_t rows, int C, int hw = 0, int side = 0, int esz = 2) {
     Act t; t.bytes = rows * C * esz; t.off = arena.alloc(t.bytes); t.C = C; t.hw = hw; t.side = side; return t;
   }
-  void drop(Act& t) { if (t.off >= 0) arena.release(t.off, t.bytes); t.off = -1; }
+  // an activation a GroupNorm will read: its producer (a GEMM) also emits per-128-row-block column sums
+  Act act_gn(int64_t rows, int C, int hw, int side) {
+    Act t = act(rows, C, hw, side);
+    if (u->gn_fuse && !u->split_k && hw > 0 && hw % 128 == 0) {
+      t.st_bytes = ((rows + 127) / 128) * (int64_t)C * 8;
+      t.st_off = arena.alloc(t.st_bytes);
+    }
+    return t;
+  }
+  Ref pending_cols;                    // set by want_stats() for the NEXT emitted GEMM
+  void want_stats(const Act& out) { pending_cols = out.st_off >= 0 ? Ref{SP_WS, out.st_off} : Ref(); }
+  void drop(Act& t) {
+    if (t.off >= 0) arena.release(t.off, t.bytes);
+    if (t.st_off >= 0) arena.release(t.st_off, t.st_bytes);
+    t.off = -1; t.st_off = -1;
+  }
   static Ref R(const Act& t) { return Ref{SP_WS, t.off}; }
 
   // ---- op emitters ------------------------------------------------------------------------------
@@ -221,6 +239,7 @@ struct Builder {
   }
   // Small-M / long-K GEMMs (one-prompt batches) run in split-K form: the partial buffer lives only for this op.
   void push_gemm(Op& o) {
+    o.col = pending_cols; pending_cols = Ref();
     const int nv = o.gd.n_valid > 0 ? o.gd.n_valid : o.gd.N;
     const int split = (!u->split_k || nv != o.gd.N) ? 1 : sdn_gemm_pick_split(o.gd.M, o.gd.N, o.gd.K, o.gd.act, o.gd.out_kind);
     if (split > 1) {
@@ -253,8 +272,12 @@ struct Builder {
     Op o; o.kind = OP_GN; o.a = R(x); if (x2) o.a2 = R(*x2);
     o.batch = B; o.hw = x.hw; o.c1 = x.C; o.c2 = x2 ? x2->C : 0; o.groups = u->cfg.norm_groups; o.eps = eps;
     o.silu = silu; o.w = gamma; o.bias = beta; o.out = R(out); o.aux = gn_stats;
-    o.bytes = 2.0 * 3.0 * (double)B * x.hw * (o.c1 + o.c2);       // two reads (stats, apply) + one write
-    snprintf(o.label, sizeof(o.label), "k_gn_stats+apply");
+    if (x.st_off >= 0 && (!x2 || x2->st_off >= 0)) {             // statistics come with the inputs: apply pass only
+      o.cols1 = Ref{SP_WS, x.st_off};
+      if (x2) o.cols2 = Ref{SP_WS, x2->st_off};
+    }
+    o.bytes = 2.0 * (o.cols1.space != SP_NONE ? 2.0 : 3.0) * (double)B * x.hw * (o.c1 + o.c2);   // reads (stats?, apply) + one write
+    snprintf(o.label, sizeof(o.label), o.cols1.space != SP_NONE ? "k_gn_apply" : "k_gn_stats+apply");
     plan->ops.push_back(o);
   }
   void layernorm(const Act& x, Ref gamma, Ref beta, const Act& out) {
@@ -330,21 +353,24 @@ struct Builder {
     const int64_t rows = (int64_t)B * x.hw;
     Act g1 = act(rows, cin, x.hw, x.side);
     groupnorm(x, skip, 1e-5f, 1, n1g, n1b, g1);
-    Act h = act(rows, cout, x.hw, x.side);
+    Act h = act_gn(rows, cout, x.hw, x.side);
+    want_stats(h);
     conv3x3(g1, cout, cout, c1w, c1b, R(h), 1, 0, Ref(), Ref{SP_WS, tproj.off + (int64_t)tcol * 4}, u->tproj_total);
     drop(g1);
     Act g2 = act(rows, cout, x.hw, x.side);
     groupnorm(h, nullptr, 1e-5f, 1, n2g, n2b, g2);
     drop(h);
-    Act out = act(rows, cout, x.hw, x.side);
+    Act out = act_gn(rows, cout, x.hw, x.side);
     if (cin != cout) {
       Ref scw = param(pfx + ".conv_shortcut.weight", SDN_P_MAT, cout, cin), scb = param(pfx + ".conv_shortcut.bias", SDN_P_VEC_F32, cout, 0);
       Act sc = act(rows, cout, x.hw, x.side);
       gemm(rows, cout, cin, R(x), scw, scb, R(sc), SDN_ACT_NONE, Ref(), SDN_OUT_BF16, 0, skip ? R(*skip) : Ref(),
            skip ? x.C : 0);
+      want_stats(out);
       conv3x3(g2, cout, cout, c2w, c2b, R(out), 1, 0, R(sc), Ref(), 0);
       drop(sc);
     } else {
+      want_stats(out);
       conv3x3(g2, cout, cout, c2w, c2b, R(out), 1, 0, R(x), Ref(), 0);
     }
     drop(g2);
@@ -360,7 +386,7 @@ struct Builder {
     int nsub = 1;
     if (u->subbatch_bytes > 0)
       while (nsub < B && bytes_full / nsub > u->subbatch_bytes && B % (nsub * 2) == 0) nsub *= 2;
-    Act out = act((int64_t)B * x.hw, x.C, x.hw, x.side);
+    Act out = nsub == 1 ? act_gn((int64_t)B * x.hw, x.C, x.hw, x.side) : act((int64_t)B * x.hw, x.C, x.hw, x.side);
     const int Bfull = B, Bs = B / nsub;
     for (int sb = 0; sb < nsub; ++sb) {
       B = Bs;
@@ -459,6 +485,7 @@ struct Builder {
     Act h4 = act(rows, C, hw, x.side);
     gemm(rows, C, 4 * C, R(ff), f2w, f2b, R(h4), SDN_ACT_NONE, R(h3));
     drop(ff); drop(h3);
+    want_stats(out);
     gemm(rows, C, C, R(h4), pow_, pob, R(out), SDN_ACT_NONE, R(rep > 1 ? *x_full : x));
     drop(h4);
   }
@@ -749,7 +776,7 @@ struct Builder {
           Act rf = act((int64_t)B * rp.hw, cout, rp.hw, rp.side);
           repeat(rp, rf, rep);
           snprintf(buf, sizeof(buf), "down_blocks.%d.attentions.%d", i, j);
-          Act t = act((int64_t)B * rp.hw, cout, rp.hw, rp.side);
+          Act t = act_gn((int64_t)B * rp.hw, cout, rp.hw, rp.side);
           transformer_body(buf, rp, t, 0, rep, &rf);
           drop(rp); drop(rf);
           cur = t; skips.push_back(cur); cur_is_skip = true;
@@ -770,7 +797,8 @@ struct Builder {
         snprintf(buf, sizeof(buf), "down_blocks.%d.downsamplers.0.conv", i);
         Ref w = param(std::string(buf) + ".weight", SDN_P_CONV3X3, cout, 9 * cout), bb = param(std::string(buf) + ".bias", SDN_P_VEC_F32, cout, 0);
         const int s2 = cur.side / 2;
-        Act d = act((int64_t)B * s2 * s2, cout, s2 * s2, s2);
+        Act d = act_gn((int64_t)B * s2 * s2, cout, s2 * s2, s2);
+        want_stats(d);
         conv3x3(cur, cout, cout, w, bb, R(d), 2, 0, Ref(), Ref(), 0);
         cur = d; skips.push_back(cur); cur_is_skip = true;
       }
@@ -803,7 +831,8 @@ struct Builder {
         snprintf(buf, sizeof(buf), "up_blocks.%d.upsamplers.0.conv", i);
         Ref w = param(std::string(buf) + ".weight", SDN_P_CONV3X3, cout, 9 * cout), bb = param(std::string(buf) + ".bias", SDN_P_VEC_F32, cout, 0);
         const int s2 = cur.side * 2;
-        Act up = act((int64_t)B * s2 * s2, cout, s2 * s2, s2);
+        Act up = act_gn((int64_t)B * s2 * s2, cout, s2 * s2, s2);
+        want_stats(up);
         conv3x3(cur, cout, cout, w, bb, R(up), 1, 1, Ref(), Ref(), 0);
         drop(cur); cur = up;
       }
@@ -837,20 +866,23 @@ struct Builder {
     const int64_t rows = (int64_t)B * x.hw;
     Act g1 = act(rows, cin, x.hw, x.side);
     groupnorm(x, nullptr, 1e-6f, 1, n1g, n1b, g1);
-    Act h = act(rows, cout, x.hw, x.side);
+    Act h = act_gn(rows, cout, x.hw, x.side);
+    want_stats(h);
     conv3x3(g1, cout, cout, c1w, c1b, R(h), 1, 0, Ref(), Ref(), 0);
     drop(g1);
     Act g2 = act(rows, cout, x.hw, x.side);
     groupnorm(h, nullptr, 1e-6f, 1, n2g, n2b, g2);
     drop(h);
-    Act out = act(rows, cout, x.hw, x.side);
+    Act out = act_gn(rows, cout, x.hw, x.side);
     if (cin != cout) {
       Ref scw = param(pfx + ".conv_shortcut.weight", SDN_P_MAT, cout, cin), scb = param(pfx + ".conv_shortcut.bias", SDN_P_VEC_F32, cout, 0);
       Act sc = act(rows, cout, x.hw, x.side);
       gemm(rows, cout, cin, R(x), scw, scb, R(sc));
+      want_stats(out);
       conv3x3(g2, cout, cout, c2w, c2b, R(out), 1, 0, R(sc), Ref(), 0);
       drop(sc);
     } else {
+      want_stats(out);
       conv3x3(g2, cout, cout, c2w, c2b, R(out), 1, 0, R(x), Ref(), 0);
     }
     drop(g2);
@@ -910,7 +942,8 @@ struct Builder {
       }
     }
     drop(sc); drop(pr); drop(vt); drop(q); drop(k); drop(v);
-    Act out = act(rows, C, hw, x.side);
+    Act out = act_gn(rows, C, hw, x.side);
+    want_stats(out);
     gemm(rows, C, C, R(at), ow, ob, R(out), SDN_ACT_NONE, R(x));
     drop(at);
     return out;
@@ -947,7 +980,8 @@ struct Builder {
         snprintf(buf, sizeof(buf), "decoder.up_blocks.%d.upsamplers.0.conv", i);
         Ref w = param(std::string(buf) + ".weight", SDN_P_CONV3X3, cout, 9 * cout), bb = param(std::string(buf) + ".bias", SDN_P_VEC_F32, cout, 0);
         const int s2 = cur.side * 2;
-        Act up = act((int64_t)B * s2 * s2, cout, s2 * s2, s2);
+        Act up = act_gn((int64_t)B * s2 * s2, cout, s2 * s2, s2);
+        want_stats(up);
         conv3x3(cur, cout, cout, w, bb, R(up), 1, 1, Ref(), Ref(), 0);
         drop(cur); cur = up;
       }
@@ -991,7 +1025,8 @@ struct Builder {
         snprintf(buf, sizeof(buf), "encoder.down_blocks.%d.downsamplers.0.conv", i);
         Ref w = param(std::string(buf) + ".weight", SDN_P_CONV3X3, cout, 9 * cout), bb = param(std::string(buf) + ".bias", SDN_P_VEC_F32, cout, 0);
         const int s2 = cur.side / 2;
-        Act d = act((int64_t)B * s2 * s2, cout, s2 * s2, s2);
+        Act d = act_gn((int64_t)B * s2 * s2, cout, s2 * s2, s2);
+        want_stats(d);
         conv3x3(cur, cout, cout, w, bb, R(d), 2, 0, Ref(), Ref(), 0, SDN_OUT_BF16, 0, 1);
         drop(cur); cur = d;
       }
@@ -1327,6 +1362,12 @@ static int launch_ops(sdn_unet* u, Plan* p, const char* W, const char* WS, const
                                                           (const float*)P(o.ln_stats), (void*)P(o.out), stream);
           break;
         }
+        if (o.col.space != SP_NONE && o.gd.split_k <= 1) {
+          rc = (f16 ? sdn_gemm_stats_f16 : sdn_gemm_stats_bf16)(&o.gd, P(o.a), P(o.a2), P(o.w), (const float*)P(o.bias),
+                                                                (const float*)P(o.rowbias), P(o.residual), (void*)P(o.out),
+                                                                (float*)P(o.col), stream);
+          break;
+        }
         if (o.gd.split_k > 1) {
           rc = (f16 ? sdn_gemm_splitk_f16 : sdn_gemm_splitk_bf16)(&o.gd, P(o.a), P(o.a2), P(o.w), (const float*)P(o.bias),
                                                                   (const float*)P(o.rowbias), (const float*)P(o.rowgate), P(o.residual),
@@ -1337,6 +1378,13 @@ static int launch_ops(sdn_unet* u, Plan* p, const char* W, const char* WS, const
                            (const float*)P(o.rowgate), P(o.residual), (void*)P(o.out), stream);
         break;
       case OP_GN:
+        if (o.cols1.space != SP_NONE) {
+          rc = (f16 ? sdn_groupnorm_cols_f16 : sdn_groupnorm_cols_bf16)(P(o.a), P(o.a2), o.batch, o.hw, o.c1, o.c2, o.groups, o.eps,
+                                                                        o.silu, (const float*)P(o.w), (const float*)P(o.bias),
+                                                                        (void*)P(o.out), (float*)P(o.aux), (const float*)P(o.cols1),
+                                                                        (const float*)P(o.cols2), stream);
+          break;
+        }
         rc = (f16 ? sdn_groupnorm_f16 : sdn_groupnorm_bf16)(P(o.a), P(o.a2), o.batch, o.hw, o.c1, o.c2, o.groups, o.eps, o.silu,
                                 (const float*)P(o.w), (const float*)P(o.bias), (void*)P(o.out), (float*)P(o.aux), stream);
         break;
@@ -1468,6 +1516,14 @@ void sdn_unet_set_graph_mode(sdn_unet* u, int32_t on) {
 extern "C" void sdn_debug_set_ln_fold(sdn_unet* u, int on) {
   if (!u) return;
   u->ln_fold = on != 0;
+  u->plans.clear();
+  for (auto& kv : u->graphs) (void)hipGraphExecDestroy(kv.second);
+  u->graphs.clear();
+}
+
+extern "C" void sdn_debug_set_gn_fuse(sdn_unet* u, int on) {
+  if (!u) return;
+  u->gn_fuse = on != 0;
   u->plans.clear();
   for (auto& kv : u->graphs) (void)hipGraphExecDestroy(kv.second);
   u->graphs.clear();

@@ -27,6 +27,8 @@ u._weights = buf
 u._prepare()
 if os.environ.get("LN_FOLD") == "0":
     sda.lib().sdn_debug_set_ln_fold(u._h, 0)
+if os.environ.get("GN_FUSE") == "0":
+    sda.lib().sdn_debug_set_gn_fuse(u._h, 0)
 if os.environ.get("SPLIT_K"):
     u.set_split_k(True)
 if os.environ.get("SUBBATCH") is not None:
