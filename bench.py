@@ -48,7 +48,11 @@ def build_engine(args, rank, world, dev):
         g = torch.Generator().manual_seed(0)
         refs = torch.randn(args.refs, 4, 64, 64, generator=g)
         refs = refs / torch.norm(refs, dim=1, keepdim=True)
+    sdist.barrier(); torch.cuda.synchronize()
+    tb0 = time.perf_counter()
     refs = sdist.broadcast_proj_ref(refs, dev)                         # RCCL broadcast, 33.75 MB
+    torch.cuda.synchronize()
+    bcast_ms = (time.perf_counter() - tb0) * 1e3                       # includes RCCL's lazy communicator set-up
     tmp = tempfile.mkdtemp(prefix=f"sdn_bench_r{rank}_")
     path = os.path.join(tmp, "repellency_proj_ref.pt")
     torch.save(refs.cpu(), path)
@@ -65,7 +69,7 @@ def build_engine(args, rank, world, dev):
     proc = thr.get_repellency_method("kernel_fast", torch.zeros(1, device=dev), None, None, 50, 1000, 0.00085, 0.012,
                                      n_embed=16, beta_threshold=beta, **knobs)
     pipe = SafeDenoiserPipeline(unet, sched, variant="threshold_time")
-    return unet, pipe, proc, beta
+    return unet, pipe, proc, beta, bcast_ms
 
 
 def _attn_pad(label: str) -> float:
@@ -104,9 +108,56 @@ def cpu_baseline(args):
                       f"DDPM step) = {dt:.2f} s of CPU work, extrapolated x50"}
 
 
+def _free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N` without a launcher: this (parent) process never touches the GPU; it starts N fresh
+    child processes with the torchrun environment contract (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), relays rank 0's
+    stdout (the JSON line) and the children's stderr, and fails if any rank fails."""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SDN_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on this pool (RCCL needs it)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    bad = []
+    while True:                                                     # a rank that dies must not leave the others waiting in
+        states = [p.poll() for p in procs]                          # a collective: stop exactly the processes started here
+        bad = [(r, rc) for r, rc in enumerate(states) if rc not in (None, 0)]
+        if bad or all(rc is not None for rc in states):
+            break
+        time.sleep(0.2)
+    if bad:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            p.wait()
+        print(f"[bench] ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    reader.join()
+    sys.stdout.write(b"".join(chunks).decode())
+    sys.stdout.flush()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--launch-check", action="store_true",
+                    help="(tests) every rank prints its RANK/WORLD_SIZE as JSON and exits without touching the GPU")
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--prompts-per-batch", type=int, default=64)
@@ -120,16 +171,28 @@ def main():
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed) VAE decoder measurement")
     args = ap.parse_args()
 
+    # N > 1 without a launcher: become the launcher BEFORE anything touches the GPU (no re-exec of a GPU process)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        sys.exit(f"[bench] --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: start one process per GPU "
+                 f"(torchrun --nproc-per-node {args.gpus}) or run `python bench.py --gpus {args.gpus}` without a launcher")
+
     from safe_denoiser_amd import dist as sdist
+    if args.launch_check:                                              # CPU-only rehearsal of the N-rank start-up
+        rank, world, local = sdist.init_from_env(backend="gloo")
+        total = sdist.sum_over_ranks(float(rank), torch.device("cpu"))
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "rank_sum": total, "local_rank": local}))
+        sdist.barrier()
+        return
     rank, world, local = sdist.init_from_env()
-    if world != args.gpus and rank == 0:
-        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the hot path has no CPU fallback")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
-    unet, pipe, proc, beta = build_engine(args, rank, world, dev)
+    unet, pipe, proc, beta, bcast_ms = build_engine(args, rank, world, dev)
     P = args.prompts_per_batch
     mine = sdist.shard_indices(args.total_prompts, rank, world)        # this rank's prompts of the 515-prompt job
     g = torch.Generator().manual_seed(7)
@@ -157,8 +220,11 @@ def main():
     for k in range(args.steps):
         out = run(args.warmup + k)
         renoise += pipe.last_stats["renoise_draws"]
-    torch.cuda.synchronize(); sdist.barrier()
+    torch.cuda.synchronize()
+    dt_mine = time.perf_counter() - t0                                  # this rank's own clock, before the closing barrier
+    sdist.barrier()
     dt = sdist.max_over_ranks(time.perf_counter() - t0, dev)
+    per_rank = [P * args.steps / d_ for d_ in sdist.gather_over_ranks(dt_mine, dev)]
     assert torch.isfinite(out).all()
 
     # ---- live kernel timing (HIP events on the launch stream) of one UNet forward at the benchmark shape ----
@@ -242,7 +308,8 @@ def main():
                                f"sharded r::{world}, CFG 7.5 (2 branches), {args.scheduler.upper()} {args.inference_steps} "
                                f"steps, 64x64x4 latents",
                    "prompts_per_batch": P, "latent_repeat": unet.latent_repeat, "images_timed": n_img, "beta_threshold": beta,
-                   "renoise_draws_rank0": renoise, "parallelism": f"prompt-shard x{world}"},
+                   "renoise_draws_rank0": renoise, "parallelism": f"prompt-shard x{world}",
+                   "per_rank_images_per_sec": per_rank, "proj_ref_broadcast_ms": bcast_ms},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": d["bytes"] / d["launches"], "kernel": dom,

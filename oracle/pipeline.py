@@ -19,9 +19,10 @@ from . import repellency as orp
 from . import schedulers as osch
 
 VARIANTS = {
-    "threshold_time": ("t", 780, 1000, True, True),
-    "time": ("t", 800, 1000, False, False),
-    "threshold": ("i", 0, 50, True, True),
+    "threshold_time": ("t", 780, 1000, True, True),      # {safree,sld}_*_threshold_time.py:429-431,552
+    "time": ("t", 800, 1000, False, False),              # *_time.py:430-431,549 (SLD file: lower bound 780, :380-382)
+    "threshold": ("i", 0, 50, True, True),               # *_threshold.py:430-431,548 -- hard-coded, kwargs never read
+    "sd_threshold_time": ("i", 0, 11, True, True),       # modified_stable_diffusion_pipeline_threshold_time.py:430-431,551
     "plain": (None, 0, 0, False, True),
 }
 
@@ -42,8 +43,14 @@ def denoise_one(unet, scheduler, text_pair, p, noise_fn, *, num_inference_steps=
     """text_pair: [2,77,768] (uncond, text) for prompt p.  repel: dict(flavour=..., proj_refs=..., **params) or None.
     Returns (final latents [1,C,S,S], stats)."""
     kind, lo_d, hi_d, use_beta, use_flag = VARIANTS[variant]
-    hi = hi_d if negation_warmup_start is None else negation_warmup_start
-    lo = lo_d if negation_warmup_end is None else negation_warmup_end
+    if variant == "threshold":
+        lo, hi = lo_d, hi_d
+    elif kind == "i":                                      # i >= start and i <= end
+        lo = lo_d if negation_warmup_start is None else negation_warmup_start
+        hi = hi_d if negation_warmup_end is None else negation_warmup_end
+    else:                                                  # t <= start and t >= end
+        hi = hi_d if negation_warmup_start is None else negation_warmup_start
+        lo = (780 if (sld and variant == "time") else lo_d) if negation_warmup_end is None else negation_warmup_end
     gen = TapeGenerator(noise_fn, p)
     is_ddpm = isinstance(scheduler, osch.DDPM)
     scheduler.set_timesteps(num_inference_steps)

@@ -1474,6 +1474,7 @@ static int run_plan(sdn_unet* u, const void* weights, const float* latents, floa
       auto it = u->graphs.find(key);
       if (it == u->graphs.end()) {
         if (u->graphs.size() >= 16) {                          // operands keep moving: graphs do not pay, stop hoarding
+          (void)hipStreamSynchronize(hs);                      // a replay may still be executing on the launch stream
           for (auto& kv : u->graphs) (void)hipGraphExecDestroy(kv.second);
           u->graphs.clear();
         }
@@ -1497,18 +1498,26 @@ static int run_plan(sdn_unet* u, const void* weights, const float* latents, floa
 
 void sdn_unet_profile_next(sdn_unet* u) { if (u) u->profile_next = true; }
 
+// Configuration calls (not on the hot path) drop the cached graphs; a replay may still be in flight on whatever stream the
+// caller launched it, so the device is drained first.
+static void drop_graphs(sdn_unet* u) {
+  if (u->graphs.empty()) return;
+  (void)hipDeviceSynchronize();
+  for (auto& kv : u->graphs) (void)hipGraphExecDestroy(kv.second);
+  u->graphs.clear();
+}
+
 void sdn_unet_set_split_k(sdn_unet* u, int32_t on) {
   if (!u || u->split_k == (on != 0)) return;
   u->split_k = on != 0;
+  drop_graphs(u);
   u->plans.clear();                                            // plans are rebuilt with / without partial buffers
-  for (auto& kv : u->graphs) (void)hipGraphExecDestroy(kv.second);
-  u->graphs.clear();
 }
 
 void sdn_unet_set_graph_mode(sdn_unet* u, int32_t on) {
   if (!u) return;
   u->use_graph = on != 0;
-  if (!on) { for (auto& kv : u->graphs) (void)hipGraphExecDestroy(kv.second); u->graphs.clear(); }
+  if (!on) drop_graphs(u);
 }
 
 // Undeclared tuning hook (tools/): size threshold of the transformer sub-batching; rebuilds the plans.
@@ -1516,22 +1525,21 @@ void sdn_unet_set_graph_mode(sdn_unet* u, int32_t on) {
 extern "C" void sdn_debug_set_ln_fold(sdn_unet* u, int on) {
   if (!u) return;
   u->ln_fold = on != 0;
+  drop_graphs(u);
   u->plans.clear();
-  for (auto& kv : u->graphs) (void)hipGraphExecDestroy(kv.second);
-  u->graphs.clear();
 }
 
 extern "C" void sdn_debug_set_gn_fuse(sdn_unet* u, int on) {
   if (!u) return;
   u->gn_fuse = on != 0;
+  drop_graphs(u);
   u->plans.clear();
-  for (auto& kv : u->graphs) (void)hipGraphExecDestroy(kv.second);
-  u->graphs.clear();
 }
 
 extern "C" void sdn_debug_set_subbatch_bytes(sdn_unet* u, long long bytes) {
   if (!u || u->is_mmdit) return;
   u->subbatch_bytes = bytes;
+  drop_graphs(u);
   u->plans.clear();
 }
 

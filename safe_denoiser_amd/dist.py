@@ -101,3 +101,13 @@ def sum_over_ranks(value: float, device) -> float:
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def gather_over_ranks(value: float, device) -> list:
+    """Every rank's `value`, in rank order, on every rank (end-of-run per-rank counters; never inside the step loop)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(value)]
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]

@@ -65,14 +65,18 @@ class RBFKernelRepellency(RepellencyMethod):
                 self.noisy_proj_refs = self.set_noisy_proj_ref(scheduler, self.num_timesteps)
             self.noisy_refs_beta_quantitle = self.empirical_beta(sigma=self.sigma, quantitle=self.quantile)
             # the reference keeps the LAST key (smallest t), :302
-            self.beta_threshold = self.noisy_refs_beta_quantitle[list(self.noisy_refs_beta_quantitle.keys())[-1]]
+            # (stored ONCE as a host float: conditioning_device() builds the gate from it every step and must not sync)
+            self.beta_threshold = float(self.noisy_refs_beta_quantitle[list(self.noisy_refs_beta_quantitle.keys())[-1]].item())
             del self.noisy_proj_refs, self.noisy_refs_beta_quantitle
 
     def conditioning_device(self, x_0_hat, beta_threshold=True, want_neg=False):
         """Sync-free: x updated in place; returns (neg|None, den[N], isneg[N] int32) device tensors."""
         gate = float(self.beta_threshold) - float(self.beta_threshold_margin) if beta_threshold else float("-inf")
-        return self.apply_device(x_0_hat, weight_fn=RBF, qnorm=QNORM_NONE, sigma=self.sigma, gate=gate,
-                                 want_neg=want_neg)
+        neg, den, isneg = self.apply_device(x_0_hat, weight_fn=RBF, qnorm=QNORM_NONE, sigma=self.sigma, gate=gate,
+                                            want_neg=want_neg)
+        if not beta_threshold:
+            isneg.fill_(1)      # conditioning_1 reports is_negation=True unconditionally (:190-193), also when den is NaN
+        return neg, den, isneg
 
     def empirical_denoiser(self, x_t, sigma=1.0, **kwargs):
         x = x_t.clone()

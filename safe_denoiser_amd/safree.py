@@ -6,7 +6,9 @@ projection_matrix, projection_and_orthogonal, safree_projection) and :458-486 (c
 prompt on [<=77, 768] matrices (the reference runs it with torch on the GPU too); it is host orchestration outside the
 step loop, so it is written with torch ops here -- the hot path proper stays in libsdn.  The CLIP encodes it needs
 (`masked_embs` = pooled embedding of the prompt with each token masked in turn, `negspace` = pooled embeddings of the
-negative-concept phrases) come from the text encoder, which is outside this engine: pass them in.
+negative-concept phrases) are produced by SafeDenoiserPipeline._masked_encode_prompt / _new_encode_negative_prompt_space
+with the engine's CLIPTextModel (pipeline.py), or passed in by a caller that has its own text encoder.
+Pinned: tests/golden/safree_golden.npz holds outputs of the reference's own helpers (tests/test_safree.py).
 """
 from __future__ import annotations
 
@@ -59,10 +61,11 @@ def projection_and_orthogonal(input_embeddings, masked_proj, concept_proj):
 
 def prepare(text_embeddings: torch.Tensor, masked_embs: torch.Tensor, negspace: torch.Tensor,
             attention_mask: torch.Tensor, *, alpha: float = 0.01, svf: bool = True, up_t: int = 10,
-            category: str = "nudity") -> dict:
+            category: str = "nudity", concept_proj: torch.Tensor | None = None) -> dict:
     """The reference's call sequence (:458-486).  Returns what SafeDenoiserPipeline takes:
-    rescaled_text_embeddings, beta_adjusted (None when svf is off), plus diagnostics."""
-    P_c = projection_matrix(negspace.T)
+    rescaled_text_embeddings, beta_adjusted (None when svf is off), plus diagnostics.  `concept_proj`: the projector of
+    `negspace` when the caller already has it (it is the same for every prompt of a batch)."""
+    P_c = projection_matrix(negspace.T) if concept_proj is None else concept_proj
     P_m = projection_matrix(masked_embs.T)
     rescaled, n_removed = safree_projection(text_embeddings, masked_embs, P_m, P_c, alpha=alpha,
                                             max_length=text_embeddings.shape[1])

@@ -77,7 +77,9 @@ def run_oracle(sd, E, refs, P, tapes, sched, variant, repel):
     return torch.cat(outs), draws
 
 
-@pytest.mark.parametrize("mode", ["ddpm_threshold_time", "ddim_threshold_time", "ddpm_time_fast", "ddpm_norepel"])
+@pytest.mark.parametrize("mode", ["ddpm_threshold_time", "ddim_threshold_time", "ddpm_time_fast", "ddpm_norepel",
+                                  "ddim_norepel",          # BASELINE config 1: DDIM 50-step plumbing with repellency OFF
+                                  "ddpm_sparse"])          # row R4 (SPELL) inside the loop
 def test_loop_matches_oracle(world, tmp_path, mode):
     u, sd, E, refs, P = world
     shape = (1, 4, 16, 16)
@@ -104,6 +106,28 @@ def test_loop_matches_oracle(world, tmp_path, mode):
         params = dict(scale=0.33)
         repel_o = dict(flavour="fast", proj_refs=refs, **params)
         proc, variant = make_proc(fast, refs, tmp_path, **params), "time"
+    elif mode == "ddpm_sparse":
+        # radius between the distances the x0 probes actually have to the references, so some prompts find neighbours
+        # (is_negation, re-noise) and others do not; scale of configs/sparse_repellency/spell.yaml
+        probe = Tapes(P, shape, 3 * STEPS + 4, seed=5)
+        unet = OracleUNet(sd, SMALL_O, act_dtype=torch.bfloat16)
+        dmin = []
+        for p in range(P):
+            s_ = sched_o(); s_.set_timesteps(STEPS)
+            lat = probe(p, shape)
+            out = unet(torch.cat([lat] * 2), 951.0, torch.stack([E[p], E[P + p]]))
+            eps = out[0:1] + 7.5 * (out[1:2] - out[0:1])
+            x0 = s_.step(eps, 951, lat, generator=torch.Generator().manual_seed(0)).pred_original_sample
+            dmin.append(float(torch.cdist(x0.reshape(1, -1), refs.reshape(len(refs), -1)).min()))
+        srt = sorted(dmin)
+        radius = 0.5 * (srt[0] + srt[1]) if srt[1] - srt[0] > 1e-3 * srt[1] else srt[0] * 1.05
+        params = dict(radius=radius, scale=0.03)
+        repel_o = dict(flavour="threshold", method="sparse", proj_refs=refs, **params)
+        path = str(tmp_path / "pr_sparse.pt")
+        torch.save(refs, path)
+        proc = thr.get_repellency_method("sparse", torch.zeros(1, device="cuda"), None, None, 50, 1000, 0.00085, 0.012,
+                                         n_embed=4, proj_ref_path=path, cache_proj_ref=True, **params)
+        variant = "threshold_time"
     else:
         repel_o, proc, variant = None, None, "threshold_time"
 
@@ -120,7 +144,7 @@ def test_loop_matches_oracle(world, tmp_path, mode):
     errs = [rel_l2(lat[p:p + 1], ref[p:p + 1]) for p in range(P)]
     print(f"{mode}: renoise draws {draws_o}, per-prompt rel L2 {['%.2e' % e for e in errs]}")
     assert max(errs) <= 8e-2, errs
-    if mode.endswith("threshold_time"):
+    if mode.endswith("threshold_time") or mode == "ddpm_sparse":
         assert draws_o > 0                                             # the gate fired at least once
 
 
@@ -199,3 +223,73 @@ def test_sld_family_loop_matches_oracle(world, tmp_path):
     errs = [rel_l2(lat[p:p + 1], ref[p:p + 1]) for p in range(P)]
     print(f"sld loop: per-prompt rel L2 {['%.2e' % e for e in errs]}")
     assert t_p.cur == t_o.cur and max(errs) <= 8e-2
+
+
+# ---- SAFREE text switching inside the loop, 3-branch `lra` batches (...threshold_time.py:518-548) -------------------
+def _safe_text(E, P, seed):
+    """A stand-in for the SAFREE-projected embeddings: same unconditional rows, perturbed text rows."""
+    g = torch.Generator().manual_seed(seed)
+    Es = E.clone()
+    Es[P:] = E[P:] + 0.5 * torch.randn(P, 77, 768, generator=g)
+    return Es
+
+
+@pytest.mark.parametrize("mode", ["lra_svf", "lra_re_attn", "svf_2branch"])
+def test_lra_and_safree_text_switch_match_oracle(world, tmp_path, mode):
+    """`lra` = three branches [uncond | E' | text_e] per prompt (the third is computed and discarded, as the reference
+    does); svf: prompt p uses the projected text while i <= beta_adjusted[p] (a DIFFERENT step count per prompt, so the
+    batch is mixed); otherwise the re_attn_t step window.  Same tapes, same draw counts, bf16 bound as above."""
+    u, sd, E, refs, P = world
+    shape = (1, 4, 16, 16)
+    Es = _safe_text(E, P, 77)
+    lra = mode.startswith("lra")
+    if mode.endswith("svf") or mode == "svf_2branch":
+        betas = [3, 0, 7][:P]
+        sf = dict(safree=True, svf=True, lra=lra, re_attn_t=(-1, -1))
+        fn = lambda p: (lambda i: i <= betas[p])
+    else:
+        betas = None
+        sf = dict(safree=True, svf=False, lra=lra, re_attn_t=(2, 6))
+        fn = lambda p: (lambda i: 2 <= i <= 6)
+    params = dict(sigma=3.15, scale=0.33, beta_threshold=1e-6, beta_threshold_margin=1e9)        # gate always fires
+    unet = OracleUNet(sd, SMALL_O, act_dtype=torch.bfloat16)
+    t_o = Tapes(P, shape, 3 * STEPS + 4, seed=21)
+    outs, draws = [], 0
+    for p in range(P):
+        lat, st = opipe.denoise_one(unet, osch.DDPM(), torch.stack([E[p], E[P + p]]), p, t_o, num_inference_steps=STEPS,
+                                    repel=dict(flavour="threshold", proj_refs=refs, **params), lra=lra,
+                                    text_safe=torch.stack([Es[p], Es[P + p]]), use_safe_fn=fn(p))
+        outs.append(lat); draws += st["renoise_draws"]
+    ref = torch.cat(outs)
+    # control: the switch matters (the oracle WITHOUT it lands elsewhere)
+    t_c = Tapes(P, shape, 3 * STEPS + 4, seed=21)
+    ctl = opipe.denoise_one(unet, osch.DDPM(), torch.stack([E[0], E[P]]), 0, t_c, num_inference_steps=STEPS,
+                            repel=dict(flavour="threshold", proj_refs=refs, **params), lra=lra)[0]
+    t_p = Tapes(P, shape, 3 * STEPS + 4, seed=21)
+    pipe = SafeDenoiserPipeline(u, DDPMScheduler(), variant="threshold_time")
+    lat = pipe(prompt_embeddings=E.cuda(), num_inference_steps=STEPS, repellency_processor=make_proc(thr, refs, tmp_path, **params),
+               noise_fn=t_p, safree_dict=sf, rescaled_text_embeddings=Es.cuda(), beta_adjusted=betas)
+    assert pipe.last_stats["branches"] == (3 if lra else 2)
+    assert t_p.cur == t_o.cur and pipe.last_stats["renoise_draws"] == draws > 0
+    errs = [rel_l2(lat[p:p + 1], ref[p:p + 1]) for p in range(P)]
+    sep = rel_l2(ctl, ref[0:1])
+    print(f"{mode}: per-prompt rel L2 {['%.2e' % e for e in errs]}; without the text switch prompt 0 is {sep:.2e} away")
+    assert max(errs) <= 8e-2 and sep > 2 * max(errs)
+
+
+def test_window_kwargs_follow_each_variant(world, tmp_path):
+    """`*_threshold.py` hard-codes its step-index window and never reads negation_warmup_start/end (...threshold.py:430-431);
+    modified_stable_diffusion_pipeline_threshold_time.py reads them as step-INDEX bounds (start = lower);
+    `*_threshold_time.py` as timestep bounds (start = upper)."""
+    u, sd, E, refs, P = world
+    params = dict(sigma=3.15, scale=0.33, beta_threshold=1e-6, beta_threshold_margin=1e9)
+    n = 10
+    def windows(variant, **kw):
+        pipe = SafeDenoiserPipeline(u, DDIMScheduler(), variant=variant)
+        pipe(prompt_embeddings=E.cuda(), num_inference_steps=n, repellency_processor=make_proc(thr, refs, tmp_path, **params), **kw)
+        return pipe.last_stats["window_steps"]
+    assert windows("threshold", negation_warmup_start=1000, negation_warmup_end=780) == n       # kwargs ignored: every step
+    assert windows("sd_threshold_time") == n                                                   # i = 0..9 all <= 11
+    assert windows("sd_threshold_time", negation_warmup_start=2, negation_warmup_end=4) == 3   # i in {2, 3, 4}
+    assert windows("threshold_time") == 2                                                      # t = 901, 801 are >= 780
+    assert windows("threshold_time", negation_warmup_start=700, negation_warmup_end=400) == 3  # t = 601, 501, 401

@@ -212,3 +212,37 @@ def test_edge_cases(tmp_path):
     import safe_denoiser_amd as sda
     with pytest.raises(sda.SdnError):
         proc.conditioning(torch.randn(1, 4, 2, 2, device="cuda"), beta_threshold=True)
+
+
+def test_g7_goldens_against_product_project(golden, tmp_path):
+    """Row R6: the product's RepellencyMethod.project() (chunks of n_embed only when len > n_embed, per-pixel channel
+    normalisation, the fast flavour's float cast) on the GPU vs the outputs the reference's project() gave for the same
+    images and the same fake embed_fn (tests/golden/make_golden.py G7)."""
+    from safe_denoiser_amd.repellency import repellency_methods_fast as fast
+    from safe_denoiser_amd.repellency import repellency_methods_threshold as thr
+
+    calls = []
+
+    def fake_embed(img):
+        calls.append(int(img.shape[0]))
+        z = torch.nn.functional.avg_pool2d(img, 8)
+        return torch.cat([z, z.sum(1, keepdim=True)], 1)
+
+    n = 0
+    for name, c in golden.items():
+        if not name.startswith("G7_"):
+            continue
+        flavour = name.split("_")[1]
+        refs = orp.channel_normalise(torch.randn(3, 4, 4, 4, generator=torch.Generator().manual_seed(600)))
+        proc = make_proc(thr if flavour == "threshold" else fast, "kernel_fast", refs, tmp_path, beta_threshold=1.0)
+        proc.embed_fn = fake_embed
+        proc.n_embed = int(c["n_embed"])
+        calls.clear()
+        imgs = T(c["imgs"]).cuda()
+        out = proc.project(imgs)
+        assert out.is_cuda and out.dtype == torch.float32
+        close(out, c["out"])
+        k, ne = imgs.shape[0], int(c["n_embed"])
+        assert calls == ([k] if k <= ne else [min(ne, k - i) for i in range(0, k, ne)]), (name, calls)
+        n += 1
+    assert n == 6

@@ -35,3 +35,49 @@ def test_projection_and_token_replacement_match_numpy():
     assert torch.equal(out["rescaled_text_embeddings"][1, 0], E[1, 0])
     assert torch.equal(out["rescaled_text_embeddings"][1, n_t + 1:], E[1, n_t + 1:])
     assert 0 <= out["beta_adjusted"] <= 10 and 0.0 <= out["beta"] <= 2.0
+
+
+# ---- pinned against the reference's own helpers (tests/golden/make_safree_golden.py: the functions at
+# ...threshold_time.py:16-99 executed in the build container; inputs/outputs only) ----
+import os
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "safree_golden.npz")
+
+
+def _gold():
+    z = np.load(GOLD)
+    return z, [str(n) for n in z["__cases__"]]
+
+
+def test_f_beta_matches_reference_grid():
+    z, _ = _gold()
+    rows = iter(z["f_beta/out"])
+    for btype in ("sigmoid", "tanh"):
+        for concept in ("nudity", "artists-VanGogh"):
+            for up_t in (10, 20):
+                want = next(rows)
+                got = [safree.f_beta(float(v), btype=btype, upperbound_timestep=up_t, concept_type=concept) for v in z["f_beta/z"]]
+                assert got == list(want), (btype, concept, up_t)
+
+
+def test_projection_helpers_match_reference_goldens():
+    z, names = _gold()
+    for name in names:
+        ie, neg, p_emb = (torch.from_numpy(z[f"{name}/{k}"]) for k in ("ie", "neg", "p_emb"))
+        alpha = float(z[f"{name}/alpha"])
+        tol = 1e-9 if ie.dtype == torch.float64 else 2e-4            # fp32 pinverse of a 17x17 / n_t x n_t Gram matrix
+        P_c, P_m = safree.projection_matrix(neg.T), safree.projection_matrix(p_emb.T)
+        if f"{name}/P_c" in z.files:
+            np.testing.assert_allclose(P_c.numpy(), z[f"{name}/P_c"], atol=tol)
+            np.testing.assert_allclose(P_m.numpy(), z[f"{name}/P_m"], atol=tol)
+            # the numpy oracle agrees with the reference too
+            np.testing.assert_allclose(osf.proj(neg.numpy().T), z[f"{name}/P_c"], atol=tol)
+        resc, n_removed = safree.safree_projection(ie, p_emb, P_m, P_c, alpha=alpha, max_length=77)
+        assert n_removed == int(z[f"{name}/n_removed"]), name
+        np.testing.assert_allclose(resc.numpy(), z[f"{name}/rescaled"], atol=tol * 10, rtol=tol * 10)
+        ort = safree.projection_and_orthogonal(ie, P_m, P_c)
+        np.testing.assert_allclose(ort.numpy(), z[f"{name}/proj_ort"], atol=tol * 10, rtol=tol * 10)
+        if ie.dtype == torch.float64:
+            ref, nr = osf.safree(ie.numpy(), p_emb.numpy(), alpha)(osf.proj(p_emb.numpy().T), osf.proj(neg.numpy().T))
+            assert nr == n_removed
+            np.testing.assert_allclose(ref, z[f"{name}/rescaled"], atol=1e-9)
