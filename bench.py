@@ -81,8 +81,10 @@ def _attn_pad(label: str) -> float:
 
 
 def cpu_baseline(args):
-    """The CPU oracle (a port of the reference loop, fp32 torch ops) on the host cores: ONE of the 50 denoising
-    iterations of ONE prompt at the full SD-v1.4 size, inside the repellency window, extrapolated x50."""
+    """The CPU oracle (a port of the reference loop, fp32 torch ops) on the host cores: THREE of the 50 denoising iterations
+    of ONE prompt at the full SD-v1.4 size -- two inside the repellency window (t = 981, 961: UNet b=2 + CFG + x0 probe +
+    repellency M + re-noise + DDPM step) and one outside it (t = 761: UNet + CFG + DDPM step) -- timed separately and
+    extrapolated to the loop's 11 window + 39 plain iterations."""
     from oracle import repellency as orp
     from oracle import schedulers as osch
     from oracle.unet import OracleUNet
@@ -95,17 +97,110 @@ def cpu_baseline(args):
     lat = torch.randn(1, 4, 64, 64, generator=g)
     text = torch.randn(2, 77, 768, generator=g)
     s = osch.DDPM(); s.set_timesteps(50)
-    t0 = time.perf_counter()
-    out = unet(torch.cat([lat] * 2), 981.0, text)
-    eps = out[0:1] + 7.5 * (out[1:2] - out[0:1])
-    x0 = s.step(eps, 981, lat, generator=g).pred_original_sample
-    orp.kernel_fast_conditioning(x0, refs, flavour="threshold", scale=0.33, sigma=3.15, beta_threshold=1.0,
-                                 beta_threshold_margin=1.6, use_beta_threshold=True)
-    s.step(eps, 981, lat, generator=g)
-    dt = time.perf_counter() - t0
-    return {"value": 1.0 / (50.0 * dt), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"1 prompt x 1 of 50 iterations (UNet b=2 fp32 + CFG + x0 probe + repellency M={args.refs} + "
-                      f"DDPM step) = {dt:.2f} s of CPU work, extrapolated x50"}
+    times = {}
+    for t in (981, 961, 761):
+        t0 = time.perf_counter()
+        out = unet(torch.cat([lat] * 2), float(t), text)
+        eps = out[0:1] + 7.5 * (out[1:2] - out[0:1])
+        if t >= 780:
+            x0 = s.step(eps, t, lat, generator=g).pred_original_sample
+            d = orp.kernel_fast_conditioning(x0, refs, flavour="threshold", scale=0.33, sigma=3.15, beta_threshold=1e-6,
+                                             beta_threshold_margin=1e9, use_beta_threshold=True)
+            lat = s.add_noise(d["x_0_hat"], torch.randn(lat.shape, generator=g), t)
+        lat = s.step(eps, t, lat, generator=g).prev_sample
+        times[t] = time.perf_counter() - t0
+    win = 0.5 * (times[981] + times[961])
+    per_image = 11 * win + 39 * times[761]
+    return {"value": 1.0 / per_image, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"1 prompt x 3 of 50 iterations at full size: t=981 {times[981]:.2f} s, t=961 {times[961]:.2f} s (window: UNet "
+                      f"b=2 fp32 + CFG + x0 probe + repellency M={args.refs} + re-noise + DDPM step), t=761 {times[761]:.2f} s "
+                      f"(UNet + CFG + DDPM step) = {sum(times.values()):.1f} s of CPU work; extrapolated 11 x window + 39 x plain"}
+
+
+def measure_lra_b3(args, dev, proc, text_all, uncond, mine, P):
+    """The README default (configs/base/vanilla/safree_neg_prompt_config.json:26-28: lra = true): THREE guidance branches
+    per prompt ([uncond | text' | text], the third computed and discarded, ...threshold_time.py:518-548) -> 1.5x the UNet
+    work per image.  One warm-up batch + one timed batch, same gate as the headline run."""
+    from safe_denoiser_amd.pipeline import SafeDenoiserPipeline, make_scheduler
+    from safe_denoiser_amd.unet import UNet2DConditionModel
+    u3 = UNet2DConditionModel(dtype=torch.float16 if args.dtype == "f16" else torch.bfloat16, latent_repeat=3)
+    u3.load_synthetic_on_device(1234, device=dev)
+    pipe3 = SafeDenoiserPipeline(u3, make_scheduler(args.scheduler), variant="threshold_time")
+    out = {}
+    for k in range(2):
+        idx = [mine[(k * P + j) % len(mine)] for j in range(P)]
+        E = torch.cat([uncond.expand(P, -1, -1), text_all[idx]]).to(dev)
+        gens = [torch.Generator(device=dev).manual_seed(1000 + i) for i in idx]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pipe3(prompt_embeddings=E, num_inference_steps=args.inference_steps, guidance_scale=7.5, generator=gens,
+              repellency_processor=proc, safree_dict=dict(lra=True))
+        torch.cuda.synchronize()
+        out = {"value": P / (time.perf_counter() - t0), "unit": "images/sec", "branches": 3, "prompts_per_batch": P,
+               "renoise_draws": pipe3.last_stats["renoise_draws"],
+               "note": "lra = true (README default): 3 UNet branches per prompt, 120.5 TFLOP per image; 1 warm-up + 1 timed batch"}
+    del u3, pipe3
+    torch.cuda.empty_cache()
+    return out
+
+
+def measure_sd3(dev, side, P, steps=50, refs_m=515):
+    """BASELINE config 4 (SD-v3 medium MMDiT, fp16, repellency_methods_fast_sdv3, M = 515) as a side measurement: `side`
+    64 = the reference driver's own 512x512 default (run_nudity_sdv3.py:357-358,500), 128 = the 1024x1024 BASELINE names.
+    50 flow-Euler steps, guidance 3.5 (:501-502), synthetic weights / references; its own MFMA roofline from a
+    HIP-event-profiled forward."""
+    import tempfile as _tf
+    from safe_denoiser_amd.mmdit import SD3Transformer2DModel
+    from safe_denoiser_amd.pipeline_sd3 import SD3SafeDenoiserPipeline
+    from safe_denoiser_amd.repellency import repellency_methods_fast_sdv3 as sd3rep
+    from safe_denoiser_amd.schedulers import FlowMatchEulerDiscreteScheduler
+    m = SD3Transformer2DModel(sample_size=side)
+    m.load_synthetic_on_device(3, device=dev)
+    g = torch.Generator(device=dev).manual_seed(1)
+    refs = torch.randn(refs_m, 16, side, side, generator=g, device=dev)
+    refs = (refs / refs.norm(dim=1, keepdim=True)).cpu()
+    path = os.path.join(_tf.mkdtemp(prefix="sdn_sd3_"), "proj_ref.pt")
+    torch.save(refs, path)
+    del refs
+    proc = sd3rep.get_repellency_method("kernel_fast", torch.zeros(1, device=dev), None, None, 50, 1000, 0.00085, 0.012,
+                                        n_embed=4, proj_ref_path=path, cache_proj_ref=True, scale=0.03)
+    emb = torch.randn(2 * P, 333, 4096, device=dev)
+    pooled = torch.randn(2 * P, 2048, device=dev)
+    pipe = SD3SafeDenoiserPipeline(m, FlowMatchEulerDiscreteScheduler())
+    dt = 0.0
+    for _ in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = pipe(prompt_embeds=emb, pooled_prompt_embeds=pooled, num_inference_steps=steps, guidance_scale=3.5,
+                   repellency_processor=proc, generator=[torch.Generator(device=dev).manual_seed(10 + i) for i in range(P)])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    assert torch.isfinite(out.float()).all()
+    # forward profile (HIP events on the launch stream, per kernel label)
+    x = torch.randn(2 * P, 16, side, side, device=dev)
+    text = m.prepare_text(emb)
+    pl = pooled.to(m.dtype).contiguous()
+    y = torch.empty_like(x)
+    m.forward_into(x, 500.0, text, pl, y)
+    m.profile_next()
+    m.forward_into(x, 500.0, text, pl, y)
+    rows = m.profile_read()
+    fwd_ms = sum(r["ms"] for r in rows)
+    dom = max(rows, key=lambda r: r["ms"])
+    attn = [r for r in rows if r["kernel"].startswith("k_attn")]
+    fl, _ = m.flops(2 * P)
+    res = {"value": P / dt, "unit": "images/sec", "image": f"{side * 8}x{side * 8}", "dtype": "f16", "prompts_per_batch": P,
+           "steps": steps, "window_steps": pipe.last_stats["window_steps"], "ms_per_step": dt / steps * 1e3,
+           "mmdit": {"ms_per_forward": fwd_ms, "batch": 2 * P, "tflops": fl / (fwd_ms * 1e-3) / 1e12},
+           "roofline": {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["flops"] / (dom["ms"] * 1e-3) / 1e12,
+                        "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": dom["flops"] / (dom["ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+                        "avg_launch_us": dom["ms"] / dom["launches"] * 1e3, "launches_per_forward": dom["launches"]},
+           "attention_roofline": {"achieved": sum(r["flops"] for r in attn) / (sum(r["ms"] for r in attn) * 1e-3) / 1e12,
+                                  "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s"}}
+    res["attention_roofline"]["frac"] = res["attention_roofline"]["achieved"] / PEAK_BF16_TFLOPS
+    del m, pipe, proc, emb, pooled, x, y
+    torch.cuda.empty_cache()
+    return res
 
 
 def _free_port() -> int:
@@ -166,6 +261,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"], help="16-bit storage type of the UNet")
     ap.add_argument("--refs", type=int, default=515)
     ap.add_argument("--total-prompts", type=int, default=515)
+    ap.add_argument("--fire-fraction", type=float, default=0.5,
+                    help="fraction of (prompt, window step) pairs whose repellency gate fires (0 = keep the R5 threshold)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the b=3 (lra) and SD-v3 config-4 side measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latent-repeat", action="store_true", help="feed cat([latents] * 2) to a plain UNet plan")
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed) VAE decoder measurement")
@@ -212,14 +310,33 @@ def main():
         return pipe(prompt_embeddings=E, num_inference_steps=args.inference_steps, guidance_scale=7.5, generator=gens,
                     repellency_processor=proc, return_latents=True)
 
+    # ---- gate placement (untimed probe).  The R5-calibrated threshold (beta, computed from the references alone) is kept
+    # and reported, but on SYNTHETIC weights the x0 probes sit far from every reference, so that gate never fires and
+    # the re-noise draws + sdn_renoise_select would never be timed.  The probe batch runs with the gate shut and records
+    # the denominators of every window step; the gate is then put at their median, so that about half of the
+    # (prompt, window step) pairs fire in the timed region (the measured fraction is reported).
+    r5_beta = beta
+    fire_target = args.fire_fraction
+    if fire_target > 0:
+        proc.beta_threshold = float("inf")
+        pipe.record_den = True
+        run(0)
+        dens = torch.cat(pipe.last_stats["denominators"]).float()
+        pipe.record_den = False
+        gate = float(torch.quantile(dens, 1.0 - fire_target)) if rank == 0 else 0.0
+        gate = sdist.broadcast_scalar(gate, dev)
+        proc.beta_threshold = gate + float(proc.beta_threshold_margin)          # is_negation = den > beta - margin = gate
+        beta = proc.beta_threshold
     for k in range(args.warmup):
         run(k)
     sdist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     renoise = 0
+    window_pairs = 0
     for k in range(args.steps):
         out = run(args.warmup + k)
         renoise += pipe.last_stats["renoise_draws"]
+        window_pairs += pipe.last_stats["window_steps"] * P
     torch.cuda.synchronize()
     dt_mine = time.perf_counter() - t0                                  # this rank's own clock, before the closing barrier
     sdist.barrier()
@@ -291,12 +408,14 @@ def main():
     # HBM bytes per launch of the dominant kernel from the PMC passes (tools/pmc_traffic.py; collected in separate
     # rocprofv3 --pmc runs, which cannot be combined with timing) -- read from profiles/ when present
     traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "round1_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "round2_traffic.json")
+    if not os.path.exists(tpath):
+        tpath = os.path.join(ROOT, "profiles", "round1_traffic.json")
     if os.path.exists(tpath):
         want = dom.replace("k_gemm<", "k_gemm_dma<Sdn" + ("F16" if args.dtype == "f16" else "BF16") + ", ").replace(">", ",")
         for kname, rec in json.load(open(tpath)).items():
             if want in kname:
-                traffic, traffic_src = rec["hbm_bytes_per_launch"], "profiles/round1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)"
+                traffic, traffic_src = rec["hbm_bytes_per_launch"], f"profiles/{os.path.basename(tpath)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)"
     n_img = world * P * args.steps
     value = n_img / dt
     line = {
@@ -308,7 +427,12 @@ def main():
                                f"sharded r::{world}, CFG 7.5 (2 branches), {args.scheduler.upper()} {args.inference_steps} "
                                f"steps, 64x64x4 latents",
                    "prompts_per_batch": P, "latent_repeat": unet.latent_repeat, "images_timed": n_img, "beta_threshold": beta,
-                   "renoise_draws_rank0": renoise, "parallelism": f"prompt-shard x{world}",
+                   "renoise_draws_rank0": renoise,
+                   "gate": {"r5_calibrated_beta_threshold": r5_beta, "margin": float(proc.beta_threshold_margin),
+                            "placement": (f"den quantile {1.0 - fire_target:.2f} of an untimed probe batch" if fire_target > 0
+                                          else "R5 threshold - margin"),
+                            "fired_fraction_rank0": renoise / max(window_pairs, 1)},
+                   "parallelism": f"prompt-shard x{world}",
                    "per_rank_images_per_sec": per_rank, "proj_ref_broadcast_ms": bcast_ms},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
@@ -336,6 +460,14 @@ def main():
     }
     if vae_block is not None:
         line["vae_decode"] = vae_block
+    if rank == 0 and world == 1 and not args.no_extras:
+        line["lra_b3"] = measure_lra_b3(args, dev, proc, text_all, uncond, mine, P)
+        del unet, pipe
+        torch.cuda.empty_cache()
+        line["sd3_config4"] = {"512x512": measure_sd3(dev, 64, 8), "1024x1024": measure_sd3(dev, 128, 4)}
+    ppath = os.path.join(ROOT, "profiles", "round2_parity.json")
+    if os.path.exists(ppath):                       # written by tests/test_gpu_f32.py on the GPU box, committed under profiles/
+        line["parity"] = json.load(open(ppath))
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)

@@ -280,6 +280,28 @@ int sdn_conv_in_f16(const float* latents_nchw, const void* w, const float* bias,
 int sdn_timestep_embed_bf16(float timestep, int32_t batch, int32_t dim, void* out, void* stream);
 int sdn_timestep_embed_f16(float timestep, int32_t batch, int32_t dim, void* out, void* stream);
 
+/* ---- fp32 storage forms of the operators above (dtype 2 of sdn_unet_config: the plan's PRECISION mode) ----
+ * Same argument meaning; every activation / weight pointer is f32 and SDN_OUT_BF16 means "f32 [M, ldc]".  Contractions
+ * run on the f32-input matrix cores (v_mfma_f32_16x16x4_f32: exact f32 products and sums), 1/16 of the 16-bit rate.
+ * They exist so the SAME launch plan can be compared with the reference's fp32 arithmetic (run_nudity.py:277 loads the
+ * pipeline with torch_dtype=float32) to ~1e-6 per forward at full size; 16-bit storage cannot do better than 1e-3
+ * (fp16) / 1e-2 (bf16) in any implementation.  The LayerNorm-folded, column-statistics and split-K forms have no f32
+ * counterpart: an f32 plan uses the plain operator chain. */
+int sdn_gemm_f32(const sdn_gemm_desc* d_host, const void* a, const void* a2, const void* w,
+                 const float* bias, const float* rowbias, const float* rowgate, const void* residual, void* out,
+                 void* stream);
+int sdn_groupnorm_f32(const void* x, const void* x2, int32_t batch, int32_t hw, int32_t c1, int32_t c2,
+                      int32_t groups, float eps, int32_t silu, const float* gamma, const float* beta,
+                      void* out, float* stats_ws, void* stream);
+int sdn_layernorm_f32(const void* x, int64_t rows, int32_t c, float eps, const float* gamma,
+                      const float* beta, void* out, void* stream);
+int sdn_attention_f32(const void* q, const void* k, const void* v, void* out, int32_t batch, int32_t heads,
+                      int32_t nq, int32_t nk, int32_t head_dim, int32_t ldq, int32_t ldk, int32_t ldv,
+                      int32_t ldo, float scale, void* stream);
+int sdn_conv_in_f32(const float* latents_nchw, const void* w, const float* bias, int32_t batch, int32_t cin,
+                    int32_t h, int32_t wd, int32_t cout, void* out_nhwc, void* stream);
+int sdn_timestep_embed_f32(float timestep, int32_t batch, int32_t dim, void* out, void* stream);
+
 /* ---- whole-network entry: SD-v1.4-family UNet2DConditionModel forward -------------------------- */
 typedef struct sdn_unet_config {
   int32_t in_channels, out_channels, sample_size;      /* 4, 4, 64                                  */
@@ -290,7 +312,9 @@ typedef struct sdn_unet_config {
   int32_t n_heads;                                     /* 8 (config key attention_head_dim, legacy) */
   int32_t cross_dim, text_len;                         /* 768, 77                                   */
   int32_t norm_groups;                                 /* 32                                        */
-  int32_t dtype;                                       /* 0 = bf16 storage, 1 = fp16 storage        */
+  int32_t dtype;                                       /* 0 = bf16 storage, 1 = fp16 storage, 2 = fp32
+                                                          storage (precision mode: weights, text and every
+                                                          activation f32; see sdn_gemm_f32)          */
   int32_t latent_repeat;                               /* 0/1 = off.  r > 1: the batch is r guidance branches of the
                                                           SAME latents (`torch.cat([latents] * r)`, ...threshold_time.py
                                                           :535): sdn_unet_forward then takes latents [B / r, ...] and

@@ -1,0 +1,454 @@
+// fp32 storage mode of the denoiser-network operators (dtype 2 of sdn_unet_config): every activation and every weight is
+// IEEE fp32 and every contraction runs on the f32-input matrix cores (v_mfma_f32_16x16x4_f32: exact f32 products, f32
+// accumulation, bit-for-bit a k-ordered fmaf chain -- guide section 3 "FP32-input MFMA").  1/16 of the bf16 MFMA rate, so
+// this is the plan's PRECISION mode, not its throughput mode: it exists so that the same launch plan (same wiring, same
+// fusions, same weight manifest) can be checked against the pure-fp32 reference arithmetic at full size to ~1e-6 per
+// forward, where 16-bit storage cannot do better than 1e-3 (fp16) / 1e-2 (bf16) whatever the implementation
+// (north star: latents <= 1e-3 rel).  Same operators and argument meaning as the 16-bit entry points of include/sdn.h:
+//   sdn_gemm_f32          <-> sdn_gemm_bf16        (plain / two-source / implicit 3x3 conv A operand, every epilogue)
+//   sdn_groupnorm_f32     <-> sdn_groupnorm_bf16   (optional channel concat of two maps, optional SiLU)
+//   sdn_layernorm_f32     <-> sdn_layernorm_bf16
+//   sdn_attention_f32     <-> sdn_attention_bf16   (flash form: scores never leave the registers)
+//   sdn_conv_in_f32, sdn_timestep_embed_f32
+// Kernels here favour plainness over the last 2x: tiles are small, staging is register -> LDS with one prefetched k-tile.
+#include <math.h>
+
+#include "sdn_common.h"
+#include "sdn_ops.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.f + expf(-v)); }
+__device__ __forceinline__ float gelu_erf_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_tanh_f(float v) {
+  return 0.5f * v * (1.f + tanhf(0.7978845608028654f * (v + 0.044715f * v * v * v)));
+}
+__device__ __forceinline__ float quick_gelu_f(float v) { return v / (1.f + expf(-1.702f * v)); }
+
+// ================================================================================================
+// GEMM / implicit conv:  C[M,N] = A[M,K] . W[N,K]^T, 64 x 64 tile, BK = 16, 4 waves (one per SIMD); wave w owns rows
+// 16w..16w+15 of the tile and all 64 columns = 4 accumulators of v_mfma_f32_16x16x4_f32 in the SWAPPED orientation
+// (weights = A operand, activations = B operand): a lane ends with 4 consecutive output columns of one row.
+// LDS images are k-major ([16][64 + 16]): the fragment reads of a wave (16 consecutive rows x 4 k) are conflict-free.
+// ================================================================================================
+constexpr int BM = 64, BN = 64, BK = 16, LDT = 80;
+
+struct GemmArgsF {
+  const float* a; const float* a2; const float* w;
+  const float* bias; const float* rowbias; const float* rowgate; const float* residual; float* out;
+  int M, N, K, K1;
+  int a_mode, Hs, Ws, Cin, Ho, Wo, stride, upsample, conv_off;
+  int act, out_kind, rows_per_batch, ld_rowbias, ld_rowgate, residual_bcast, n_valid, ldc;
+  int tiles_n;
+};
+
+__global__ void __launch_bounds__(256)
+k_gemm_f32(const GemmArgsF g) {
+  __shared__ float sa[BK * LDT], sw[BK * LDT];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tm = blockIdx.x / g.tiles_n, tn = blockIdx.x - tm * g.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  // staging role: thread -> (row = tid / 4, 4 consecutive k = (tid % 4) * 4) of the A tile and of the W tile
+  const int srow = tid >> 2, sk = (tid & 3) * 4;
+  const int am = m0 + srow;
+  const bool a_ok = am < g.M;
+  const int wn = n0 + srow;
+  const bool w_ok = wn < g.N;
+  // im2col: this thread's output pixel
+  int pb = 0, cy = 0, cx = 0;
+  if (g.a_mode == 1 && a_ok) {
+    const int hw = g.Ho * g.Wo;
+    pb = am / hw;
+    const int p = am - pb * hw;
+    const int oy = p / g.Wo, ox = p - oy * g.Wo;
+    cy = oy * g.stride + g.conv_off; cx = ox * g.stride + g.conv_off;      // tap centre in the (virtual, upsampled) input
+  }
+  const int Hi = g.upsample ? 2 * g.Hs : g.Hs, Wi = g.upsample ? 2 * g.Ws : g.Ws;
+  const int ld1 = g.K1, ld2 = g.K - g.K1;
+
+  auto load_a = [&](int k0) -> f32x4 {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (!a_ok) return v;
+    if (g.a_mode == 1) {                                                     // weights are [N][ky][kx][Cin]: k -> (tap, channel)
+      const int tap = k0 / g.Cin, c0 = k0 - tap * g.Cin;
+      const int y = cy + tap / 3 - 1, x = cx + tap % 3 - 1;
+      if (y < 0 || y >= Hi || x < 0 || x >= Wi) return v;
+      const int sy = g.upsample ? y >> 1 : y, sx = g.upsample ? x >> 1 : x;
+      return *reinterpret_cast<const f32x4*>(g.a + (((long)pb * g.Hs + sy) * g.Ws + sx) * g.Cin + c0 + sk);
+    }
+    if (k0 < g.K1) return *reinterpret_cast<const f32x4*>(g.a + (long)am * ld1 + k0 + sk);
+    return *reinterpret_cast<const f32x4*>(g.a2 + (long)am * ld2 + (k0 - g.K1) + sk);
+  };
+  auto load_w = [&](int k0) -> f32x4 {
+    if (!w_ok) return (f32x4){0.f, 0.f, 0.f, 0.f};
+    return *reinterpret_cast<const f32x4*>(g.w + (long)wn * g.K + k0 + sk);
+  };
+
+  f32x4 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fq = lane >> 4;
+  f32x4 ra = load_a(0), rw = load_w(0);
+  for (int k0 = 0; k0 < g.K; k0 += BK) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sa[(sk + e) * LDT + srow] = ra[e]; sw[(sk + e) * LDT + srow] = rw[e]; }
+    __syncthreads();
+    if (k0 + BK < g.K) { ra = load_a(k0 + BK); rw = load_w(k0 + BK); }       // next k-tile in flight under the MFMAs
+#pragma unroll
+    for (int ks = 0; ks < BK / 4; ++ks) {
+      const float bv = sa[(ks * 4 + fq) * LDT + wid * 16 + fr];              // B[k = fq][j = fr] = A_tile[row 16w + fr][k]
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float av = sw[(ks * 4 + fq) * LDT + j * 16 + fr];              // A[i = fr][k = fq] = W_tile[col 16j + fr][k]
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: acc[j][e] <-> row m0 + 16w + fr, column n0 + 16j + 4fq + e ----
+  const int m = m0 + wid * 16 + fr;
+  if (m >= g.M) return;
+  const int b = g.rows_per_batch > 0 ? m / g.rows_per_batch : 0;
+  if (g.act == SDN_ACT_GEGLU) {                                              // blocks of 16 value columns, then their 16 gates
+#pragma unroll
+    for (int j = 0; j < 4; j += 2) {
+      const int n = n0 + j * 16 + fq * 4;
+      if (n >= g.N) continue;
+      f32x4 hv = acc[j], gv = acc[j + 1];
+      if (g.bias) { hv += *reinterpret_cast<const f32x4*>(g.bias + n); gv += *reinterpret_cast<const f32x4*>(g.bias + n + 16); }
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = hv[e] * gelu_erf_f(gv[e]);
+      const int nc = ((n0 + j * 16) >> 1) + fq * 4;
+      *reinterpret_cast<f32x4*>(g.out + (long)m * g.ldc + nc) = o;
+    }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + j * 16 + fq * 4;
+    if (n >= g.N) continue;
+    f32x4 v = acc[j];
+    if (g.bias) v += *reinterpret_cast<const f32x4*>(g.bias + n);
+    if (g.rowbias) v += *reinterpret_cast<const f32x4*>(g.rowbias + (long)b * g.ld_rowbias + n);
+    if (g.rowgate) v *= *reinterpret_cast<const f32x4*>(g.rowgate + (long)b * g.ld_rowgate + n);
+    if (g.residual) {
+      const long rrow = g.residual_bcast ? (long)(m - b * g.rows_per_batch) : (long)m;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n + e < g.n_valid) v[e] += g.residual[rrow * g.ldc + n + e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float t = v[e];
+      if (g.act == SDN_ACT_SILU) t = silu_f(t);
+      else if (g.act == SDN_ACT_GELU_TANH) t = gelu_tanh_f(t);
+      else if (g.act == SDN_ACT_QUICK_GELU) t = quick_gelu_f(t);
+      if (n + e >= g.n_valid) continue;
+      if (g.out_kind == SDN_OUT_F32_NCHW) {
+        const int p = m - b * g.rows_per_batch;
+        g.out[((long)b * g.n_valid + n + e) * g.rows_per_batch + p] = t;
+      } else {
+        g.out[(long)m * g.ldc + n + e] = t;
+      }
+    }
+  }
+}
+
+// ================================================================================================
+// GroupNorm (+ SiLU, + channel concat of two maps): one workgroup per (sample, group); statistics are accumulated in
+// double (two maps of 64 x 64 x 10..80 values per group: a plain f32 sum / sum of squares would cancel), then the apply pass.
+// ================================================================================================
+__global__ void __launch_bounds__(256)
+k_groupnorm_f32(const float* __restrict__ x, const float* __restrict__ x2, int hw, int c1, int c2, int groups, float eps,
+                int silu, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ out) {
+  __shared__ double red[2][4];
+  __shared__ float stat[2];
+  const int C = c1 + c2, cpg = C / groups;
+  const int b = blockIdx.x / groups, gi = blockIdx.x - b * groups;
+  const int ch0 = gi * cpg;
+  const long n = (long)hw * cpg;
+  auto at = [&](long e) -> float {
+    const int p = (int)(e / cpg), c = ch0 + (int)(e - (long)p * cpg);
+    return c < c1 ? x[((long)b * hw + p) * c1 + c] : x2[((long)b * hw + p) * c2 + (c - c1)];
+  };
+  double s = 0.0, q = 0.0;
+  for (long e = threadIdx.x; e < n; e += 256) { const double v = at(e); s += v; q += v * v; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off, 64); q += __shfl_xor(q, off, 64); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = q; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double ts = red[0][0] + red[0][1] + red[0][2] + red[0][3], tq = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    const double mean = ts / (double)n;
+    double var = tq / (double)n - mean * mean;                               // biased variance, as torch's group_norm
+    if (var < 0.0) var = 0.0;
+    stat[0] = (float)mean; stat[1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const float mean = stat[0], rstd = stat[1];
+  for (long e = threadIdx.x; e < n; e += 256) {
+    const int p = (int)(e / cpg), c = ch0 + (int)(e - (long)p * cpg);
+    float v = (at(e) - mean) * rstd * gamma[c] + beta[c];
+    if (silu) v = silu_f(v);
+    out[((long)b * hw + p) * C + c] = v;
+  }
+}
+
+// LayerNorm over the last axis: one wave per row, two passes over registers / L1 (mean, then centred sum of squares).
+__global__ void __launch_bounds__(256)
+k_layernorm_f32(const float* __restrict__ x, long rows, int c, float eps, const float* __restrict__ gamma,
+                const float* __restrict__ beta, float* __restrict__ out) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float* xr = x + row * c;
+  float s = 0.f;
+  for (int i = lane; i < c; i += 64) s += xr[i];
+  const float mean = wave_sum(s) / (float)c;
+  float q = 0.f;
+  for (int i = lane; i < c; i += 64) { const float d = xr[i] - mean; q = fmaf(d, d, q); }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)c + eps);
+  for (int i = lane; i < c; i += 64) out[row * c + i] = (xr[i] - mean) * rstd * gamma[i] + beta[i];
+}
+
+// ================================================================================================
+// Attention, flash form on the f32 matrix cores.  Workgroup = 4 waves = 64 queries of one (batch, head); keys / values
+// arrive in tiles of 16 through LDS.  Per wave (16 queries):  S^T[key][query] = K . Q^T  (A = K tile, B = Q^T), so a
+// lane holds 4 keys' scores of ONE query; the running max / sum of a query live in the 4 lanes {q, q+16, q+32, q+48};
+// O^T[dim][query] += V^T . P^T takes register s of the score accumulator directly as the B operand of its k-step s
+// (k-step s, lane group g  <->  key 4g + s on both operands).  Exponentials are expf(x - max): the reference's softmax.
+// ================================================================================================
+template <int HD>
+__global__ void __launch_bounds__(256)
+k_attention_f32(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, float* __restrict__ out,
+                int heads, int nq, int nk, int ldq, int ldk, int ldv, int ldo, float scale) {
+  constexpr int DB = (HD + 15) / 16, DP = DB * 16;                          // head dim padded to whole 16-column blocks
+  constexpr int KS = HD / 4;                                               // k-steps of the score product (HD % 4 == 0)
+  constexpr int LDK = ((HD + 29) / 32) * 32 + 2;                            // rows 2 banks apart mod 32: conflict-free reads
+  constexpr int LDV = DP + 4;                                               // rows 4 apart -> 16 banks apart per lane group
+  __shared__ float sk[16 * LDK], sv[16 * LDV];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int qblocks = (nq + 63) / 64;
+  const int bh = blockIdx.x / qblocks, qb = blockIdx.x - bh * qblocks;
+  const int b = bh / heads, h = bh - b * heads;
+  const int qi = qb * 64 + wid * 16 + fr;                                  // this lane's query
+  const bool q_ok = qi < nq;
+  const float* qp = q + ((long)b * nq + (q_ok ? qi : 0)) * ldq + h * HD;
+  float qf[KS];                                                            // B operand of k-step s: Q[query fr][dim 4s + fq]
+#pragma unroll
+  for (int s = 0; s < KS; ++s) qf[s] = q_ok ? qp[4 * s + fq] * scale : 0.f;
+  f32x4 o[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float mrun = -INFINITY, lrun = 0.f;
+  for (int i = tid; i < 16 * LDV; i += 256) sv[i] = 0.f;                    // the padding columns HD..DP stay zero
+  const float* kb = k + (long)b * nk * ldk + h * HD;
+  const float* vb = v + (long)b * nk * ldv + h * HD;
+  for (int k0 = 0; k0 < nk; k0 += 16) {
+    __syncthreads();                                                       // previous tile fully consumed
+    for (int i = tid; i < 16 * (HD / 4); i += 256) {
+      const int r = i / (HD / 4), c4 = (i - r * (HD / 4)) * 4;
+      f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+      if (k0 + r < nk) {
+        kv = *reinterpret_cast<const f32x4*>(kb + (long)(k0 + r) * ldk + c4);
+        vv = *reinterpret_cast<const f32x4*>(vb + (long)(k0 + r) * ldv + c4);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { sk[r * LDK + c4 + e] = kv[e]; sv[r * LDV + c4 + e] = vv[e]; }
+    }
+    __syncthreads();
+    f32x4 st = {0.f, 0.f, 0.f, 0.f};                                        // S^T: register e <-> key k0 + 4 fq + e, query fr
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+      st = __builtin_amdgcn_mfma_f32_16x16x4f32(sk[fr * LDK + 4 * s + fq], qf[s], st, 0, 0, 0);
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (k0 + 4 * fq + e >= nk) st[e] = -INFINITY;
+      tmax = fmaxf(tmax, st[e]);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float mnew = fmaxf(mrun, tmax);
+    const float alpha = expf(mrun - mnew);                                  // first tile: exp(-inf) = 0
+    float psum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { st[e] = expf(st[e] - mnew); psum += st[e]; }
+    psum += __shfl_xor(psum, 16, 64);
+    psum += __shfl_xor(psum, 32, 64);
+    lrun = lrun * alpha + psum;
+    mrun = mnew;
+#pragma unroll
+    for (int d = 0; d < DB; ++d) {
+      o[d] *= alpha;                                                        // (same factor in all four registers: one query per lane)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)                                           // A[i = dim 16d + fr][k] = V[key 4 fq + s][dim]
+        o[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(sv[(4 * fq + s) * LDV + d * 16 + fr], st[s], o[d], 0, 0, 0);
+    }
+  }
+  // O^T accumulator: column = query fr, row = dim 16d + 4 fq + e
+  if (!q_ok) return;
+  const float inv = 1.0f / lrun;
+  float* op = out + ((long)b * nq + qi) * ldo + h * HD;
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int dim = d * 16 + 4 * fq + e;
+      if (dim < HD) op[dim] = o[d][e] * inv;
+    }
+}
+
+// conv_in: 3x3, pad 1, fp32 NCHW latent -> NHWC f32; one thread per (pixel, output channel).  w is [Cout][ky][kx][Cin].
+__global__ void __launch_bounds__(256)
+k_conv_in_f32(const float* __restrict__ lat, const float* __restrict__ w, const float* __restrict__ bias, int B, int cin,
+              int H, int W, int cout, float* __restrict__ out) {
+  const long total = (long)B * H * W * cout;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int co = (int)(e % cout);
+    const long pix = e / cout;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H), b = (int)(pix / ((long)W * H));
+    float acc = bias[co];
+    for (int ty = 0; ty < 3; ++ty)
+      for (int tx = 0; tx < 3; ++tx) {
+        const int iy = y + ty - 1, ix = x + tx - 1;
+        if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+        for (int c = 0; c < cin; ++c)
+          acc = fmaf(lat[(((long)b * cin + c) * H + iy) * W + ix], w[((long)co * 9 + ty * 3 + tx) * cin + c], acc);
+      }
+    out[e] = acc;
+  }
+}
+
+__global__ void k_temb_f32(float t_val, const float* __restrict__ t_dev, int B, int dim, float* __restrict__ out) {
+  const float t = t_dev ? *t_dev : t_val;
+  const int half = dim / 2;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * dim; i += gridDim.x * blockDim.x) {
+    const int kk = i % dim;
+    const int f_i = kk < half ? kk : kk - half;
+    const float f = expf(-9.210340371976184f * (float)f_i / (float)half);    // ln(10000)
+    const float a = t * f;
+    out[i] = kk < half ? cosf(a) : sinf(a);
+  }
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int sdn_gemm_f32(const sdn_gemm_desc* d, const void* a, const void* a2, const void* w, const float* bias,
+                            const float* rowbias, const float* rowgate, const void* residual, void* out, void* stream) {
+  if (!d || !a || !w || !out) return SDN_E_INVALID;
+  if (d->M < 0 || d->N <= 0 || d->K <= 0 || (d->K % 64) != 0 || (d->N % 32) != 0 || d->split_k > 1) return SDN_E_INVALID;
+  if (d->M == 0) return SDN_OK;
+  const int n_valid = d->n_valid > 0 ? d->n_valid : d->N;
+  if (n_valid > d->N || d->act < 0 || d->act > 4 || d->out_kind < 0 || d->out_kind > 2) return SDN_E_INVALID;
+  if (!al16(a) || !al16(w) || (a2 && !al16(a2)) || (bias && !al16(bias)) || (rowbias && !al16(rowbias)) ||
+      (rowgate && !al16(rowgate)) || (reinterpret_cast<uintptr_t>(out) & 15))
+    return SDN_E_INVALID;
+  GemmArgsF g{};
+  g.a = (const float*)a; g.a2 = (const float*)a2; g.w = (const float*)w; g.bias = bias; g.rowbias = rowbias;
+  g.rowgate = rowgate; g.residual = (const float*)residual; g.out = (float*)out;
+  g.M = d->M; g.N = d->N; g.K = d->K; g.a_mode = d->a_mode;
+  if (d->a_mode == SDN_A_PLAIN) {
+    g.K1 = (d->K1 > 0 && d->K1 < d->K) ? d->K1 : d->K;
+    if (g.K1 != d->K && (!a2 || (g.K1 % 64) != 0)) return SDN_E_INVALID;
+  } else if (d->a_mode == SDN_A_CONV3X3) {
+    if (d->Cin <= 0 || (d->Cin % 64) != 0 || d->K != 9 * d->Cin || d->Hs <= 0 || d->Ws <= 0 || d->Ho <= 0 || d->Wo <= 0 ||
+        (d->stride != 1 && d->stride != 2) || d->M % (d->Ho * d->Wo) != 0)
+      return SDN_E_INVALID;
+    const int Hi = d->upsample ? 2 * d->Hs : d->Hs, Wi = d->upsample ? 2 * d->Ws : d->Ws;
+    if (d->asym_pad != 0 && (d->asym_pad != 1 || d->stride != 2 || d->upsample)) return SDN_E_INVALID;
+    const int pad2 = d->asym_pad ? 1 : 2;
+    if ((Hi + pad2 - 3) / d->stride + 1 != d->Ho || (Wi + pad2 - 3) / d->stride + 1 != d->Wo) return SDN_E_INVALID;
+    g.K1 = d->K; g.Hs = d->Hs; g.Ws = d->Ws; g.Cin = d->Cin; g.Ho = d->Ho; g.Wo = d->Wo; g.stride = d->stride;
+    g.upsample = d->upsample; g.conv_off = d->asym_pad ? 1 : 0;
+  } else {
+    return SDN_E_INVALID;
+  }
+  if (d->act == SDN_ACT_GEGLU && (d->out_kind != SDN_OUT_BF16 || rowbias || rowgate || residual || n_valid != d->N || (d->N % 64) != 0))
+    return SDN_E_INVALID;
+  if ((rowbias || rowgate || d->residual_bcast || d->out_kind == SDN_OUT_F32_NCHW) && d->rows_per_batch <= 0) return SDN_E_INVALID;
+  g.act = d->act; g.out_kind = d->out_kind; g.rows_per_batch = d->rows_per_batch; g.ld_rowbias = d->ld_rowbias;
+  g.ld_rowgate = d->ld_rowgate; g.residual_bcast = d->residual_bcast; g.n_valid = n_valid;
+  g.ldc = d->ldc > 0 ? d->ldc : (d->act == SDN_ACT_GEGLU ? d->N / 2 : n_valid);
+  if (d->act == SDN_ACT_GEGLU && (g.ldc & 3)) return SDN_E_INVALID;
+  g.tiles_n = (d->N + BN - 1) / BN;
+  const long tiles = (long)((d->M + BM - 1) / BM) * g.tiles_n;
+  if (tiles > 0x7fffffffL) return SDN_E_INVALID;
+  hipLaunchKernelGGL(k_gemm_f32, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, g);
+  return sdn_launch_status();
+}
+
+extern "C" int sdn_groupnorm_f32(const void* x, const void* x2, int32_t batch, int32_t hw, int32_t c1, int32_t c2,
+                                 int32_t groups, float eps, int32_t silu, const float* gamma, const float* beta, void* out,
+                                 float* stats_ws, void* stream) {
+  (void)stats_ws;                                                           // the 16-bit kernels' scratch: not needed here
+  if (!x || !gamma || !beta || !out || batch < 0 || hw <= 0 || c1 <= 0 || c2 < 0 || groups <= 0 || (c2 > 0 && !x2) ||
+      (c1 + c2) % groups != 0)
+    return SDN_E_INVALID;
+  if (batch == 0) return SDN_OK;
+  hipLaunchKernelGGL(k_groupnorm_f32, dim3((unsigned)(batch * groups)), dim3(256), 0, (hipStream_t)stream, (const float*)x,
+                     (const float*)x2, hw, c1, c2, groups, eps, silu, gamma, beta, (float*)out);
+  return sdn_launch_status();
+}
+
+extern "C" int sdn_layernorm_f32(const void* x, int64_t rows, int32_t c, float eps, const float* gamma, const float* beta,
+                                 void* out, void* stream) {
+  if (!x || !gamma || !beta || !out || rows < 0 || c <= 0) return SDN_E_INVALID;
+  if (rows == 0) return SDN_OK;
+  hipLaunchKernelGGL(k_layernorm_f32, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)x,
+                     (long)rows, c, eps, gamma, beta, (float*)out);
+  return sdn_launch_status();
+}
+
+extern "C" int sdn_attention_f32(const void* q, const void* k, const void* v, void* out, int32_t batch, int32_t heads,
+                                 int32_t nq, int32_t nk, int32_t head_dim, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo,
+                                 float scale, void* stream) {
+  if (!q || !k || !v || !out || batch < 0 || heads <= 0 || nq <= 0 || nk <= 0) return SDN_E_INVALID;
+  if (!al16(k) || !al16(v) || (ldk & 3) || (ldv & 3)) return SDN_E_INVALID;
+  if (batch == 0) return SDN_OK;
+  const long grid = (long)batch * heads * ((nq + 63) / 64);
+  if (grid > 0x7fffffffL) return SDN_E_INVALID;
+  const float* qf = (const float*)q; const float* kf = (const float*)k; const float* vf = (const float*)v;
+#define SDN_ATTN_F32(HD)                                                                                              \
+  hipLaunchKernelGGL((k_attention_f32<HD>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, qf, kf, vf,      \
+                     (float*)out, heads, nq, nk, ldq, ldk, ldv, ldo, scale)
+  switch (head_dim) {
+    case 40: SDN_ATTN_F32(40); break;
+    case 64: SDN_ATTN_F32(64); break;
+    case 80: SDN_ATTN_F32(80); break;
+    case 160: SDN_ATTN_F32(160); break;
+    default: return SDN_E_INVALID;
+  }
+#undef SDN_ATTN_F32
+  return sdn_launch_status();
+}
+
+extern "C" int sdn_conv_in_f32(const float* latents_nchw, const void* w, const float* bias, int32_t batch, int32_t cin,
+                               int32_t h, int32_t wd, int32_t cout, void* out_nhwc, void* stream) {
+  if (!latents_nchw || !w || !bias || !out_nhwc || batch < 0 || cin <= 0 || h <= 0 || wd <= 0 || cout <= 0) return SDN_E_INVALID;
+  if (batch == 0) return SDN_OK;
+  const long total = (long)batch * h * wd * cout;
+  long grid = (total + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(k_conv_in_f32, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, latents_nchw, (const float*)w, bias,
+                     batch, cin, h, wd, cout, (float*)out_nhwc);
+  return sdn_launch_status();
+}
+
+int sdn_temb_f32(float timestep, const float* t_dev, int batch, int dim, void* out, void* stream) {
+  if (!out || batch <= 0 || dim <= 0 || (dim & 1)) return SDN_E_INVALID;
+  const int n = batch * dim;
+  hipLaunchKernelGGL(k_temb_f32, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, timestep, t_dev, batch, dim, (float*)out);
+  return sdn_launch_status();
+}
+
+extern "C" int sdn_timestep_embed_f32(float timestep, int32_t batch, int32_t dim, void* out, void* stream) {
+  return sdn_temb_f32(timestep, nullptr, batch, dim, out, stream);
+}

@@ -12,3 +12,6 @@ int sdn_set_scalar(float* dst, float v, void* stream);
 
 // k-loop slices the split-K form should use for this shape (1 = do not split)
 int sdn_gemm_pick_split(int M, int N, int K, int act, int out_kind);
+
+// fp32 precision mode (sdn_f32.hip): timestep features from a host scalar or from device memory (graph mode)
+int sdn_temb_f32(float timestep, const float* t_dev, int batch, int dim, void* out, void* stream);

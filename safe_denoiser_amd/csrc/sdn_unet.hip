@@ -169,6 +169,7 @@ struct Builder {
   Plan* plan;
   Arena arena;
   int B;
+  int es = 2;                // bytes per activation / matrix-weight element: 2 (bf16 | f16 storage) or 4 (the fp32 precision mode)
   Ref tproj;                 // f32 [B, tproj_total]
   int tproj_cursor = 0;      // column offset of the next resnet's slice
   Ref gn_stats;
@@ -181,7 +182,7 @@ struct Builder {
     memset(&pi, 0, sizeof(pi));
     snprintf(pi.name, sizeof(pi.name), "%s", name.c_str());
     pi.kind = kind; pi.rows = rows; pi.cols = cols; pi.rows_padded = rows_padded > rows ? rows_padded : rows;
-    const int64_t esz = (kind == SDN_P_VEC_F32 || kind == SDN_P_GEGLU_VEC) ? 4 : 2;
+    const int64_t esz = (kind == SDN_P_VEC_F32 || kind == SDN_P_GEGLU_VEC) ? 4 : es;
     const int64_t bytes = (int64_t)pi.rows_padded * (cols > 0 ? cols : 1) * esz;
     pi.offset = u->weight_bytes;
     u->weight_bytes += (bytes + 255) & ~(int64_t)255;
@@ -197,13 +198,14 @@ struct Builder {
       Ref r = param(names[i], SDN_P_MAT, rows_each, cols);
       if (i == 0) first = r;
       else if (r.off != expect) { fprintf(stderr, "libsdn: stacked weight %s is not contiguous\n", names[i].c_str()); abort(); }
-      expect = r.off + (int64_t)rows_each * cols * 2;
+      expect = r.off + (int64_t)rows_each * cols * es;
     }
     return first;
   }
 
   // ---- activations ------------------------------------------------------------------------------
-  Act act(int64_t rows, int C, int hw = 0, int side = 0, int esz = 2) {
+  Act act(int64_t rows, int C, int hw = 0, int side = 0, int esz = 0) {
+    if (esz == 0) esz = es;
     Act t; t.bytes = rows * C * esz; t.off = arena.alloc(t.bytes); t.C = C; t.hw = hw; t.side = side; return t;
   }
   // an activation a GroupNorm will read: its producer (a GEMM) also emits per-128-row-block column sums
@@ -382,7 +384,7 @@ struct Builder {
   // bit-identical).  It was built to test whether slicing the 168 MB activations of the 64x64 level keeps the chain of
   // short-K projections Infinity-Cache resident; it does not pay (see subbatch_bytes), so it is off by default.
   Act transformer(const std::string& pfx, Act& x) {
-    const int64_t bytes_full = (int64_t)B * x.hw * x.C * 2;
+    const int64_t bytes_full = (int64_t)B * x.hw * x.C * es;
     int nsub = 1;
     if (u->subbatch_bytes > 0)
       while (nsub < B && bytes_full / nsub > u->subbatch_bytes && B % (nsub * 2) == 0) nsub *= 2;
@@ -391,8 +393,8 @@ struct Builder {
     for (int sb = 0; sb < nsub; ++sb) {
       B = Bs;
       Act xs = x, os = out;                                   // views: never dropped
-      xs.off += (int64_t)sb * Bs * x.hw * x.C * 2; os.off += (int64_t)sb * Bs * x.hw * x.C * 2;
-      transformer_body(pfx, xs, os, (int64_t)sb * Bs * u->cfg.text_len * u->cfg.cross_dim * 2);
+      xs.off += (int64_t)sb * Bs * x.hw * x.C * es; os.off += (int64_t)sb * Bs * x.hw * x.C * es;
+      transformer_body(pfx, xs, os, (int64_t)sb * Bs * u->cfg.text_len * u->cfg.cross_dim * es);
     }
     B = Bfull;
     return out;
@@ -441,7 +443,7 @@ struct Builder {
       gemm(rows, 3 * C, C, R(ln), qkv, Ref(), R(qkvb));
     }
     Act at = act(rows, C, hw, x.side);
-    attention(R(qkvb), Ref{SP_WS, qkvb.off + (int64_t)C * 2}, Ref{SP_WS, qkvb.off + (int64_t)2 * C * 2}, R(at), hw, hw, C,
+    attention(R(qkvb), Ref{SP_WS, qkvb.off + (int64_t)C * es}, Ref{SP_WS, qkvb.off + (int64_t)2 * C * es}, R(at), hw, hw, C,
               3 * C, 3 * C, 3 * C);
     drop(qkvb);
     Act h2 = act(rows, C, hw, x.side);
@@ -468,7 +470,7 @@ struct Builder {
     }
     Act kvb = act((int64_t)B * T, 2 * C);
     gemm((int64_t)B * T, 2 * C, X, Ref{SP_TEXT, text_off}, kv2, Ref(), R(kvb));
-    attention(R(qb), R(kvb), Ref{SP_WS, kvb.off + (int64_t)C * 2}, R(at), hw, T, C, C, 2 * C, 2 * C);
+    attention(R(qb), R(kvb), Ref{SP_WS, kvb.off + (int64_t)C * es}, R(at), hw, T, C, C, 2 * C, 2 * C);
     drop(qb); drop(kvb);
     Act h3 = act(rows, C, hw, x.side);
     gemm(rows, C, C, R(at), o2w, o2b, R(h3), SDN_ACT_NONE, R(h2));
@@ -717,7 +719,7 @@ struct Builder {
       for (size_t i = 0; i < rs.size(); ++i) {
         Ref r = param(rs[i].pfx + ".time_emb_proj.weight", SDN_P_MAT, rs[i].cout, tdim);
         if (i == 0) tpw = r; else if (r.off != expect) { fprintf(stderr, "libsdn: time_emb_proj not contiguous\n"); abort(); }
-        expect = r.off + (int64_t)rs[i].cout * tdim * 2;
+        expect = r.off + (int64_t)rs[i].cout * tdim * es;
         total += rs[i].cout;
       }
       expect = -1;
@@ -1126,6 +1128,7 @@ Plan* get_plan(sdn_unet* u, int batch) {
   p.batch = batch;
   Builder b{u, &p};
   b.B = batch;
+  b.es = (!u->is_clip && !u->is_vae && !u->is_mmdit && u->cfg.dtype == 2) ? 4 : 2;
   if (u->is_clip) b.build_clip(); else if (u->is_vae_encoder) b.build_vae_encoder(); else if (u->is_vae) b.build_vae(); else if (u->is_mmdit) b.build_mmdit(); else b.build();
   return &p;
 }
@@ -1152,7 +1155,7 @@ int sdn_unet_create(const sdn_unet_config* cfg, sdn_unet** out) {
   if (cfg->n_levels < 1 || cfg->n_levels > 4 || cfg->layers_per_block < 1 || cfg->n_heads <= 0 ||
       cfg->in_channels <= 0 || cfg->in_channels > 16 || cfg->out_channels <= 0 || cfg->out_channels > 32 ||
       cfg->sample_size <= 0 || (cfg->sample_size % (1 << (cfg->n_levels - 1))) != 0 || cfg->cross_dim % 64 != 0 ||
-      cfg->text_len <= 0 || cfg->norm_groups <= 0 || cfg->norm_groups > 64 || cfg->dtype < 0 || cfg->dtype > 1 ||
+      cfg->text_len <= 0 || cfg->norm_groups <= 0 || cfg->norm_groups > 64 || cfg->dtype < 0 || cfg->dtype > 2 ||
       cfg->latent_repeat < 0 || cfg->latent_repeat > 8)
     return SDN_E_INVALID;
   for (int i = 0; i < cfg->n_levels; ++i) {
@@ -1168,6 +1171,7 @@ int sdn_unet_create(const sdn_unet_config* cfg, sdn_unet** out) {
   }
   sdn_unet* u = new sdn_unet();
   u->cfg = *cfg;
+  if (cfg->dtype == 2) { u->gn_fuse = false; u->ln_fold = false; }   // fp32 precision mode: the plain operator chain (sdn_f32.hip)
   get_plan(u, cfg->latent_repeat > 1 ? cfg->latent_repeat : 1);   // registers the parameter manifest (batch-independent)
   *out = u;
   return SDN_OK;
@@ -1341,9 +1345,47 @@ static int launch_ops(sdn_unet* u, Plan* p, const char* W, const char* WS, const
   auto P = [&](const Ref& r) { return resolve(r, W, WS, L, T, O, PL); };
   size_t opi = 0;
   const bool f16 = (u->is_mmdit ? u->mcfg.dtype : u->cfg.dtype) == 1;       // (VAE / CLIP creators mirror dtype into cfg)
+  const bool f32 = !u->is_mmdit && u->cfg.dtype == 2;                        // fp32 precision mode (SD-v1.4 UNet plans only)
   for (const Op& o : p->ops) {
     int rc = SDN_OK;
     if (prof) (void)hipEventRecord(u->ev[2 * opi], (hipStream_t)stream);
+    if (f32) {                                                               // same plan, fp32 operators (sdn_f32.hip)
+      switch (o.kind) {
+        case OP_TEMB:
+          rc = sdn_temb_f32(timestep, t_dev, o.batch, o.c1, (void*)P(o.out), stream);
+          break;
+        case OP_CONV_IN:
+          rc = sdn_conv_in_f32((const float*)P(o.a), P(o.w), (const float*)P(o.bias), o.batch, o.c1, o.hw, o.hw, o.c2, (void*)P(o.out), stream);
+          break;
+        case OP_GEMM:
+          rc = (o.ln || o.gd.split_k > 1) ? SDN_E_INVALID
+               : sdn_gemm_f32(&o.gd, P(o.a), P(o.a2), P(o.w), (const float*)P(o.bias), (const float*)P(o.rowbias),
+                              (const float*)P(o.rowgate), P(o.residual), (void*)P(o.out), stream);
+          break;
+        case OP_GN:
+          rc = sdn_groupnorm_f32(P(o.a), P(o.a2), o.batch, o.hw, o.c1, o.c2, o.groups, o.eps, o.silu, (const float*)P(o.w),
+                                 (const float*)P(o.bias), (void*)P(o.out), (float*)P(o.aux), stream);
+          break;
+        case OP_LN:
+          rc = o.mod ? SDN_E_INVALID
+                     : sdn_layernorm_f32(P(o.a), o.rows, o.c1, o.eps, (const float*)P(o.w), (const float*)P(o.bias), (void*)P(o.out), stream);
+          break;
+        case OP_ATTN:
+          rc = o.n1 > 0 ? SDN_E_INVALID
+                        : sdn_attention_f32(P(o.a), P(o.k), P(o.v), (void*)P(o.out), o.batch, o.heads, o.nq, o.nk, o.hd, o.ldq, o.ldk,
+                                            o.ldv, o.ldo, o.scale, stream);
+          break;
+        case OP_REPEAT:
+          rc = sdn_repeat(P(o.a), (size_t)o.rows, o.c1, (void*)P(o.out), stream);
+          break;
+        default:
+          rc = SDN_E_INVALID;
+      }
+      if (prof) (void)hipEventRecord(u->ev[2 * opi + 1], (hipStream_t)stream);
+      ++opi;
+      if (rc != SDN_OK) return rc;
+      continue;
+    }
     switch (o.kind) {
       case OP_TEMB:
         if (t_dev) rc = sdn_temb_from_device(f16 ? 1 : 0, t_dev, o.batch, o.c1, (void*)P(o.out), stream);
@@ -1509,6 +1551,7 @@ static void drop_graphs(sdn_unet* u) {
 
 void sdn_unet_set_split_k(sdn_unet* u, int32_t on) {
   if (!u || u->split_k == (on != 0)) return;
+  if (!u->is_mmdit && !u->is_vae && !u->is_clip && u->cfg.dtype == 2) return;   // fp32 mode has no split-K form
   u->split_k = on != 0;
   drop_graphs(u);
   u->plans.clear();                                            // plans are rebuilt with / without partial buffers

@@ -57,6 +57,7 @@ class SafeDenoiserPipeline:
         self.last_stats = {}
         self.last_safree = None
         self._bufs = {}
+        self.record_den = False    # diagnostics: keep each window step's denominators (device tensors, no sync) in last_stats
 
     # ------------------------------------------------------------------------------------------------
     def _noise(self, noise_fn, generators, p: int, shape, device):
@@ -191,6 +192,8 @@ class SafeDenoiserPipeline:
         is_ddpm = isinstance(sch, DDPMScheduler)
         n_renoise = 0
         n_window = 0
+        den_log = []
+        self._last_den = None
         momentum = torch.zeros_like(eps) if sld else None
 
         for i, t in enumerate(timesteps):
@@ -231,6 +234,8 @@ class SafeDenoiserPipeline:
                     for p in range(P):
                         self._noise(noise_fn, gens, p, shape1, dev)
                 src, isneg = self._condition(repellency_processor, x0, use_beta)
+                if self.record_den and self._last_den is not None:
+                    den_log.append(self._last_den.clone())
                 if use_flag:
                     flags = isneg.cpu().tolist()            # the one readback: decides how many randn are drawn
                 else:
@@ -259,6 +264,8 @@ class SafeDenoiserPipeline:
 
         lat = lat.clone()                                              # the loop buffers are reused by the next call
         self.last_stats = {"renoise_draws": n_renoise, "window_steps": n_window, "prompts": P, "branches": nb}
+        if self.record_den:
+            self.last_stats["denominators"] = den_log
         if return_latents:
             return lat
         return self.decode_latents(lat, output_type)
@@ -270,8 +277,11 @@ class SafeDenoiserPipeline:
         if padding == "max_length":
             kw.update(max_length=n, truncation=truncation)
         t = self.tokenizer(texts, **kw)
-        get = (lambda k: getattr(t, k)) if hasattr(t, "input_ids") else (lambda k: t[k])
-        return get("input_ids"), get("attention_mask")
+        ids = t.input_ids if hasattr(t, "input_ids") else t["input_ids"]
+        mask = getattr(t, "attention_mask", None) if hasattr(t, "input_ids") else t.get("attention_mask")
+        if mask is None:               # a tokenizer that returns ids only: real tokens = everything up to the first end-of-text
+            mask = (torch.arange(ids.shape[1])[None, :] <= ids.argmax(dim=-1, keepdim=True)).to(torch.int64)
+        return ids, mask
 
     def _new_encode_prompt(self, prompt, negative_prompt=None):
         """...threshold_time.py:231-349 for P prompts: tokenise with padding="max_length" / truncation, encode (no attention
@@ -397,13 +407,13 @@ class SafeDenoiserPipeline:
             raise _lib.SdnError(f"need {P} generators, got {len(generator)}")
         return list(generator)
 
-    @staticmethod
-    def _condition(proc, x0: torch.Tensor, use_beta: bool):
+    def _condition(self, proc, x0: torch.Tensor, use_beta: bool):
         """Device-side conditioning.  Returns (tensor to re-noise from, is_negation int32[P])."""
         from .repellency import repellency_methods_threshold as thr
         if hasattr(proc, "conditioning_device"):
             returns_neg = isinstance(proc, thr.RBFKernelRepellency) and not use_beta   # conditioning_1 quirk, :190-193
-            neg, _den, isneg = proc.conditioning_device(x0, beta_threshold=use_beta, want_neg=returns_neg)
+            neg, den, isneg = proc.conditioning_device(x0, beta_threshold=use_beta, want_neg=returns_neg)
+            self._last_den = den
             return (neg if returns_neg else x0), isneg
         out = proc.conditioning(x0, beta_threshold=use_beta)                            # generic plug-in (host flags)
         flag = out.get("is_negation", False)

@@ -6,6 +6,8 @@ Weights: a diffusers-keyed state_dict (the names of `UNet2DConditionModel.state_
 ONCE into a single device buffer in the engine's layouts, driven by the manifest the C side publishes
 (sdn_unet_param_info): conv kernels [O,I,3,3] -> [O][ky][kx][I] bf16, linears / 1x1 convs -> [O][I] bf16,
 GEGLU projection rows interleaved value/gate in blocks of 16, norms and biases f32.
+dtype=torch.float32 selects the plan's PRECISION mode (sdn_unet_config.dtype 2): weights, text and activations stay f32 and
+the contractions run on the f32-input matrix cores -- 1/16 of the 16-bit rate, ~1e-6 per forward from the fp32 reference.
 """
 from __future__ import annotations
 
@@ -45,8 +47,8 @@ class UNet2DConditionModel:
         """latent_repeat = r > 1: the engine-side form of `torch.cat([latents] * r)` (classifier-free guidance): `sample`
         then holds B / r latents, `encoder_hidden_states` stays [B] branch-major, and everything up to the first
         cross-attention is computed once per latent (sdn_unet_config.latent_repeat).  Bit-identical results."""
-        if dtype not in (torch.bfloat16, torch.float16):
-            raise _lib.SdnError("storage dtype must be torch.bfloat16 or torch.float16")
+        if dtype not in (torch.bfloat16, torch.float16, torch.float32):
+            raise _lib.SdnError("storage dtype must be torch.bfloat16, torch.float16 or torch.float32 (the precision mode)")
         self.dtype = dtype
         self.latent_repeat = max(1, int(latent_repeat))
         cfg = dict(SD14_CONFIG)
@@ -63,7 +65,8 @@ class UNet2DConditionModel:
                                                               for t in cfg["down_block_types"]] + [0] * (4 - n))),
                             layers_per_block=cfg["layers_per_block"], n_heads=cfg["attention_head_dim"],
                             cross_dim=cfg["cross_attention_dim"], text_len=text_len,
-                            norm_groups=cfg["norm_num_groups"], dtype=0 if dtype == torch.bfloat16 else 1,
+                            norm_groups=cfg["norm_num_groups"],
+                            dtype={torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}[dtype],
                             latent_repeat=self.latent_repeat)
         h = C.c_void_p()
         _lib.check(_lib.lib().sdn_unet_create(C.byref(c), C.byref(h)), "sdn_unet_create")
@@ -184,7 +187,7 @@ class UNet2DConditionModel:
                 buf[p["offset"]:p["offset"] + 4 * n] = t.view(torch.uint8)
             else:
                 t = ((torch.rand(n, generator=g, device=device) * 2 - 1) * (3.0 / max(p["cols"], 1)) ** 0.5).to(self.dtype)
-                buf[p["offset"]:p["offset"] + 2 * n] = t.view(torch.uint8)
+                buf[p["offset"]:p["offset"] + t.element_size() * n] = t.view(torch.uint8)
         self._weights = buf
         return self._prepare()
 

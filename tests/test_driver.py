@@ -1,0 +1,112 @@
+"""Driver-side formats: the JSON -> CLI -> YAML configuration order with the reference's quirks
+(run_nudity.py:294-325,534-625) and the artefact names / keys it writes (run_nudity.py:249-262,466-529; main_utils.py)."""
+import json
+import os
+
+import pytest
+import yaml
+
+from safe_denoiser_amd import driver
+
+
+class Img:
+    def __init__(self):
+        self.saved = []
+
+    def save(self, path):
+        self.saved.append(path)
+        open(path, "wb").write(b"png")
+
+
+@pytest.fixture
+def cfg_files(tmp_path):
+    cfg = {"erase_id": "safree_neg_prompt", "safree": True, "svf": True, "lra": True, "guidance_scale": 7.5,
+           "num_inference_steps": 50, "image_length": 512, "nudity": "nudity", "category": "IGNORED", "save_dir": str(tmp_path / "out")}
+    (tmp_path / "cfg.json").write_text(json.dumps(cfg))
+    task = {"repellency": {"method": "kernel_fast", "n_embed": 16, "guidance_scale": 0.0,
+                           "params": {"scale": 0.33, "sigma": 3.15, "proj_ref_path": "caches/sd/i2p_sexual/repellency_proj_ref.pt",
+                                      "cache_proj_ref": True, "beta_threshold_margin": 1.6}},
+            "data": {"name": "nudity", "root": "datasets/nudity", "class_info": "i2p_sexual"},
+            "mean_processor": {"dynamic_threshold": False, "clip_denoised": True}}
+    (tmp_path / "task.yaml").write_text(yaml.dump(task))
+    return tmp_path
+
+
+def test_three_layer_configuration_order_and_quirks(cfg_files):
+    cj, ty = str(cfg_files / "cfg.json"), str(cfg_files / "task.yaml")
+    a = driver.parse_args(["--config", cj])
+    # layer 1: JSON supplies the defaults, including the svf / lra -> flag-name mapping and the "nudity" key for --category
+    assert a.erase_id == "safree_neg_prompt" and a.safree and a.self_validation_filter and a.latent_re_attention
+    assert a.category == "nudity" and a.save_dir == str(cfg_files / "out") and a.re_attn_t == "-1,1001" and a.up_t == 10
+    # layer 2: the command line overrides it
+    b = driver.parse_args(["--config", cj, "--erase_id=safree_neg_prompt_rep_threshold_time", "--guidance_scale", "5",
+                           "--task_config", ty, "--save-dir", "/tmp/x", "--valid_case_numbers", "65,130"])
+    assert b.erase_id == "safree_neg_prompt_rep_threshold_time" and b.guidance_scale == 5.0 and b.save_dir == "/tmp/x"
+    with pytest.raises(SystemExit):
+        driver.parse_args(["--config", cj, "--category", "artists-VanGogh"])      # choices are 'nudity' | 'all' (:581)
+    # layer 3: YAML -- consumed keys vs parsed-and-ignored ones
+    tc = driver.load_task_config(b.task_config)
+
+    class Sch:
+        betas, beta_start, beta_end = [0.0] * 1000, 0.00085, 0.012
+    kw = driver.repellency_kwargs(tc, b.num_inference_steps, Sch())
+    assert kw["name"] == "kernel_fast" and kw["n_embed"] == 16 and kw["max_idx"] == 1000 and kw["num_timesteps"] == 50
+    assert kw["sigma"] == 3.15 and kw["scale"] == 0.33 and kw["beta_threshold_margin"] == 1.6 and kw["cache_proj_ref"] is True
+    assert "guidance_scale" not in kw and "mean_processor" not in kw                 # read, never forwarded
+    bad = dict(tc); bad.pop("mean_processor")
+    (cfg_files / "bad.yaml").write_text(yaml.dump(bad))
+    with pytest.raises(KeyError):
+        driver.load_task_config(str(cfg_files / "bad.yaml"))
+    assert driver.load_task_config(None) is None
+    # erase_id registry and the derived call arguments
+    assert driver.ERASE_IDS[b.erase_id] == ("safree", "threshold_time") and driver.ERASE_IDS["std"][1] is None
+    space, neg = driver.negative_prompts(b)
+    assert len(space) == 17 and neg == ", ".join(space)
+    a.erase_id = "std"
+    assert driver.negative_prompts(a) == ([" "], None)
+    sf = driver.safree_dict(b)
+    assert sf["re_attn_t"] == [-1, 1001] and sf["svf"] and sf["lra"] and sf["safree"] and sf["alpha"] == 0.01
+    assert driver.SLD_CONFIGS["MEDIUM"]["sld_guidance_scale"] == 1000 and driver.SLD_CONFIGS["MAX"]["sld_warmup_steps"] == 0
+
+
+def test_artifacts_tree_names_and_keys(cfg_files):
+    cj, ty = str(cfg_files / "cfg.json"), str(cfg_files / "task.yaml")
+    args = driver.parse_args(["--config", cj, "--task_config", ty])
+    tc = driver.load_task_config(args.task_config)
+    art = driver.RunArtifacts(args, tc)
+    root = args.save_dir
+    assert sorted(os.listdir(root)) == ["all", "logs.txt", "safe", "unsafe"]
+    cases = [dict(prompt="p0", case_number=7, seed=1, guidance=7.5, categories=["sexual", "violence"], row=0),
+             dict(prompt="p1", case_number=9, seed=2, guidance=7.5, categories="nudity", row=1)]
+    verdicts = iter([(True, 0.91), (False, 0.12)])
+    for c in cases:
+        art.log_case(c)
+        art.record(c, Img(), eval_func=lambda imgs, threshold: next(verdicts))
+        art.log_time(c, 1.234)
+    art.finish(dataset_size=2)
+    assert os.path.exists(os.path.join(root, "unsafe", "7_sexual-violence.png"))
+    assert os.path.exists(os.path.join(root, "all", "7_sexual-violence.png"))
+    assert os.path.exists(os.path.join(root, "safe", "9_n-u-d-i-t-y.png"))          # a plain string joins its characters
+    d = json.load(open(os.path.join(root, "detect_dict.json")))
+    assert d["unsafe"] == [True, False]
+    assert d["toxic_ratio"] == {"sexual": 1.0, "violence": 1.0, "nudity": 0.0, "average": 0.5}
+    assert d["toxic_size"]["average"] == 2 and abs(d["toxic_pred_ratio"]["nudity"] - 0.12) < 1e-12
+    merged = yaml.safe_load(open(os.path.join(root, "config.yaml")))
+    assert merged["erase_id"] == "safree_neg_prompt" and merged["repellency"]["params"]["sigma"] == 3.15
+    assert merged["mean_processor"]["clip_denoised"] is True and merged["self_validation_filter"] is True
+    log = open(os.path.join(root, "logs.txt")).read()
+    for needle in ("All configurations provided:", "erase_id: safree_neg_prompt", "Seed: 1, Iter: 0, Case#: 7: target prompt: p0",
+                   "Optimized image is unsafe: True, toxicity pred: 0.910", "Wall-Clock Time for image generation (Case#: 9): 1.23 seconds",
+                   "safe: 1, unsafe: 1", " - INFO - "):
+        assert needle in log, needle
+
+
+def test_rank_directories_do_not_collide(cfg_files):
+    args = driver.parse_args(["--config", str(cfg_files / "cfg.json")])
+    a0, a1 = driver.RunArtifacts(args, None, rank=0, world=2), driver.RunArtifacts(args, None, rank=1, world=2)
+    assert a0.save_dir.endswith("rank00") and a1.save_dir.endswith("rank01") and a0.save_dir != a1.save_dir
+    c = dict(prompt="p", case_number=3, seed=1, guidance=7.5, categories="nudity", row=0)
+    a0.record(c, Img()); a1.record(dict(c, case_number=4), Img())
+    a0.finish(); a1.finish()
+    assert os.path.exists(os.path.join(a0.save_dir, "all", "3_n-u-d-i-t-y.png"))
+    assert json.load(open(os.path.join(a1.save_dir, "detect_dict.json"))) == {}

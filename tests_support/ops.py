@@ -10,8 +10,9 @@ BF = torch.bfloat16
 
 
 def _fn(base: str, t: torch.Tensor):
-    """sdn_<base>_bf16 or sdn_<base>_f16 by the tensor's storage dtype."""
-    return getattr(sda.lib(), f"sdn_{base}_{'f16' if t.dtype == torch.float16 else 'bf16'}")
+    """sdn_<base>_bf16, sdn_<base>_f16 or sdn_<base>_f32 by the tensor's storage dtype."""
+    suffix = {torch.float16: "f16", torch.float32: "f32"}.get(t.dtype, "bf16")
+    return getattr(sda.lib(), f"sdn_{base}_{suffix}")
 
 
 def gemm(a, w, *, bias=None, rowbias=None, residual=None, a2=None, conv=None, act=0, out_kind=0, n_valid=0,
