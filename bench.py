@@ -316,6 +316,7 @@ def main():
     # the denominators of every window step; the gate is then put at their median, so that about half of the
     # (prompt, window step) pairs fire in the timed region (the measured fraction is reported).
     r5_beta = beta
+    placement = "R5 threshold - margin"
     fire_target = args.fire_fraction
     if fire_target > 0:
         proc.beta_threshold = float("inf")
@@ -323,8 +324,15 @@ def main():
         run(0)
         dens = torch.cat(pipe.last_stats["denominators"]).float()
         pipe.record_den = False
-        gate = float(torch.quantile(dens, 1.0 - fire_target)) if rank == 0 else 0.0
-        gate = sdist.broadcast_scalar(gate, dev)
+        lo_d, hi_d = float(dens.min()), float(dens.max())
+        if hi_d > lo_d * (1.0 + 1e-6):
+            gate, placement = float(torch.quantile(dens, 1.0 - fire_target)), f"den quantile {1.0 - fire_target:.2f} of an untimed probe batch"
+        else:
+            # degenerate: with RANDOM UNet weights every x0 probe is ~1e3 away from every reference, all weights underflow and
+            # every denominator equals epsilon -- no threshold separates the prompts.  Take the worst case instead: the
+            # gate below all of them, so EVERY (prompt, window step) pair draws a re-noise tensor and runs the select.
+            gate, placement = 0.5 * lo_d, "below every denominator of an untimed probe batch (they all equal epsilon on synthetic weights): every pair fires"
+        gate = sdist.broadcast_scalar(gate if rank == 0 else 0.0, dev)
         proc.beta_threshold = gate + float(proc.beta_threshold_margin)          # is_negation = den > beta - margin = gate
         beta = proc.beta_threshold
     for k in range(args.warmup):
@@ -429,8 +437,7 @@ def main():
                    "prompts_per_batch": P, "latent_repeat": unet.latent_repeat, "images_timed": n_img, "beta_threshold": beta,
                    "renoise_draws_rank0": renoise,
                    "gate": {"r5_calibrated_beta_threshold": r5_beta, "margin": float(proc.beta_threshold_margin),
-                            "placement": (f"den quantile {1.0 - fire_target:.2f} of an untimed probe batch" if fire_target > 0
-                                          else "R5 threshold - margin"),
+                            "placement": placement,
                             "fired_fraction_rank0": renoise / max(window_pairs, 1)},
                    "parallelism": f"prompt-shard x{world}",
                    "per_rank_images_per_sec": per_rank, "proj_ref_broadcast_ms": bcast_ms},
