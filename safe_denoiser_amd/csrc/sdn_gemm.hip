@@ -728,3 +728,40 @@ extern "C" int sdn_ln_fold(int32_t dtype, const void* w, const float* gamma, con
                        bias, cols, (unsigned short*)w_folded, c, dvec);
   return sdn_launch_status();
 }
+
+// ---- product of two linears (sdn_linear_pair_fold, sdn_ops.h): prepare-time, one thread per output element --------------
+namespace {
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_linear_pair_fold(const unsigned short* __restrict__ wa, const unsigned short* __restrict__ wb, const float* __restrict__ ba,
+                   const float* __restrict__ bb, int C, int K, unsigned short* __restrict__ wcat, float* __restrict__ bcat) {
+  const int n = blockIdx.y;
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  const int KC = K + C;
+  if (k < K) {
+    float acc = 0.f;
+    for (int j = 0; j < C; ++j) acc = fmaf(T::to_f(wb[(long)n * C + j]), T::to_f(wa[(long)j * K + k]), acc);
+    wcat[(long)n * KC + k] = (unsigned short)(T::pack2(acc, 0.f) & 0xffffu);
+  } else if (k < KC) {
+    wcat[(long)n * KC + k] = wb[(long)n * C + (k - K)];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    float acc = bb ? bb[n] : 0.f;
+    if (ba) for (int j = 0; j < C; ++j) acc = fmaf(T::to_f(wb[(long)n * C + j]), ba[j], acc);
+    bcat[n] = acc;
+  }
+}
+}  // namespace
+
+int sdn_linear_pair_fold(int dtype, const void* wa, const void* wb, const float* ba, const float* bb, int C, int K, void* w_cat,
+                         float* b_cat, void* stream) {
+  if (!wa || !wb || !w_cat || !b_cat || C <= 0 || K <= 0 || dtype < 0 || dtype > 1) return SDN_E_INVALID;
+  const dim3 grid((K + C + 255) / 256, C);
+  if (dtype == 1)
+    hipLaunchKernelGGL((k_linear_pair_fold<SdnF16>), grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)wa,
+                       (const unsigned short*)wb, ba, bb, C, K, (unsigned short*)w_cat, b_cat);
+  else
+    hipLaunchKernelGGL((k_linear_pair_fold<SdnBF16>), grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)wa,
+                       (const unsigned short*)wb, ba, bb, C, K, (unsigned short*)w_cat, b_cat);
+  return sdn_launch_status();
+}

@@ -15,3 +15,9 @@ int sdn_gemm_pick_split(int M, int N, int K, int act, int out_kind);
 
 // fp32 precision mode (sdn_f32.hip): timestep features from a host scalar or from device memory (graph mode)
 int sdn_temb_f32(float timestep, const float* t_dev, int batch, int dim, void* out, void* stream);
+
+// Two linears with nothing but a residual between them, out = Wb (h + Wa f + ba) + bb, as one contraction over [f | h]:
+// w_cat [C][K + C] = [Wb Wa | Wb] (16 bit, product formed in fp32 and rounded once), b_cat[C] = Wb ba + bb.
+// wa [C][K], wb [C][C] in the plan's 16-bit dtype (0 = bf16, 1 = f16).  Prepare-time helper (sdn_unet_prepare).
+int sdn_linear_pair_fold(int dtype, const void* wa, const void* wb, const float* ba, const float* bb, int C, int K, void* w_cat,
+                         float* b_cat, void* stream);

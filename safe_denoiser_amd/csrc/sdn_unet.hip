@@ -140,7 +140,9 @@ struct sdn_unet {
   bool use_graph = false;
   bool gn_fuse = true;                  // GroupNorm statistics from the producing GEMMs' column partials (hw % 128 == 0)
   bool ln_fold = true;                  // BasicTransformerBlock LayerNorms folded into their consumer GEMMs where it pays
-  struct FoldJob { int64_t w, gamma, beta, bias, wf, c, d; int rows, cols; };
+  bool ff_fuse = true;                  // FeedForward's output linear and the block's proj_out (no nonlinearity between them)
+                                        // contracted into ONE GEMM over [ff | h3] with the product weight (sdn_linear_pair_fold)
+  struct FoldJob { int64_t w, gamma, beta, bias, wf, c, d; int rows, cols; int kind = 0; };   // kind 0: LayerNorm fold; 1: linear pair
   std::vector<FoldJob> fold_jobs;       // what sdn_unet_prepare has to compute into the SDN_P_DERIVED regions
   bool split_k = false;                 // sdn_unet_set_split_k: small-M GEMMs of the plan take the split-K form (off by
                                         // default: it changes fp32 summation order with the batch size, and batch rows are
@@ -484,6 +486,18 @@ struct Builder {
       gemm(rows, 8 * C, C, R(ln), f1w, f1b, R(ff), SDN_ACT_GEGLU);
     }
     if (ln.off >= 0) drop(ln);
+    if (u->ff_fuse) {
+      // out = x + Wpo (h3 + W2 ff + b2) + bpo = x + [ff | h3] . [Wpo W2 | Wpo]^T + (Wpo b2 + bpo): the FeedForward output linear
+      // and proj_out are one GEMM (two-source A operand, K = 5C); the [M, C] tensor between them is never written or re-read
+      // and the worst-shaped launch of the block (M x C x C) disappears.  The product weight is derived once per weight set.
+      const bool fresh = u->param_index.find(pfx + ".proj_out.weight#ff") == u->param_index.end();
+      Ref wcat = derived(pfx + ".proj_out.weight#ff", (int64_t)C * 5 * C * 2), bcat = derived(pfx + ".proj_out.bias#ff", (int64_t)C * 4);
+      if (fresh) { sdn_unet::FoldJob j{f2w.off, pow_.off, f2b.off, pob.off, wcat.off, bcat.off, -1, C, 4 * C}; j.kind = 1; u->fold_jobs.push_back(j); }
+      want_stats(out);
+      gemm(rows, C, 5 * C, R(ff), wcat, bcat, R(out), SDN_ACT_NONE, R(rep > 1 ? *x_full : x), SDN_OUT_BF16, 0, R(h3), 4 * C);
+      drop(ff); drop(h3);
+      return;
+    }
     Act h4 = act(rows, C, hw, x.side);
     gemm(rows, C, 4 * C, R(ff), f2w, f2b, R(h4), SDN_ACT_NONE, R(h3));
     drop(ff); drop(h3);
@@ -1171,7 +1185,7 @@ int sdn_unet_create(const sdn_unet_config* cfg, sdn_unet** out) {
   }
   sdn_unet* u = new sdn_unet();
   u->cfg = *cfg;
-  if (cfg->dtype == 2) { u->gn_fuse = false; u->ln_fold = false; }   // fp32 precision mode: the plain operator chain (sdn_f32.hip)
+  if (cfg->dtype == 2) { u->gn_fuse = false; u->ln_fold = false; u->ff_fuse = false; }   // fp32 precision mode: the plain operator chain (sdn_f32.hip)
   get_plan(u, cfg->latent_repeat > 1 ? cfg->latent_repeat : 1);   // registers the parameter manifest (batch-independent)
   *out = u;
   return SDN_OK;
@@ -1257,6 +1271,12 @@ int sdn_unet_prepare(sdn_unet* u, void* weights, void* stream) {
   char* W = (char*)weights;
   const int dt = (u->is_mmdit ? u->mcfg.dtype : u->cfg.dtype) == 1 ? 1 : 0;
   for (const auto& j : u->fold_jobs) {
+    if (j.kind == 1) {
+      const int rc1 = sdn_linear_pair_fold(dt, W + j.w, W + j.gamma, (const float*)(W + j.beta), (const float*)(W + j.bias), j.rows, j.cols,
+                                           W + j.wf, (float*)(W + j.c), stream);
+      if (rc1 != SDN_OK) return rc1;
+      continue;
+    }
     const int rc = sdn_ln_fold(dt, W + j.w, (const float*)(W + j.gamma), (const float*)(W + j.beta),
                                j.bias >= 0 ? (const float*)(W + j.bias) : nullptr, j.rows, j.cols, W + j.wf, (float*)(W + j.c),
                                (float*)(W + j.d), stream);
@@ -1568,6 +1588,13 @@ void sdn_unet_set_graph_mode(sdn_unet* u, int32_t on) {
 extern "C" void sdn_debug_set_ln_fold(sdn_unet* u, int on) {
   if (!u) return;
   u->ln_fold = on != 0;
+  drop_graphs(u);
+  u->plans.clear();
+}
+
+extern "C" void sdn_debug_set_ff_fuse(sdn_unet* u, int on) {
+  if (!u) return;
+  u->ff_fuse = on != 0;
   drop_graphs(u);
   u->plans.clear();
 }
