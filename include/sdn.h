@@ -448,8 +448,9 @@ typedef struct sdn_vae_config {
 int sdn_vae_decoder_create(const sdn_vae_config* cfg_host, sdn_unet** out_host);
 /* image [B, out_channels, 8S.., 8S..] fp32 NCHW (the decoder's raw output, nominally in [-1, 1]) =
  * decoder(post_quant_conv(latent_scale * latents [B, latent_channels, S, S] fp32)).  latent_scale = 1 / scaling_factor
- * folds the first line of decode_latents.  The batch is bounded by 32-bit byte offsets inside one activation
- * (15 images at 512 x 512): larger batches return SDN_E_INVALID -- decode in chunks. */
+ * folds the first line of decode_latents.  Any batch: byte offsets inside one activation are 32-bit, so the entry
+ * point replays the plan on chunks of at most 8 images (fewer at 1024 x 1024) against the same workspace, stream-ordered;
+ * sdn_unet_workspace_bytes(vae, batch) returns the size of the largest chunk's workspace. */
 int sdn_vae_decode(sdn_unet* vae, const void* weights, const float* latents, float latent_scale, float* image,
                    int32_t batch, void* workspace, size_t workspace_bytes, void* stream);
 /* Encoder half: the embed_fn of the proj_ref builder, `pipe.vae.encode(x).latent_dist.sample() * scaling_factor`

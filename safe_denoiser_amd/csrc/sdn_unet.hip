@@ -1297,8 +1297,14 @@ int sdn_unet_param_info(const sdn_unet* u, int32_t index, sdn_param_info* info) 
 
 size_t sdn_unet_weight_bytes(const sdn_unet* u) { return u ? (size_t)u->weight_bytes : 0; }
 
+static int vae_chunk(const sdn_unet* v);
 size_t sdn_unet_workspace_bytes(sdn_unet* u, int32_t batch) {
   if (!u || batch <= 0) return 0;
+  if (u->is_vae) {                                                 // VAE entry points run large batches in chunks of vae_chunk()
+    const int cap = vae_chunk(u);
+    if (cap == 0) return 0;
+    if (batch > cap) batch = cap;
+  }
   const int64_t b = get_plan(u, batch)->ws_bytes;
   return b < 0 ? 0 : (size_t)b;
 }
@@ -1313,29 +1319,51 @@ double sdn_unet_flops(sdn_unet* u, int32_t batch, double* attn) {
 static int run_plan(sdn_unet* u, const void* weights, const float* latents, float timestep, const void* text,
                     const void* pooled, float* out, int32_t batch, void* workspace, size_t workspace_bytes, void* stream);
 
-int sdn_vae_decode(sdn_unet* v, const void* weights, const float* latents, float latent_scale, float* image, int32_t batch,
-                   void* workspace, size_t workspace_bytes, void* stream) {
-  if (!v || !v->is_vae || v->is_vae_encoder) return SDN_E_INVALID;
-  // byte offsets inside one activation are 32-bit in the GEMM's DMA descriptors: bound the batch by the largest tensor
+// Images one plan invocation of a VAE takes: byte offsets inside one activation are 32-bit in the GEMM's DMA descriptors, so the
+// largest tensor (batch x side^2 x widest channel count x 2 B) must stay below 4 GiB; larger batches are cut into chunks INSIDE
+// the entry points (each chunk replays the same plan on the same workspace, stream-ordered).
+static int vae_chunk(const sdn_unet* v) {
   const sdn_vae_config& c = v->vcfg;
   const int64_t side = (int64_t)c.sample_size << (c.n_levels - 1);
   int64_t cmax = 0;
   for (int i = 0; i < c.n_levels; ++i) if (c.block_out_channels[i] > cmax) cmax = c.block_out_channels[i];
-  if (batch > 0 && (int64_t)batch * side * side * cmax * 2 >= ((int64_t)1 << 32)) return SDN_E_INVALID;
-  return run_plan(v, weights, latents, latent_scale, weights /* no text operand */, nullptr, image, batch, workspace,
-                  workspace_bytes, stream);
+  int64_t cap = (((int64_t)1 << 32) - 1) / (side * side * cmax * 2);
+  if (cap > 8) cap = 8;                                            // (beyond 8 images the kernels are saturated; bounds the workspace)
+  return cap < 1 ? 0 : (int)cap;
+}
+
+int sdn_vae_decode(sdn_unet* v, const void* weights, const float* latents, float latent_scale, float* image, int32_t batch,
+                   void* workspace, size_t workspace_bytes, void* stream) {
+  if (!v || !v->is_vae || v->is_vae_encoder || batch < 0) return SDN_E_INVALID;
+  const int cap = vae_chunk(v);
+  if (cap == 0) return SDN_E_INVALID;                              // a single image already exceeds the 32-bit offsets
+  const sdn_vae_config& c = v->vcfg;
+  const int64_t side = (int64_t)c.sample_size << (c.n_levels - 1);
+  const int64_t lat_n = (int64_t)c.latent_channels * c.sample_size * c.sample_size, img_n = (int64_t)c.out_channels * side * side;
+  for (int lo = 0; lo < batch; lo += cap) {
+    const int nb = batch - lo < cap ? batch - lo : cap;
+    const int rc = run_plan(v, weights, latents + lo * lat_n, latent_scale, weights /* no text operand */, nullptr, image + lo * img_n,
+                            nb, workspace, workspace_bytes, stream);
+    if (rc != SDN_OK) return rc;
+  }
+  return SDN_OK;
 }
 
 int sdn_vae_encode(sdn_unet* v, const void* weights, const float* image, float* moments, int32_t batch, void* workspace,
                    size_t workspace_bytes, void* stream) {
-  if (!v || !v->is_vae || !v->is_vae_encoder) return SDN_E_INVALID;
+  if (!v || !v->is_vae || !v->is_vae_encoder || batch < 0) return SDN_E_INVALID;
+  const int cap = vae_chunk(v);
+  if (cap == 0) return SDN_E_INVALID;
   const sdn_vae_config& c = v->vcfg;
   const int64_t side = (int64_t)c.sample_size << (c.n_levels - 1);
-  int64_t cmax = 0;
-  for (int i = 0; i < c.n_levels; ++i) if (c.block_out_channels[i] > cmax) cmax = c.block_out_channels[i];
-  if (batch > 0 && (int64_t)batch * side * side * cmax * 2 >= ((int64_t)1 << 32)) return SDN_E_INVALID;
-  return run_plan(v, weights, image, 1.0f, weights /* no text operand */, nullptr, moments, batch, workspace, workspace_bytes,
-                  stream);
+  const int64_t img_n = (int64_t)c.out_channels * side * side, mom_n = (int64_t)2 * c.latent_channels * c.sample_size * c.sample_size;
+  for (int lo = 0; lo < batch; lo += cap) {
+    const int nb = batch - lo < cap ? batch - lo : cap;
+    const int rc = run_plan(v, weights, image + lo * img_n, 1.0f, weights /* no text operand */, nullptr, moments + lo * mom_n, nb,
+                            workspace, workspace_bytes, stream);
+    if (rc != SDN_OK) return rc;
+  }
+  return SDN_OK;
 }
 
 int sdn_clip_forward(sdn_unet* m, const void* weights, const int32_t* input_ids, const int32_t* attention_mask,

@@ -275,3 +275,42 @@ class RunArtifacts:
         with open(os.path.join(self.save_dir, "detect_dict.json"), "w") as f:
             json.dump(self.detect, f, indent=4)
         self.logger.close()
+
+
+def run_job(args, pipe, repellency_processor=None, task_config: Optional[Mapping[str, Any]] = None, eval_func: Optional[Callable] = None,
+            prompts_per_batch: int = 64, rank: int = 0, world: int = 1, device="cuda") -> RunArtifacts:
+    """The body of the reference's main() after model loading (run_nudity.py:341-529) on the batched engine: read the prompt
+    table (`args.data`, `--valid_case_numbers`), shard it over the ranks, and for every batch of prompts that share a guidance
+    scale call `pipe(prompt, ..., negative_prompt, negative_prompt_space, generator, repellency_processor, safree_dict,
+    **SLD config)` once, then save / classify / log every image exactly as the reference does per prompt.
+    `pipe`: a SafeDenoiserPipeline with text_encoder, tokenizer and vae attached (images come back as PIL)."""
+    import time
+
+    from . import cases as _cases
+    art = RunArtifacts(args, task_config, rank=rank, world=world)
+    log = art.logger
+    family, _variant = ERASE_IDS[args.erase_id]
+    space, neg = negative_prompts(args)
+    safe_config = SLD_CONFIGS[args.safe_level] if "sld" in args.erase_id else None
+    if safe_config is not None:
+        log.log(f"SLD safe level: {args.safe_level}")
+        log.log(f"SLD safe config: {safe_config}")
+    if task_config is not None:
+        log.log(f"Repellency method : {task_config['repellency']['method']}")
+    table = _cases.read_cases(args.data, args.valid_case_numbers, default_guidance=args.guidance_scale)
+    for batch in _cases.batches(table, prompts_per_batch, rank, world):
+        for c in batch:
+            art.log_case(c)
+        t0 = time.time()
+        sf = safree_dict(args, logger=log)
+        imgs = pipe([c["prompt"] for c in batch], num_inference_steps=args.num_inference_steps, guidance_scale=batch[0]["guidance"],
+                    negative_prompt=neg, negative_prompt_space=space, height=args.image_length, width=args.image_length,
+                    generator=_cases.generators(batch, device=device),
+                    repellency_processor=repellency_processor if args.task_config is not None else None,
+                    safree_dict=sf, return_latents=False, output_type="pil", **(safe_config or {}))
+        dt = time.time() - t0
+        for c, im in zip(batch, imgs):
+            art.log_time(c, dt / len(batch))                       # the batch's wall clock, per image
+            art.record(c, im, eval_func=eval_func)
+    art.finish(dataset_size=len(table))
+    return art

@@ -36,7 +36,8 @@ class SD3SafeDenoiserPipeline:
                  num_inference_steps: int = 50, guidance_scale: float = 7.0, generator=None, latents=None,
                  prompt_embeds: Optional[torch.Tensor] = None, pooled_prompt_embeds: Optional[torch.Tensor] = None,
                  repellency_processor=None, latents_dtype=torch.float16, return_latents: bool = True,
-                 noise_fn: Optional[Callable] = None, **kwargs):
+                 noise_fn: Optional[Callable] = None, rescaled_text_embeddings: Optional[torch.Tensor] = None,
+                 masked_embs=None, negspace_embs: Optional[torch.Tensor] = None, safree_alpha: float = 0.01, **kwargs):
         _lib.require_gpu()
         if prompt_embeds is None or pooled_prompt_embeds is None:
             raise NotImplementedError("text encoders are outside the hot path: pass prompt_embeds [2P,T,4096] and "
@@ -56,7 +57,21 @@ class SD3SafeDenoiserPipeline:
         if height is not None and (height // self.vae_scale_factor, (width or height) // self.vae_scale_factor) != (s, s):
             raise _lib.SdnError(f"this MMDiT plan is built for {s * 8}x{s * 8} images")
         shape1 = (1, C_, s, s)
-        text = tr.prepare_text(prompt_embeds.to(dev))
+        # SAFREE on the T5-side embeddings (models/sdv3/safe_denoiser_pipeline.py:1061-1078): the reference's loop feeds the
+        # projected text to the transformer at EVERY step (:1115).  The T5 / CLIP encoders are outside this engine: the caller
+        # passes either the finished `rescaled_text_embeddings` [2P,T,4096], or the first-token T5 states it takes its
+        # projectors from (`masked_embs`: one [n_tokens, 4096] tensor per prompt, `negspace_embs` [n_phrases, 4096]).
+        if rescaled_text_embeddings is None and masked_embs is not None and negspace_embs is not None:
+            from . import safree
+            E = prompt_embeds.to(dev)
+            rows = []
+            for p_ in range(P):
+                pair = torch.stack([E[p_], E[P + p_]])
+                rows.append(safree.prepare_sd3(pair, masked_embs[p_].to(dev), negspace_embs.to(dev), alpha=safree_alpha)
+                            ["rescaled_text_embeddings"][1])
+            rescaled_text_embeddings = torch.cat([E[:P], torch.stack(rows).to(E.dtype)])
+        text_src = prompt_embeds if rescaled_text_embeddings is None else rescaled_text_embeddings
+        text = tr.prepare_text(text_src.to(dev))
         pooled = pooled_prompt_embeds.to(device=dev, dtype=tr.dtype).contiguous()
 
         sch = self.scheduler

@@ -79,3 +79,48 @@ def prepare(text_embeddings: torch.Tensor, masked_embs: torch.Tensor, negspace: 
         out["beta"] = beta
         out["beta_adjusted"] = f_beta(beta, upperbound_timestep=up_t, concept_type=category)
     return out
+
+
+# ---- SD-v3 variant (models/sdv3/safe_denoiser_pipeline.py:72-153,1061-1078): T5 hidden states, 16-bit matmuls ------------
+def projection_matrix_sd3(E: torch.Tensor) -> torch.Tensor:
+    """:72-82: the same projector, computed in fp32 whatever the embeddings' dtype."""
+    Ef = E.float()
+    return Ef @ torch.pinverse(Ef.T @ Ef) @ Ef.T
+
+
+def mask_to_onp(input_embeddings: torch.Tensor, p_emb: torch.Tensor, masked_proj: torch.Tensor, concept_proj: torch.Tensor,
+                alpha: float = 0.0, max_length: int = 333):
+    """:100-153.  As safree_projection, with the reference's dtype quirks kept: the two matrix products run in bfloat16
+    ((I - P_c).bfloat16() @ p_emb.T.bfloat16(), and (I - P_c).bf16 @ P_m.bf16 @ text.T.bf16), the distance norm and the
+    leave-one-out means in that dtype's values; the token mask is written at positions 1..n_t of a length-`max_length` vector
+    (the 333 = 77 CLIP + 256 T5 token axis).  Returns (embeddings [2, max_length, dim], keep mask [max_length, 1],
+    inverse mask [max_length], n_removed)."""
+    n_t, dim = p_emb.shape
+    dev = p_emb.device
+    eye_m_c = torch.eye(dim, device=dev) - concept_proj
+    dist = torch.norm(eye_m_c.bfloat16() @ p_emb.T.bfloat16(), dim=0)
+    means = [torch.mean(torch.cat((dist[:i], dist[i + 1:]))) for i in range(n_t)]
+    mean_dist = torch.tensor(means).to(dev)                                   # float32 copies of the bf16 means, as torch.tensor() makes
+    keep = (dist < (1.0 + alpha) * mean_dist).float()
+    inv = (dist >= (1.0 + alpha) * mean_dist).float()
+    n_removed = n_t - keep.sum()
+    ones = torch.ones(max_length, device=dev)
+    ones[1:n_t + 1] = keep
+    ones = ones.unsqueeze(1)
+    inverse = torch.ones(max_length, device=dev)
+    inverse[1:n_t + 1] = inv
+    uncond_e, text_e = input_embeddings.chunk(2)
+    text_e = text_e.squeeze()
+    projected = (eye_m_c.bfloat16() @ masked_proj.bfloat16() @ text_e.T.bfloat16()).T
+    merged = torch.where(ones.bool(), text_e, projected)
+    return torch.cat([uncond_e, merged.unsqueeze(0)]), ones, inverse, n_removed.item()
+
+
+def prepare_sd3(text_embeddings: torch.Tensor, masked_embs: torch.Tensor, negspace: torch.Tensor, *, alpha: float = 0.01) -> dict:
+    """The call sequence of the SD-v3 pipeline (:1061-1078): masked_embs = first-token T5 states of the prompt with each
+    token masked in turn, negspace = first-token T5 states of the concept phrases; the loop then feeds the result to the
+    transformer at EVERY step (:1115)."""
+    P_m = projection_matrix_sd3(masked_embs.T)
+    P_c = projection_matrix_sd3(negspace.T)
+    resc, keep, inv, n_removed = mask_to_onp(text_embeddings, masked_embs, P_m, P_c, alpha=alpha, max_length=text_embeddings.shape[1])
+    return {"rescaled_text_embeddings": resc, "sp_vector": keep, "inv_vector": inv, "n_removed": n_removed}

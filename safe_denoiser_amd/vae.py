@@ -82,7 +82,7 @@ class AutoencoderKL(UNet2DConditionModel):
     sample_size / 2**(levels-1).  The object itself is the decoder half; `.encoder_half` (built on first use or when
     the state_dict carries `encoder.*`) is the same class in the encoder role."""
 
-    MAX_CHUNK = 8                      # images per sdn_vae_* call (32-bit offsets bound it at 15 for 512 x 512)
+    MAX_CHUNK = 8                      # images per plan invocation; sdn_vae_* chunk larger batches themselves (32-bit DMA offsets)
 
     def __init__(self, dtype=torch.bfloat16, _role: str = "decoder", **config):
         if dtype not in (torch.bfloat16, torch.float16):
@@ -194,12 +194,10 @@ class AutoencoderKL(UNet2DConditionModel):
             raise _lib.SdnError(f"images must be [B,{enc.config.out_channels},{side},{side}], got {tuple(x.shape)}")
         L, s = enc.config.latent_channels, enc.latent_size
         mom = torch.empty((x.shape[0], 2 * L, s, s), dtype=torch.float32, device=x.device)
-        for lo in range(0, x.shape[0], enc.MAX_CHUNK):
-            hi = min(lo + enc.MAX_CHUNK, x.shape[0])
-            ws = enc._workspace(hi - lo, x.device)
-            _lib.check(_lib.lib().sdn_vae_encode(enc._h, _lib.dptr(enc._weights), _lib.dptr(x[lo:hi], torch.float32),
-                                                 _lib.dptr(mom[lo:hi], torch.float32), hi - lo, _lib.dptr(ws), ws.numel(),
-                                                 _lib.stream_ptr()), "sdn_vae_encode")
+        ws = enc._workspace(x.shape[0], x.device)                      # the entry point chunks large batches itself
+        _lib.check(_lib.lib().sdn_vae_encode(enc._h, _lib.dptr(enc._weights), _lib.dptr(x, torch.float32),
+                                             _lib.dptr(mom, torch.float32), x.shape[0], _lib.dptr(ws), ws.numel(),
+                                             _lib.stream_ptr()), "sdn_vae_encode")
         dist = DiagonalGaussianDistribution(mom)
         return EncoderOutput(dist) if return_dict else (dist,)
 
@@ -226,9 +224,7 @@ class AutoencoderKL(UNet2DConditionModel):
             raise _lib.SdnError(f"latents must be [B,{self.config.latent_channels},{s},{s}], got {tuple(z.shape)}")
         side = s * self.up_factor
         out = torch.empty((z.shape[0], self.config.out_channels, side, side), dtype=torch.float32, device=z.device)
-        for lo in range(0, z.shape[0], self.MAX_CHUNK):
-            hi = min(lo + self.MAX_CHUNK, z.shape[0])
-            self._decode_into(z[lo:hi], latent_scale, out[lo:hi])
+        self._decode_into(z, latent_scale, out)                         # any batch: sdn_vae_decode chunks internally
         return DecoderOutput(out) if return_dict else (out,)
 
     def postprocess(self, image: torch.Tensor, uint8: bool = False) -> torch.Tensor:

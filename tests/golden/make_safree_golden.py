@@ -21,16 +21,17 @@ import numpy as np
 import torch
 
 SRC = "/root/reference/models/textuals_visual/modified_safree_diffusion_pipeline_threshold_time.py"
+SRC_SD3 = "/root/reference/models/sdv3/safe_denoiser_pipeline.py"      # projection_matrix / mask_to_onp, lines 71-153
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "safree_golden.npz")
 WANT = ("sigmoid", "f_beta", "projection_matrix", "projection_and_orthogonal", "safree_projection")
 
 
-def load_helpers():
-    tree = ast.parse(open(SRC).read(), SRC)
-    body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in WANT]
-    assert sorted(n.name for n in body) == sorted(WANT), [n.name for n in body]
+def load_helpers(src=SRC, want=WANT):
+    tree = ast.parse(open(src).read(), src)
+    body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in want]
+    assert sorted(n.name for n in body) == sorted(want), [n.name for n in body]
     ns = {"torch": torch, "math": math, "F": torch.nn.functional}
-    exec(compile(ast.Module(body=body, type_ignores=[]), SRC, "exec"), ns)
+    exec(compile(ast.Module(body=body, type_ignores=[]), src, "exec"), ns)
     return ns
 
 
@@ -77,6 +78,27 @@ def main():
             store[f"{name}/{k}"] = v.numpy()
         store[f"{name}/alpha"] = np.float64(alpha)
         store[f"{name}/n_removed"] = np.int64(n_removed)
+    # ---- SD-v3 variant: projection_matrix (fp32 pinverse) + mask_to_onp (bf16 products), a 333-token axis ----
+    sd3 = load_helpers(SRC_SD3, ("projection_matrix", "mask_to_onp"))
+    sd3_names = []
+    for ci, (dim, n_t, n_neg, alpha, dt) in enumerate([(128, 9, 17, 0.01, torch.float32), (256, 14, 17, 0.01, torch.float16)]):
+        g = torch.Generator().manual_seed(300 + ci)
+        ie = torch.randn(2, 333, dim, generator=g).to(dt)
+        neg = torch.randn(n_neg, dim, generator=g).to(dt)
+        p_emb = torch.randn(n_t, dim, generator=g).to(dt)
+        p_emb[3] = (neg[:4].float().mean(0) * 3 + 0.05 * p_emb[3].float()).to(dt)
+        P_m = sd3["projection_matrix"](p_emb.T)
+        P_c = sd3["projection_matrix"](neg.T)
+        with contextlib.redirect_stdout(io.StringIO()):
+            resc, keep, inv, n_removed = sd3["mask_to_onp"](ie, p_emb, P_m, P_c, alpha=alpha, debug=False)
+        name = f"sd3_case{ci}"
+        sd3_names.append(name)
+        for k, v in dict(ie=ie, neg=neg, p_emb=p_emb, rescaled=resc, keep=keep, inv=inv).items():
+            store[f"{name}/{k}"] = v.float().numpy()
+        store[f"{name}/alpha"] = np.float64(alpha)
+        store[f"{name}/n_removed"] = np.float64(n_removed)
+        store[f"{name}/f16"] = np.int64(dt == torch.float16)
+    store["__sd3_cases__"] = np.asarray(sd3_names)
     store["__cases__"] = np.asarray(names)
     np.savez_compressed(OUT, **store)
     print(f"wrote {OUT}: f_beta grid {store['f_beta/out'].shape}, {len(names)} projection cases")

@@ -1,0 +1,73 @@
+"""The driver loop end to end on the engine: a prompt table in the i2p dialect -> `run_job` -> the
+reference's output tree, with the configuration read through the JSON -> CLI -> YAML layers.  Small synthetic UNet / CLIP /
+VAE, a stand-in tokenizer and a stand-in classifier (NudeNet is out of scope)."""
+import json
+import os
+
+import pytest
+import torch
+import yaml
+
+from oracle import repellency as orp
+from safe_denoiser_amd import driver
+from safe_denoiser_amd.clip import CLIPTextModel
+from safe_denoiser_amd.pipeline import SafeDenoiserPipeline
+from safe_denoiser_amd.repellency import repellency_methods_threshold as thr
+from safe_denoiser_amd.schedulers import DDPMScheduler
+from safe_denoiser_amd.unet import UNet2DConditionModel
+from safe_denoiser_amd.vae import AutoencoderKL
+from tests.test_gpu_pipeline import SMALL
+from tests.test_gpu_safree_call import CLIP_CFG
+from tests_support.fake_tokenizer import FakeCLIPTokenizer
+
+pytestmark = pytest.mark.gpu
+
+
+def test_run_job_writes_the_reference_tree(tmp_path):
+    rows = ["Unnamed: 0,prompt,categories,evaluation_seed,evaluation_guidance,case_number",
+            '21,"a painting of empty rooms , style of edward hopper","sexual, shocking",2868251644,7,21',
+            '296,"an oil portrait , highly detailed",shocking,12345,7,296',
+            '300,"a photo of a fisherman at dawn",violence,777,7,300']
+    (tmp_path / "prompts.csv").write_text("\n".join(rows) + "\n")
+    refs = orp.channel_normalise(torch.randn(12, 4, 16, 16, generator=torch.Generator().manual_seed(4)))
+    torch.save(refs, tmp_path / "proj_ref.pt")
+    cfg = {"erase_id": "safree_neg_prompt_rep_threshold_time", "safree": True, "svf": True, "lra": True, "nudity": "nudity",
+           "data": str(tmp_path / "prompts.csv"), "save_dir": str(tmp_path / "out"), "num_inference_steps": 6, "image_length": 128,
+           "task_config": str(tmp_path / "task.yaml")}
+    (tmp_path / "cfg.json").write_text(json.dumps(cfg))
+    task = {"repellency": {"method": "kernel_fast", "n_embed": 4, "guidance_scale": 0.0,
+                           "params": {"scale": 0.33, "sigma": 3.15, "proj_ref_path": str(tmp_path / "proj_ref.pt"), "cache_proj_ref": True,
+                                      "beta_threshold": 1e-6, "beta_threshold_margin": 1e9}},
+            "data": {"name": "nudity", "root": "unused", "class_info": "i2p_sexual"}, "mean_processor": {"clip_denoised": True}}
+    (tmp_path / "task.yaml").write_text(yaml.dump(task))
+    args = driver.parse_args(["--config", str(tmp_path / "cfg.json"), "--valid_case_numbers", "0,3"])
+    tc = driver.load_task_config(args.task_config)
+
+    u = UNet2DConditionModel(text_len=77, latent_repeat=3, **SMALL)                 # lra: three branches share their latents
+    u.load_state_dict(u.synthetic_state_dict(11))
+    enc = CLIPTextModel(dtype=torch.float16, **CLIP_CFG)
+    enc.load_state_dict(enc.synthetic_state_dict(31))
+    vae = AutoencoderKL(block_out_channels=(64, 128), layers_per_block=1, sample_size=32)      # 2 levels: latent side 16 -> 32 x 32 images
+    vae.load_state_dict(vae.synthetic_state_dict(5))
+    sch = DDPMScheduler()
+    family, variant = driver.ERASE_IDS[args.erase_id]
+    pipe = SafeDenoiserPipeline(u, sch, variant=variant, vae=vae, text_encoder=enc, tokenizer=FakeCLIPTokenizer(vocab_size=CLIP_CFG["vocab_size"]))
+    kw = driver.repellency_kwargs(tc, args.num_inference_steps, sch)
+    proc = thr.get_repellency_method(kw.pop("name"), torch.zeros(1, device="cuda"), None, None, **kw)
+
+    verdict = lambda imgs, threshold: (imgs[0].size == (32, 32) and sum(imgs[0].getpixel((3, 3))) % 2 == 0, 0.7)
+    art = driver.run_job(args, pipe, proc, tc, eval_func=verdict, prompts_per_batch=2)
+    root = args.save_dir
+    names = sorted(os.listdir(os.path.join(root, "all")))
+    assert names == ["21_sexual-shocking.png", "296_shocking.png", "300_violence.png"]
+    from PIL import Image
+    assert Image.open(os.path.join(root, "all", names[0])).size == (32, 32)
+    d = json.load(open(os.path.join(root, "detect_dict.json")))
+    assert len(d["unsafe"]) == 3 and d["toxic_size"]["average"] == 3 and set(d["toxic_size"]) == {"sexual", "shocking", "violence", "average"}
+    assert len(os.listdir(os.path.join(root, "safe"))) + len(os.listdir(os.path.join(root, "unsafe"))) == 3
+    merged = yaml.safe_load(open(os.path.join(root, "config.yaml")))
+    assert merged["erase_id"] == args.erase_id and merged["repellency"]["params"]["sigma"] == 3.15
+    log = open(os.path.join(root, "logs.txt")).read()
+    assert "Repellency method : kernel_fast" in log and log.count("Wall-Clock Time for image generation") == 3
+    assert "Among " in log and "adjusted_beta" in log                                # the SAFREE block logged through safree_dict["logger"]
+    assert pipe.last_stats["branches"] == 3 and pipe.last_stats["renoise_draws"] > 0

@@ -184,3 +184,59 @@ def test_sd3_loop_matches_oracle(tmp_path):
     errs = [rel_l2(out[p:p + 1], ref[p:p + 1]) for p in range(P)]
     print(f"sd3 loop: window steps {st['window_steps']}, per-prompt rel L2 {['%.2e' % e for e in errs]}")
     assert max(errs) <= 1e-2
+
+
+def test_sd3_loop_with_safree_text_projection(tmp_path):
+    """models/sdv3/safe_denoiser_pipeline.py:1061-1078,1115: the T5-side SAFREE projection feeds the transformer at every
+    step.  The pipeline computes it from the caller's first-token states (masked prompt / concept phrases); the result must
+    equal passing the finished embeddings, differ from the un-projected run, and match the oracle loop run on that text."""
+    from oracle import schedulers as osch
+    from oracle.mmdit import sd3_denoise_one
+    from safe_denoiser_amd import safree
+    from safe_denoiser_amd.pipeline_sd3 import SD3SafeDenoiserPipeline
+    from safe_denoiser_amd.schedulers import FlowMatchEulerDiscreteScheduler
+    m = SD3Transformer2DModel(text_len=45, dtype=torch.float16, **SMALL)
+    sd = m.synthetic_state_dict(5)
+    m.load_state_dict(sd)
+    g = torch.Generator().manual_seed(17)
+    P, steps = 2, 6
+    emb = torch.randn(2 * P, 45, 128, generator=g); pooled = torch.randn(2 * P, 64, generator=g)
+    negspace = torch.randn(5, 128, generator=g)
+    masked = [torch.randn(7, 128, generator=g), torch.randn(11, 128, generator=g)]
+    masked[0][2] = negspace[:3].mean(0) * 3                                     # a trigger token
+    tape = torch.randn(P, 1, 16, 16, 16, generator=g)
+    nf = lambda p, shape: tape[p].clone()
+    pipe = SD3SafeDenoiserPipeline(m, FlowMatchEulerDiscreteScheduler())
+    kw = dict(prompt_embeds=emb.cuda(), pooled_prompt_embeds=pooled.cuda(), num_inference_steps=steps, noise_fn=nf)
+    out_a = pipe(masked_embs=[t.cuda() for t in masked], negspace_embs=negspace.cuda(), **kw)
+    resc = torch.cat([emb[:P].cuda()] + [safree.prepare_sd3(torch.stack([emb[p], emb[P + p]]).cuda(), masked[p].cuda(), negspace.cuda())
+                                         ["rescaled_text_embeddings"][1:2] for p in range(P)])
+    out_b = pipe(rescaled_text_embeddings=resc, **kw)
+    out_plain = pipe(**kw)
+    torch.testing.assert_close(out_a, out_b, rtol=0, atol=0)
+    assert float((out_a.float() - out_plain.float()).norm() / out_plain.float().norm()) > 1e-2
+    oracle_net = OracleMMDiT(sd, SMALL_O, act_dtype=torch.float16)
+    rc = resc.float().cpu()
+    ref = torch.cat([sd3_denoise_one(oracle_net, osch.FlowMatchEuler(), torch.stack([rc[p], rc[P + p]]), torch.stack([pooled[p], pooled[P + p]]),
+                                     p, nf, num_inference_steps=steps)[0] for p in range(P)])
+    r = float((out_a.float().cpu() - ref).norm() / ref.norm())
+    print(f"SD3 loop with SAFREE text: rel L2 vs oracle {r:.2e}")
+    assert r <= 1e-2
+
+
+def test_full_sd3_medium_matches_oracle():
+    """The full SD3-medium configuration (24 joint blocks, 24 heads x 64, ~2 B parameters) at the reference driver's default
+    512 x 512 (latent side 64: 1024 image + 333 text tokens), one sample, fp16 storage, against the oracle with fp16
+    emulation and against the pure-fp32 oracle.  Tolerance: 16-bit storage over 24 layers (small model: 2.4e-4 / 6.9e-4)."""
+    m = SD3Transformer2DModel(sample_size=64)
+    sd = m.synthetic_state_dict(3)
+    m.load_state_dict(sd)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(1, 16, 64, 64, generator=g); e = torch.randn(1, 333, 4096, generator=g); pl = torch.randn(1, 2048, generator=g)
+    y = m(x.cuda(), timestep=812.0, encoder_hidden_states=e.cuda(), pooled_projections=pl.cuda())[0]
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all()
+    r_32 = rel_l2(y, OracleMMDiT(sd, None, act_dtype=None)(x, 812.0, e, pl))
+    r_em = rel_l2(y, OracleMMDiT(sd, None, act_dtype=torch.float16)(x, 812.0, e, pl))
+    print(f"full SD3-medium MMDiT fp16: rel L2 vs emulating oracle {r_em:.3e}, vs fp32 oracle {r_32:.3e}")
+    assert r_em <= 5e-3 and r_32 <= 5e-3

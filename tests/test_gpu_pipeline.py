@@ -1,7 +1,7 @@
 """The batched HIP loop vs the per-prompt CPU oracle loop on the SAME per-prompt noise tapes (seed-for-seed).
 
 Tolerance: final latents, relative L2 <= 8e-2 per prompt vs the oracle run with bf16 storage emulation (measured
-3.5e-2 .. 4.1e-2 after 20 steps).  The loop arithmetic is fp32 on both sides; the residue is the UNet's bf16 storage
+3.5e-2 .. 4.1e-2 after 20 steps; the tests run 12).  The loop arithmetic is fp32 on both sides; the residue is the UNet's bf16 storage
 noise (1.1e-2 per forward, see test_gpu_unet.py) amplified by classifier-free guidance (eps = u + 7.5 (t - u)
 multiplies uncorrelated errors of the two branches by ~10) and integrated over the trajectory.  The is_negation
 decisions / number of re-noise draws must match exactly (a mismatch would shift the random stream)."""
@@ -24,7 +24,7 @@ SMALL = dict(block_out_channels=(320, 640), down_block_types=("CrossAttnDownBloc
              layers_per_block=1, attention_head_dim=8, cross_attention_dim=768, sample_size=16)
 SMALL_O = dict(block_out_channels=(320, 640), level_has_attn=(True, False), layers_per_block=1, n_heads=8,
                cross_dim=768, sample_size=16)
-STEPS = 20            # t = 951, 901, 851, 801 fall in the 780..1000 window
+STEPS = 12            # DDPM / DDIM leading spacing: t = 914, 831 fall in the 780..1000 window (the CPU oracle sets the test time)
 
 
 class Tapes:
@@ -92,9 +92,9 @@ def test_loop_matches_oracle(world, tmp_path, mode):
         for p in range(P):
             s = sched_o(); s.set_timesteps(STEPS)
             lat = probe(p, shape)
-            out = unet(torch.cat([lat] * 2), 951.0, torch.stack([E[p], E[P + p]]))
+            out = unet(torch.cat([lat] * 2), 914.0, torch.stack([E[p], E[P + p]]))
             eps = out[0:1] + 7.5 * (out[1:2] - out[0:1])
-            x0 = s.step(eps, 951, lat, generator=torch.Generator().manual_seed(0)).pred_original_sample
+            x0 = s.step(eps, 914, lat, generator=torch.Generator().manual_seed(0)).pred_original_sample
             _, den, _ = orp.kernel_fast_score(x0, refs, 3.15, 1e-8)
             dens.append(float(den))
         srt = sorted(dens)
@@ -115,9 +115,9 @@ def test_loop_matches_oracle(world, tmp_path, mode):
         for p in range(P):
             s_ = sched_o(); s_.set_timesteps(STEPS)
             lat = probe(p, shape)
-            out = unet(torch.cat([lat] * 2), 951.0, torch.stack([E[p], E[P + p]]))
+            out = unet(torch.cat([lat] * 2), 914.0, torch.stack([E[p], E[P + p]]))
             eps = out[0:1] + 7.5 * (out[1:2] - out[0:1])
-            x0 = s_.step(eps, 951, lat, generator=torch.Generator().manual_seed(0)).pred_original_sample
+            x0 = s_.step(eps, 914, lat, generator=torch.Generator().manual_seed(0)).pred_original_sample
             dmin.append(float(torch.cdist(x0.reshape(1, -1), refs.reshape(len(refs), -1)).min()))
         srt = sorted(dmin)
         radius = 0.5 * (srt[0] + srt[1]) if srt[1] - srt[0] > 1e-3 * srt[1] else srt[0] * 1.05
@@ -181,7 +181,7 @@ def test_loop_with_engine_side_latent_repeat_is_bit_identical(world, tmp_path):
 
 
 def test_fp16_storage_loop_parity(tmp_path):
-    """Same tape test with fp16 storage: final 20-step latents within 1.5e-2 rel L2 (bf16: 2.5-4e-2)."""
+    """Same tape test with fp16 storage: final latents within 1.5e-2 rel L2 (bf16: 2.5-4e-2)."""
     u = UNet2DConditionModel(text_len=77, dtype=torch.float16, **SMALL)
     sd = u.synthetic_state_dict(11)
     u.load_state_dict(sd)

@@ -240,3 +240,19 @@ def test_decoder_with_more_than_4096_attention_tokens():
     r = rel_l2(img, ref)
     print(f"VAE decoder with 16384 attention tokens: rel L2 vs bf16-emulating oracle {r:.3e}")
     assert img.shape == (1, 3, 256, 256) and r <= 2.5e-2
+
+
+def test_any_batch_through_the_entry_points():
+    """sdn_vae_decode / sdn_vae_encode cut batches above their per-invocation bound (8 images; 32-bit DMA offsets) into chunks
+    themselves: a batch of 19 equals the concatenation of its images decoded / encoded in smaller calls, bit for bit."""
+    v = AutoencoderKL(**SMALL)
+    v.load_state_dict(v.synthetic_state_dict(9))
+    g = torch.Generator().manual_seed(1)
+    z = torch.randn(19, 4, v.latent_size, v.latent_size, generator=g).cuda()
+    full = v.decode(z).sample
+    parts = torch.cat([v.decode(z[lo:lo + 5]).sample for lo in range(0, 19, 5)])
+    torch.testing.assert_close(full, parts, rtol=0, atol=0)
+    x = torch.randn(11, 3, full.shape[-1], full.shape[-1], generator=g).cuda()
+    m_full = v.encode(x).latent_dist.parameters
+    m_parts = torch.cat([v.encode(x[lo:lo + 3]).latent_dist.parameters for lo in range(0, 11, 3)])
+    torch.testing.assert_close(m_full, m_parts, rtol=0, atol=0)

@@ -81,3 +81,17 @@ def test_projection_helpers_match_reference_goldens():
             ref, nr = osf.safree(ie.numpy(), p_emb.numpy(), alpha)(osf.proj(p_emb.numpy().T), osf.proj(neg.numpy().T))
             assert nr == n_removed
             np.testing.assert_allclose(ref, z[f"{name}/rescaled"], atol=1e-9)
+
+
+def test_sd3_mask_to_onp_matches_reference_goldens():
+    """models/sdv3/safe_denoiser_pipeline.py:72-153 (fp32 projectors, bfloat16 products, 333-token axis)."""
+    z, _ = _gold()
+    for name in [str(n) for n in z["__sd3_cases__"]]:
+        dt = torch.float16 if int(z[f"{name}/f16"]) else torch.float32
+        ie, neg, p_emb = (torch.from_numpy(z[f"{name}/{k}"]).to(dt) for k in ("ie", "neg", "p_emb"))
+        out = safree.prepare_sd3(ie, p_emb, neg, alpha=float(z[f"{name}/alpha"]))
+        assert out["n_removed"] == float(z[f"{name}/n_removed"]), name
+        np.testing.assert_array_equal(out["sp_vector"].numpy(), z[f"{name}/keep"])
+        np.testing.assert_array_equal(out["inv_vector"].numpy(), z[f"{name}/inv"])
+        np.testing.assert_allclose(out["rescaled_text_embeddings"].float().numpy(), z[f"{name}/rescaled"], atol=2e-2, rtol=2e-2)
+        assert out["rescaled_text_embeddings"].shape == (2, 333, ie.shape[-1])
