@@ -617,7 +617,8 @@ static int sdn_gemm_impl(int dtype, const sdn_gemm_desc* d, const void* a, const
   hipStream_t st = (hipStream_t)stream;
   // operands must stay below the LDS-DMA out-of-range sentinel (2 GiB per tensor)
   const long a_rows = d->a_mode == SDN_A_CONV3X3 ? (long)(d->M / (d->Ho * d->Wo)) * d->Hs * d->Ws : (long)d->M;
-  if (a_rows * (long)(d->a_mode == SDN_A_CONV3X3 ? d->Cin : d->K) * 2 >= (1L << 31) || (long)d->N * d->K * 2 >= (1L << 31))
+  const long a_ld1 = d->a_mode == SDN_A_CONV3X3 ? d->Cin : g.K1, a_ld2 = d->a_mode == SDN_A_CONV3X3 ? 0 : d->K - g.K1;   // per SOURCE
+  if (a_rows * a_ld1 * 2 >= (1L << 31) || a_rows * a_ld2 * 2 >= (1L << 31) || (long)d->N * d->K * 2 >= (1L << 31))
     return SDN_E_INVALID;
   if (d->split_k > 1) {
     // split-K: fp32 partials per k slice, then one deterministic reduce + epilogue pass

@@ -400,3 +400,25 @@ def test_f16_twins_are_8x_tighter():
     sp = lambda t: t.float().reshape(1, 256, 8, 40).transpose(1, 2)
     ref = F.scaled_dot_product_attention(sp(q), sp(k), sp(v)).transpose(1, 2).reshape(1, 256, 320)
     assert rel_l2(ops.attention(q.cuda(), k.cuda(), v.cuda(), 8), ref) <= 1.5e-3
+
+
+def test_groupnorm_from_column_sums_with_a_large_mean():
+    """E[x^2] - mean^2 from fp32 column sums of 16-bit values (sdn_groupnorm_cols_*) when |mean| >> std: the variance then
+    loses log2((mean/std)^2) bits to cancellation.  mean/std = 100 (far beyond what the UNet's activations show: their
+    |mean|/std stays below ~3) must still be within the 16-bit output rounding of torch's GroupNorm; the bias term comes
+    from a GEMM bias so that the producing kernel really is the GEMM."""
+    B, hw, K, N = 2, 256, 64, 320
+    M = B * hw
+    a = rnd(M, K, seed=91); w = rnd(N, K, seed=92, scale=K ** -0.5)
+    bias = torch.full((N,), 100.0)                                       # y = N(0, 1) + 100
+    cols = torch.zeros(M // 128, N, 2, device="cuda")
+    y = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), col_stats=cols)
+    gamma = (1 + 0.1 * torch.randn(N, generator=torch.Generator().manual_seed(93))).cuda()
+    beta = (0.1 * torch.randn(N, generator=torch.Generator().manual_seed(94))).cuda()
+    g_cols = ops.groupnorm(y.reshape(B, hw, N), None, 32, 1e-5, 0, gamma, beta, cols1=cols)
+    g_plain = ops.groupnorm(y.reshape(B, hw, N), None, 32, 1e-5, 0, gamma, beta)
+    ref = F.group_norm(y.float().cpu().reshape(B, hw, N).permute(0, 2, 1).double(), 32, gamma.cpu().double(), beta.cpu().double(), 1e-5)
+    ref = ref.permute(0, 2, 1)
+    r_cols, r_plain = rel_l2(g_cols, ref), rel_l2(g_plain, ref)
+    print(f"GroupNorm at mean/std = 100: rel L2 vs float64, from column sums {r_cols:.2e}, two-pass kernel {r_plain:.2e}")
+    assert r_cols <= 6e-3 and r_plain <= 6e-3

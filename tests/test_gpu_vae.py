@@ -246,7 +246,7 @@ def test_any_batch_through_the_entry_points():
     """sdn_vae_decode / sdn_vae_encode cut batches above their per-invocation bound (8 images; 32-bit DMA offsets) into chunks
     themselves: a batch of 19 equals the concatenation of its images decoded / encoded in smaller calls, bit for bit."""
     v = AutoencoderKL(**SMALL)
-    v.load_state_dict(v.synthetic_state_dict(9))
+    v.load_state_dict(v.synthetic_state_dict(9, with_encoder=True))
     g = torch.Generator().manual_seed(1)
     z = torch.randn(19, 4, v.latent_size, v.latent_size, generator=g).cuda()
     full = v.decode(z).sample
