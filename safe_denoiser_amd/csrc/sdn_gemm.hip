@@ -71,7 +71,18 @@ __device__ __forceinline__ float erf_as(float x) {
   const float r = fmaf(-p * t, e, 1.0f);
   return copysignf(r, x);
 }
-__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erf_as(v * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_ref(float v) { return 0.5f * v * (1.f + erf_as(v * 0.70710678118654752f)); }
+// GELU (erf form) for a 16-BIT output: x * Phi(x) with Phi(x) = 1 / (1 + 2^(x (a + b x^2 + c x^4))), a quintic-argument logistic
+// fitted to the exact function (minimax over |x| <= 12): |error| <= 2.6e-5 absolute, <= 7.7e-5 relative for x > 0.02 -- 1/25 of
+// the bf16 and 1/3 of the fp16 half-ulp of the stored result -- in 9 VALU instructions (2 transcendental) instead of 17.
+// In-kernel timing made the point: at K = 320 the GEGLU projection's epilogue (32 GELUs per lane) costs as much as its whole
+// k loop (the per-output cost equals ~310 columns of K), and that epilogue is mostly this function.  x^2 is clamped at 100:
+// beyond |x| = 11 the quintic would change sign; the clamped argument keeps growing linearly, so the tails are exact 0 / x.
+__device__ __forceinline__ float gelu_erf(float v) {
+  const float x2 = fminf(v * v, 100.0f);
+  const float u = v * fmaf(x2, fmaf(x2, 0.0010142630198970437f, -0.10677572339773178f), -2.301121234893799f);   // -log2(e) folded in
+  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u));
+}
 __device__ __forceinline__ float gelu_tanh(float v) {                       // GELU(approximate="tanh"), MMDiT feed-forward
   const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
   // 0.5 (1 + tanh u) = 1 / (1 + exp(-2u))   (one v_exp + one v_rcp; saturates cleanly for |u| large)

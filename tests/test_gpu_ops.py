@@ -422,3 +422,24 @@ def test_groupnorm_from_column_sums_with_a_large_mean():
     r_cols, r_plain = rel_l2(g_cols, ref), rel_l2(g_plain, ref)
     print(f"GroupNorm at mean/std = 100: rel L2 vs float64, from column sums {r_cols:.2e}, two-pass kernel {r_plain:.2e}")
     assert r_cols <= 6e-3 and r_plain <= 6e-3
+
+
+def test_geglu_epilogue_gelu_is_within_the_16_bit_output_rounding():
+    """The GEGLU epilogue evaluates GELU with a quintic-argument logistic (<= 2.6e-5 absolute from the erf form).  With fp16
+    storage -- the tighter of the two 16-bit modes -- the result must sit at one output rounding from torch's exact-erf GEGLU,
+    and gates spanning the whole useful range (|g| up to 12) must not show the approximation."""
+    from safe_denoiser_amd.unet import _interleave16
+    M, C = 512, 320
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(M, C, generator=g) * 1.5).half()
+    w = (torch.randn(8 * C, C, generator=g) * C ** -0.5 * 2.0).half()           # gates with std ~3: tails well exercised
+    b = torch.randn(8 * C, generator=g)
+    proj = x.float() @ w.float().T + b
+    val, gate = proj.chunk(2, -1)
+    ref = val * F.gelu(gate)
+    out = ops.gemm(x.cuda(), _interleave16(w).contiguous().cuda(), bias=_interleave16(b).contiguous().cuda(), act=2)
+    err = (out.float().cpu() - ref)
+    r = float(err.norm() / ref.norm())
+    print(f"GEGLU f16: rel L2 {r:.2e}, gate range [{float(gate.min()):.1f}, {float(gate.max()):.1f}]")
+    assert r <= 4e-4                                                            # fp16 rounding alone: ~2.9e-4
+    assert float(gate.abs().max()) > 10.0
