@@ -322,10 +322,13 @@ def main():
         proc.beta_threshold = float("inf")
         pipe.record_den = True
         run(0)
-        dens = torch.cat(pipe.last_stats["denominators"]).float()
+        den_list = pipe.last_stats["denominators"]
         pipe.record_den = False
-        lo_d, hi_d = float(dens.min()), float(dens.max())
-        if hi_d > lo_d * (1.0 + 1e-6):
+        dens = torch.cat(den_list).float() if den_list else None
+        lo_d, hi_d = (float(dens.min()), float(dens.max())) if dens is not None else (0.0, 0.0)
+        if dens is None:                                              # no step inside the window (short --inference-steps runs)
+            gate, placement = r5_beta - float(proc.beta_threshold_margin), "R5 threshold - margin (no window step in this run)"
+        elif hi_d > lo_d * (1.0 + 1e-6):
             gate, placement = float(torch.quantile(dens, 1.0 - fire_target)), f"den quantile {1.0 - fire_target:.2f} of an untimed probe batch"
         else:
             # degenerate: with RANDOM UNet weights every x0 probe is ~1e3 away from every reference, all weights underflow and

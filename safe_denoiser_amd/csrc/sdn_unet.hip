@@ -140,6 +140,7 @@ struct sdn_unet {
   bool use_graph = false;
   bool gn_fuse = true;                  // GroupNorm statistics from the producing GEMMs' column partials (hw % 128 == 0)
   bool ln_fold = true;                  // BasicTransformerBlock LayerNorms folded into their consumer GEMMs where it pays
+  int ln_prepass_all = 0;               // debug A/B: 1 = every folded LayerNorm takes its row statistics from the pre-pass
   bool ff_fuse = true;                  // FeedForward's output linear and the block's proj_out (no nonlinearity between them)
                                         // contracted into ONE GEMM over [ff | h3] with the product weight (sdn_linear_pair_fold)
   struct FoldJob { int64_t w, gamma, beta, bias, wf, c, d; int rows, cols; int kind = 0; };   // kind 0: LayerNorm fold; 1: linear pair
@@ -439,7 +440,7 @@ struct Builder {
     if (!fold12 || !fold3) ln = act(rows, C, hw, x.side);
     Act qkvb = act(rows, 3 * C, hw, x.side);
     if (fold12) {
-      gemm_ln(h, rows, 3 * C, C, tb + ".attn1.to_q.weight", qkv, l1g, l1b, Ref(), R(qkvb), SDN_ACT_NONE, 3 * C > 960);
+      gemm_ln(h, rows, 3 * C, C, tb + ".attn1.to_q.weight", qkv, l1g, l1b, Ref(), R(qkvb), SDN_ACT_NONE, 3 * C > 960 || u->ln_prepass_all);
     } else {
       layernorm(h, l1g, l1b, ln);
       gemm(rows, 3 * C, C, R(ln), qkv, Ref(), R(qkvb));
@@ -454,7 +455,7 @@ struct Builder {
     // cross-attention
     Act qb = act(rows, C, hw, x.side);
     if (fold12) {
-      gemm_ln(h2, rows, C, C, tb + ".attn2.to_q.weight", q2w, l2g, l2b, Ref(), R(qb), SDN_ACT_NONE, false);
+      gemm_ln(h2, rows, C, C, tb + ".attn2.to_q.weight", q2w, l2g, l2b, Ref(), R(qb), SDN_ACT_NONE, u->ln_prepass_all != 0);
     } else {
       layernorm(h2, l2g, l2b, ln);
       gemm(rows, C, C, R(ln), q2w, Ref(), R(qb));
@@ -1616,6 +1617,13 @@ void sdn_unet_set_graph_mode(sdn_unet* u, int32_t on) {
 extern "C" void sdn_debug_set_ln_fold(sdn_unet* u, int on) {
   if (!u) return;
   u->ln_fold = on != 0;
+  drop_graphs(u);
+  u->plans.clear();
+}
+
+extern "C" void sdn_debug_set_ln_prepass_all(sdn_unet* u, int on) {
+  if (!u) return;
+  u->ln_prepass_all = on;
   drop_graphs(u);
   u->plans.clear();
 }

@@ -20,7 +20,7 @@ y = torch.empty(B, 4, 64, 64, device="cuda")
 res = {0: [], 1: []}
 for rnd in range(4):
     for on in (1, 0):
-        sda.lib().sdn_debug_set_ff_fuse(u._h, on)
+        getattr(sda.lib(), os.environ.get("HOOK", "sdn_debug_set_ff_fuse"))(u._h, on)
         u._ws = {}
         u.forward_into(x, 981.0, e, y)
         torch.cuda.synchronize()
@@ -31,4 +31,4 @@ for rnd in range(4):
         res[on].append((time.perf_counter() - t0) / 5 * 1e3)
 for on in (1, 0):
     v = sorted(res[on])
-    print(f"ff_fuse={on}: forward ms per round {['%.2f' % t for t in res[on]]}  median {v[len(v) // 2]:.2f}  min {v[0]:.2f}")
+    print(f"{os.environ.get('HOOK', 'sdn_debug_set_ff_fuse')}={on}: forward ms per round {['%.2f' % t for t in res[on]]}  median {v[len(v) // 2]:.2f}  min {v[0]:.2f}")
