@@ -1,7 +1,9 @@
 """CPU oracle (numpy, independent of torch's pinverse) for the SAFREE text projection
 (models/textuals_visual/modified_safree_diffusion_pipeline_threshold_time.py:38-99,458-486).  TEST INFRASTRUCTURE.
-Parity status: restated from the reference's in-tree source (these helpers ARE in /root/reference, but the module
-imports diffusers at file scope, so it cannot be imported here to capture golden vectors)."""
+Parity status: PINNED -- the module that holds these helpers imports diffusers at file scope and cannot be imported, but the
+helper functions themselves are pure torch: tests/golden/make_safree_golden.py parses the file, executes exactly those function
+definitions and stores their inputs / outputs (tests/golden/safree_golden.npz); tests/test_safree.py holds this restatement
+and the product's safree.py to them."""
 import numpy as np
 
 
