@@ -177,7 +177,12 @@ def test_full_sd14_fp32_plan_forward_and_10_step_loop_meet_the_north_star_tolera
     ref, st = opipe.denoise_one(oracle, osch.DDPM(), E, 0, t_o, num_inference_steps=steps,
                                 repel=dict(flavour="threshold", proj_refs=refs, **params))
     res = {}
-    for name, dt in (("fp32", torch.float32), ("fp16", torch.float16), ("bf16", torch.bfloat16)):
+    import os
+    # the 16-bit arms (two more 860 M-parameter packs and loops) only when asked: SDN_PARITY_FULL=1 refreshes the record
+    # profiles/round2_parity.json; the default run asserts the fp32 plan alone
+    arms = (("fp32", torch.float32), ("fp16", torch.float16), ("bf16", torch.bfloat16)) if os.environ.get("SDN_PARITY_FULL") else \
+        (("fp32", torch.float32),)
+    for name, dt in arms:
         un = u if dt == torch.float32 else UNet2DConditionModel(text_len=77, dtype=dt, latent_repeat=2)
         if dt != torch.float32:
             un.load_state_dict(sd)
@@ -189,10 +194,11 @@ def test_full_sd14_fp32_plan_forward_and_10_step_loop_meet_the_north_star_tolera
         del un
     print(f"full SD-v1.4 10-step loop vs pure-fp32 oracle (re-noise draws {st['renoise_draws']}): " +
           ", ".join(f"{k} {v[0]:.2e}" for k, v in res.items()))
-    import json, os
+    import json
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
-    json.dump({"what": "full SD-v1.4 (859.5 M parameters), 1 prompt, CFG 7.5, DDPM, 10 steps (2 in the repellency window, gate "
+    if len(arms) == 3:
+        json.dump({"what": "full SD-v1.4 (859.5 M parameters), 1 prompt, CFG 7.5, DDPM, 10 steps (2 in the repellency window, gate "
                        "fires both times), tape noise: rel L2 of the HIP path's final latents vs the pure-fp32 CPU oracle",
                "source": "tests/test_gpu_f32.py::test_full_sd14_fp32_plan_forward_and_10_step_loop_meet_the_north_star_tolerance",
                "unet_forward_fp32_plan": r_fwd, "loop_10_steps": {k: v[0] for k, v in res.items()},
@@ -200,4 +206,5 @@ def test_full_sd14_fp32_plan_forward_and_10_step_loop_meet_the_north_star_tolera
                "north_star_bound": 1e-3}, open(os.path.join(out_dir, "round2_parity.json"), "w"), indent=1)
     assert res["fp32"][1] == st["renoise_draws"] == 2 and res["fp32"][2] == t_o.i
     assert res["fp32"][0] <= 1e-3                                        # the north-star bound
-    assert res["fp16"][0] <= 3e-2 and res["bf16"][0] <= 2e-1              # 16-bit storage: reported, loosely bounded
+    if len(arms) == 3:
+        assert res["fp16"][0] <= 3e-2 and res["bf16"][0] <= 2e-1          # 16-bit storage: reported, loosely bounded

@@ -24,7 +24,7 @@ SMALL = dict(block_out_channels=(320, 640), down_block_types=("CrossAttnDownBloc
              layers_per_block=1, attention_head_dim=8, cross_attention_dim=768, sample_size=16)
 SMALL_O = dict(block_out_channels=(320, 640), level_has_attn=(True, False), layers_per_block=1, n_heads=8,
                cross_dim=768, sample_size=16)
-STEPS = 12            # DDPM / DDIM leading spacing: t = 914, 831 fall in the 780..1000 window (the CPU oracle sets the test time)
+STEPS = 10            # DDPM / DDIM leading spacing: t = 901, 801 fall in the 780..1000 window (the CPU oracle sets the test time)
 
 
 class Tapes:
@@ -52,7 +52,7 @@ def world():
     sd = u.synthetic_state_dict(11)
     u.load_state_dict(sd)
     g = torch.Generator().manual_seed(2)
-    P = 3
+    P = 2
     E = torch.randn(2 * P, 77, 768, generator=g)
     refs = orp.channel_normalise(torch.randn(24, 4, 16, 16, generator=g))
     return u, sd, E, refs, P
@@ -92,9 +92,9 @@ def test_loop_matches_oracle(world, tmp_path, mode):
         for p in range(P):
             s = sched_o(); s.set_timesteps(STEPS)
             lat = probe(p, shape)
-            out = unet(torch.cat([lat] * 2), 914.0, torch.stack([E[p], E[P + p]]))
+            out = unet(torch.cat([lat] * 2), 901.0, torch.stack([E[p], E[P + p]]))
             eps = out[0:1] + 7.5 * (out[1:2] - out[0:1])
-            x0 = s.step(eps, 914, lat, generator=torch.Generator().manual_seed(0)).pred_original_sample
+            x0 = s.step(eps, 901, lat, generator=torch.Generator().manual_seed(0)).pred_original_sample
             _, den, _ = orp.kernel_fast_score(x0, refs, 3.15, 1e-8)
             dens.append(float(den))
         srt = sorted(dens)
@@ -115,9 +115,9 @@ def test_loop_matches_oracle(world, tmp_path, mode):
         for p in range(P):
             s_ = sched_o(); s_.set_timesteps(STEPS)
             lat = probe(p, shape)
-            out = unet(torch.cat([lat] * 2), 914.0, torch.stack([E[p], E[P + p]]))
+            out = unet(torch.cat([lat] * 2), 901.0, torch.stack([E[p], E[P + p]]))
             eps = out[0:1] + 7.5 * (out[1:2] - out[0:1])
-            x0 = s_.step(eps, 914, lat, generator=torch.Generator().manual_seed(0)).pred_original_sample
+            x0 = s_.step(eps, 901, lat, generator=torch.Generator().manual_seed(0)).pred_original_sample
             dmin.append(float(torch.cdist(x0.reshape(1, -1), refs.reshape(len(refs), -1)).min()))
         srt = sorted(dmin)
         radius = 0.5 * (srt[0] + srt[1]) if srt[1] - srt[0] > 1e-3 * srt[1] else srt[0] * 1.05
@@ -154,10 +154,10 @@ def test_device_generators_are_per_prompt(world):
     gens = lambda idx: [torch.Generator(device="cuda").manual_seed(1000 + i) for i in idx]
     pipe = SafeDenoiserPipeline(u, DDPMScheduler(), variant="threshold_time")
     full = pipe(prompt_embeddings=E.cuda(), num_inference_steps=5, generator=gens(range(P)))
-    sel = [2]
+    sel = [P - 1]
     Esel = torch.cat([E[:P][sel], E[P:][sel]])
     one = pipe(prompt_embeddings=Esel.cuda(), num_inference_steps=5, generator=gens(sel))
-    assert rel_l2(one, full[2:3]) <= 1e-6
+    assert rel_l2(one, full[P - 1:P]) <= 1e-6
     with pytest.raises(NotImplementedError):
         pipe(prompt="a photo", num_inference_steps=5)
 
@@ -244,7 +244,7 @@ def test_lra_and_safree_text_switch_match_oracle(world, tmp_path, mode):
     Es = _safe_text(E, P, 77)
     lra = mode.startswith("lra")
     if mode.endswith("svf") or mode == "svf_2branch":
-        betas = [3, 0, 7][:P]
+        betas = [3, 0, 7][:P]                                            # different step counts: the batch is mixed
         sf = dict(safree=True, svf=True, lra=lra, re_attn_t=(-1, -1))
         fn = lambda p: (lambda i: i <= betas[p])
     else:

@@ -35,9 +35,8 @@ NEG_SPACE = ["Sexual Acts", "Content Meant to Arouse Sexual Excitement", "Nudity
              "Seductive", "Orgasmic", "Libido", "Kinky", "Sexual Orientation", "Sexual Attraction", "Sexual Intercourse",
              "Sexual Pleasure", "Sexual Fantasy", "Carnal Desires", "Sexual Gratification"]       # run_nudity.py:353-358
 PROMPTS = ["a painting of a woman standing near the sea , lustful mood",
-           "two astronauts riding horses",
            "portrait photo of an old fisherman , dramatic light , 85mm"]
-STEPS = 12
+STEPS = 10
 
 
 def test_safree_helpers_on_cuda_match_reference_goldens():
