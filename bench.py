@@ -443,7 +443,9 @@ def main():
                             "placement": placement,
                             "fired_fraction_rank0": renoise / max(window_pairs, 1)},
                    "parallelism": f"prompt-shard x{world}",
-                   "per_rank_images_per_sec": per_rank, "proj_ref_broadcast_ms": bcast_ms},
+                   "per_rank_images_per_sec": per_rank, "proj_ref_broadcast_ms": bcast_ms,
+                   **({"rehearsal": "SDN_SHARE_GPU=1: ranks share the visible GPU(s) and talk over gloo -- a functional check of "
+                                    "the N > 1 path, NOT a scaling measurement"} if os.environ.get("SDN_SHARE_GPU") == "1" else {})},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": d["bytes"] / d["launches"], "kernel": dom,

@@ -20,6 +20,12 @@ def init_from_env(backend: Optional[str] = None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal on a box with fewer GPUs than ranks (SDN_SHARE_GPU=1): ranks share the devices round-robin and talk over gloo
+    # (RCCL refuses two ranks on one device).  Functional check of the N > 1 path only -- never a scaling measurement.
+    share = os.environ.get("SDN_SHARE_GPU") == "1" and torch.cuda.is_available()
+    if share:
+        local = local % max(torch.cuda.device_count(), 1)
+        backend = backend or "gloo"
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -52,18 +58,24 @@ def valid_case_numbers(n_items: int, rank: int, world: int):
     return (idx[0], idx[-1] + 1) if idx else (n_items, n_items)
 
 
+def _comm_device(device):
+    """Tensors of a collective live on the GPU for RCCL and on the CPU for gloo (tests, shared-GPU rehearsals)."""
+    return torch.device("cpu") if dist.is_initialized() and dist.get_backend() == "gloo" else device
+
+
 def broadcast_proj_ref(refs: Optional[torch.Tensor], device, src: int = 0) -> torch.Tensor:
     """Rank `src` holds refs [M,C,H,W] fp32; everyone returns the same tensor on `device`.  Verifies the payload
     with an fp64 checksum all-reduced MIN/MAX (cheap, once per run)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return refs.to(device)
     rank = dist.get_rank()
-    meta = torch.zeros(4, dtype=torch.int64, device=device)
+    cdev = _comm_device(device)
+    meta = torch.zeros(4, dtype=torch.int64, device=cdev)
     if rank == src:
-        meta = torch.tensor(list(refs.shape), dtype=torch.int64, device=device)
+        meta = torch.tensor(list(refs.shape), dtype=torch.int64, device=cdev)
     dist.broadcast(meta, src=src)
-    buf = refs.to(device=device, dtype=torch.float32).contiguous() if rank == src else \
-        torch.empty(tuple(meta.tolist()), dtype=torch.float32, device=device)
+    buf = refs.to(device=cdev, dtype=torch.float32).contiguous() if rank == src else \
+        torch.empty(tuple(meta.tolist()), dtype=torch.float32, device=cdev)
     dist.broadcast(buf, src=src)
     chk = buf.double().sum().reshape(1)
     lo, hi = chk.clone(), chk.clone()
@@ -71,13 +83,13 @@ def broadcast_proj_ref(refs: Optional[torch.Tensor], device, src: int = 0) -> to
     dist.all_reduce(hi, op=dist.ReduceOp.MAX)
     if float(lo) != float(hi):
         raise RuntimeError("proj_ref broadcast checksum mismatch across ranks")
-    return buf
+    return buf.to(device)
 
 
 def broadcast_scalar(value: float, device, src: int = 0) -> float:
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_comm_device(device))
     dist.broadcast(t, src=src)
     return float(t.item())
 
@@ -90,7 +102,7 @@ def barrier():
 def max_over_ranks(value: float, device) -> float:
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_comm_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -98,7 +110,7 @@ def max_over_ranks(value: float, device) -> float:
 def sum_over_ranks(value: float, device) -> float:
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_comm_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
 
@@ -107,7 +119,7 @@ def gather_over_ranks(value: float, device) -> list:
     """Every rank's `value`, in rank order, on every rank (end-of-run per-rank counters; never inside the step loop)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return [float(value)]
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_comm_device(device))
     out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(out, t)
     return [float(o.item()) for o in out]

@@ -98,3 +98,32 @@ def test_scheduler_round_trip_full_size(cls):
     if cls is DDIMScheduler:
         a = s.step(n, 981, x0).prev_sample
         assert torch.equal(a, s.step(n, 981, x0).prev_sample)
+
+
+@pytest.mark.parametrize("N,M,C,S", [(1, 1, 4, 4), (5, 63, 4, 8), (17, 64, 16, 4), (33, 65, 4, 8), (65, 130, 4, 16), (130, 515, 4, 16),
+                                     (16, 7, 4, 64), (64, 40, 16, 8)])
+def test_batched_projection_matches_the_oracle_per_query(tmp_path, N, M, C, S):
+    """The matrix-core sweeps tile queries by 16 / 32 / 64 (and groups of 64), references by 64 and columns by 64-column
+    slices: every tile boundary (ragged N, M, a single reference, several query groups) against the per-query CPU oracle,
+    RBF (threshold flavour, sigma from the YAML) and SPARSE."""
+    g = torch.Generator().manual_seed(N * 1000 + M)
+    refs = orp.channel_normalise(torch.randn(M, C, S, S, generator=g))
+    x = torch.randn(N, C, S, S, generator=g) * 0.5
+    x[N // 2] = refs[M // 2] * 1.1 + 0.01 * x[N // 2]                       # one query close to a reference
+    params = dict(sigma=3.15, scale=0.33, beta_threshold=1.0, beta_threshold_margin=0.25)
+    p = make_proc(refs, tmp_path, **params)
+    a = x.clone().cuda()
+    neg, den, isneg = p.conditioning_device(a, want_neg=True)
+    for i in sorted({0, N // 2, N - 1}):
+        o = orp.kernel_fast_conditioning(x[i:i + 1].clone(), refs, flavour="threshold", use_beta_threshold=True, **params)
+        torch.testing.assert_close(a[i:i + 1].cpu(), o["x_0_hat"], rtol=2e-5, atol=2e-6)
+        torch.testing.assert_close(den[i].cpu(), torch.tensor(o["mean_x_0_hat"]["denominator"], dtype=torch.float32), rtol=2e-5, atol=0)
+        assert bool(isneg[i].item()) == o["is_negation"]
+    radius = float(torch.cdist(x.reshape(N, -1), refs.reshape(M, -1)).median())
+    ps = make_proc(refs, tmp_path, method="sparse", radius=radius, scale=0.03)
+    b = x.clone().cuda()
+    _, _, isn = ps.conditioning_device(b)
+    for i in sorted({0, N // 2, N - 1}):
+        o = orp.sparse_conditioning(x[i:i + 1].clone(), refs, flavour="threshold", radius=radius, scale=0.03)
+        torch.testing.assert_close(b[i:i + 1].cpu(), o["x_0_hat"], rtol=2e-5, atol=2e-5)
+        assert bool(isn[i].item()) == o["is_negation"]
