@@ -243,7 +243,9 @@ def launch_ranks(n: int, argv) -> int:
         print(f"[bench] ranks failed (rank, exit code): {bad}", file=sys.stderr)
         return 1
     reader.join()
-    sys.stdout.write(b"".join(chunks).decode())
+    for line in b"".join(chunks).decode().splitlines():            # stdout carries the JSON line only: library chatter on
+        dst = sys.stdout if line.startswith("{") else sys.stderr    # rank 0's stdout (gloo's "[Gloo] Rank 0 is connected
+        print(line, file=dst)                                       # ..." in the rehearsal mode) goes to stderr
     sys.stdout.flush()
     return 0
 

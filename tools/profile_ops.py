@@ -54,7 +54,7 @@ for _ in range(3):
         a[0] += 1; a[1] += out[i * 6]; a[2] += out[i * 6 + 1]
 tot = sum(a[1] for a in agg.values()) / 3
 print(f"B={B}: {tot:.2f} ms per forward")
-for key, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:28]:
+for key, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get("TOP", "28"))]:
     ms = a[1] / 3
     tf = a[2] / 3 / (ms * 1e-3) / 1e12 if ms > 0 else 0
     print(f"{key[0]:16s} M={key[1]:7d} N={key[2]:6d} K={key[3]:6d}  x{a[0] // 3:3d}  {ms:7.3f} ms  {100 * ms / tot:5.1f}%  {tf:7.1f} TF/s")
