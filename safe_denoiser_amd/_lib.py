@@ -102,6 +102,7 @@ SIGNATURES = {
     "sdn_gemm_ln_f16": (C.c_int, [C.POINTER(GemmDesc), _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp]),
     "sdn_row_stats_bf16": (C.c_int, [_vp, _i64, _i32, _f32, _vp, _vp]),
     "sdn_row_stats_f16": (C.c_int, [_vp, _i64, _i32, _f32, _vp, _vp]),
+    "sdn_ffn_geglu_fused": (C.c_int, [_i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sdn_gemm_stats_bf16": (C.c_int, [C.POINTER(GemmDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sdn_gemm_stats_f16": (C.c_int, [C.POINTER(GemmDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sdn_groupnorm_cols_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

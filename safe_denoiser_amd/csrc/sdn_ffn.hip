@@ -1,0 +1,279 @@
+// GEGLU feed-forward of a C = 320 transformer block as ONE kernel (rows U5 / U4, the 64 x 64 level of SD-v1.4):
+//
+//   out = x + [ GEGLU(LN3(h3) W1^T + b1) | h3 ] . [ Wpo W2 | Wpo ]^T + (Wpo b2 + bpo)
+//
+// i.e. LayerNorm-folded GEGLU projection (sdn_gemm_ln_*, N = 8C) followed by the FeedForward output linear already
+// contracted with the block's proj_out (two-source GEMM, K = 5C) -- what sdn_unet.hip emitted as two launches.  Between
+// them sat the [M, 4C] hidden tensor: 1.34 GB written and re-read per block at B = 128 samples, and ablations of the two
+// launches (tools/bench_gemm.py, VARIANTS=0,32,16: in-loop DMA off / stores off) put 23-38 % of their time on exactly that
+// traffic and on the L2 -> LDS re-streaming of A by 20 column tiles (13.4 GB per launch, 60 % of what the L2s can deliver).
+// Here a workgroup keeps a 128-row block of h3 in LDS for its whole life and the hidden activation never leaves the CU:
+//
+//   X      [128 x 320]  h3 rows, 5 swizzled k-tile images (80 KB), loaded once: A operand of the projection AND of the
+//                       trailing [h3 | Wpo] k-tiles
+//   for each chunk of 64 hidden units (20 chunks; = 128 value/gate-interleaved columns of W1):
+//       acc1[128 x 128]  = X . W1_chunk^T           5 k-tiles of W1 (16 KB each) through a 2-deep LDS-DMA ring
+//       H[128 x 64]      = (LN fold) value * gelu(gate), 16 bit, written as ONE k-tile image into the ring stage just freed
+//       acc[128 x 320] += H . Wcat[:, chunk]^T      one 40 KB k-tile of the contracted output weight
+//   acc += X . Wcat[:, 4C:]^T (5 k-tiles, double-buffered), + bias + residual x -> staged 16-bit store (+ GroupNorm column sums)
+//
+// 8 waves as 2 (M) x 4 (N): a wave owns 64 x 32 of acc1 (one value/gate fragment pair -> 16 hidden columns) and 64 x 80 of
+// acc.  Per 128 rows the L2 -> LDS traffic is 2.7 MB for 682 MFLOP (4 B/kFLOP against 15.6 for the 128 x 128 projection tile).
+//
+// Arithmetic is IDENTICAL to the two-launch path, bit for bit: same k order per output element (16x16x32 MFMA chains over
+// k-tiles 0..4 for the projection, 0..24 for the contraction, accumulators started from the bias), same LayerNorm-fold /
+// GELU / pack expressions, same residual add, same row-group order of the column sums -- tests/test_gpu_ops.py checks equality.
+//
+// LDS hazards, in program order (every wave executes the same sequence):
+//   ring stage s = g & 1 for projection k-tile g = 5 chunk + kt.  Iteration g issues k-tile g+1 into stage s^1, last read
+//   in iteration g-1 (ended by a barrier) -- or, for kt = 0, holding H of the previous chunk, whose readers (the previous
+//   contraction) are behind the barrier that ends it.  H goes into stage (5 chunk + 4) & 1, last read in iteration kt = 4.
+//   The contraction tile for a chunk arrives in 5 one-piece-per-wave slices issued AFTER each iteration's ring DMA, so the
+//   iteration's `vmcnt(1)` retires the ring k-tile (and the previous slice) while the newest slice stays in flight; the buffer
+//   was released by the barrier after the previous contraction.  `vmcnt(0)` + barrier precede every read of a buffer.
+#include "sdn_gemm_common.h"
+
+namespace sdn_gemm_detail {
+
+#define SDN_STAMP(IDX) {}
+
+struct FfnArgs {
+  const void* x;            // h3 [M, C] 16 bit
+  const float* stats;       // [M][2] (mean, rstd) of the rows of x (sdn_row_stats_*)
+  const void* w1;           // [8C, C] 16 bit: value/gate rows interleaved in groups of 16, LayerNorm gamma folded in
+  const float* c1; const float* d1;   // [8C] fold coefficients (sdn_ln_fold)
+  const void* w2;           // [C, 5C] 16 bit: [Wpo W2 | Wpo]
+  const float* b2;          // [C]
+  const void* residual;     // [M, C] 16 bit
+  void* out;                // [M, C] 16 bit
+  float* col_stats;         // nullable: [ceil(M / 128)][C][2]
+  int M;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(512, 1)
+k_ffn320(const FfnArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int C = 320, HID = 4 * C, KT1 = C / BK, NCH = HID / 64, KT2 = NCH + KT1;      // 5 / 20 chunks / 25 contraction k-tiles
+  constexpr int BM = 128, BN = C, THREADS = 512, NWAVES = 8, NREP = 5;
+  constexpr int XIMG = BM * 128;                             // one k-tile image of X or H: 16 KB
+  constexpr int W2IMG = C * 128;                             // one k-tile of the contraction weight: 40 KB
+  constexpr int OFF_W2A = KT1 * XIMG;                        // 81920
+  constexpr int OFF_RING = OFF_W2A + W2IMG;                  // 122880: ring stages 0 / 1 (16 KB each) + 8 KB = second W2 buffer (tail)
+  constexpr int LDS_BYTES = OFF_RING + W2IMG;                // 163840
+  constexpr unsigned OOB = 0x80000000u;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 2, wn = wid & 3;
+  const int lrow = lane >> 3, lchunk = (lane & 7) ^ lrow;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int m0 = blockIdx.x * BM, n0 = 0;
+
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(a.x, (unsigned)((long)a.M * C * 2));
+  const __amdgpu_buffer_rsrc_t rs_w1 = make_rsrc(a.w1, (unsigned)(2 * HID * C * 2));
+  const __amdgpu_buffer_rsrc_t rs_w2 = make_rsrc(a.w2, (unsigned)(C * (HID + C) * 2));
+
+  // ---- X: 80 pieces of 1 KiB (k-tile image kt = p / 16, rows 8 (p % 16) ..), 10 per wave ----
+#pragma unroll
+  for (int q = 0; q < 10; ++q) {
+    const int p = wid * 10 + q;
+    const int kt = p >> 4, rg = p & 15;
+    const int m = m0 + rg * 8 + lrow;
+    const unsigned off = m < a.M ? (unsigned)(((long)m * C + kt * BK + lchunk * 8) * 2) : OOB;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(smem + p * 1024), 16, off, 0, 0, 0);
+  }
+  // projection weight k-tile g (chunk g / 5, k-tile g % 5): 16 pieces, 2 per wave
+  const unsigned w1_lane = (unsigned)(((wid * 2 * 8 + lrow) * C + lchunk * 8) * 2);
+  auto issue_w1 = [&](int g) {
+    const int jc = g / KT1, kt = g - jc * KT1;
+    unsigned char* dst = smem + OFF_RING + (g & 1) * XIMG + wid * 2048;
+    const unsigned base = w1_lane + (unsigned)((jc * 128 * C + kt * BK) * 2);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w1, (lds_ptr_t)dst, 16, base, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w1, (lds_ptr_t)(dst + 1024), 16, base + (unsigned)(8 * C * 2), 0, 0, 0);
+  };
+  // contraction weight k-tile t: 40 pieces, 5 per wave; slice q of a wave = piece wid * 5 + q
+  const unsigned w2_lane = (unsigned)(((wid * 5 * 8 + lrow) * (HID + C) + lchunk * 8) * 2);
+  auto issue_w2_slice = [&](int t, int q, int buf_off) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w2, (lds_ptr_t)(smem + buf_off + (wid * 5 + q) * 1024), 16,
+                                             w2_lane + (unsigned)((q * 8 * (HID + C) + t * BK) * 2), 0, 0, 0);
+  };
+
+  issue_w1(0);
+  // accumulators of the contraction start from the bias; row statistics of this wave's rows
+  f32x4 acc[4][NREP];
+  {
+    f32x4 bv[NREP];
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) bv[j] = *reinterpret_cast<const f32x4*>(a.b2 + wn * 16 * NREP + j * 16 + fq * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NREP; ++j) acc[i][j] = bv[j];
+  }
+  float ln_mu[4], ln_rs[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + fr;
+    const float2 st2 = *reinterpret_cast<const float2*>(a.stats + 2 * (long)(m < a.M ? m : 0));
+    ln_mu[i] = st2.x; ln_rs[i] = st2.y;
+  }
+  // fold coefficients of this wave's value / gate fragment pair, one chunk ahead
+  f32x4 cv[2], dv[2];
+  auto load_cd = [&](int jc) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = jc * 128 + wn * 32 + j * 16 + fq * 4;
+      cv[j] = *reinterpret_cast<const f32x4*>(a.c1 + n); dv[j] = *reinterpret_cast<const f32x4*>(a.d1 + n);
+    }
+  };
+  load_cd(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const unsigned char* sa_x = smem + (wm * 64) * 128;                       // + kt * XIMG
+  for (int jc = 0; jc < NCH; ++jc) {
+    f32x4 acc1[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { acc1[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    f32x4 cvn[2] = {cv[0], cv[1]}, dvn[2] = {dv[0], dv[1]};                 // this chunk's coefficients (cv / dv are refilled below)
+    // ---- projection: 5 k-tiles ----
+#pragma unroll
+    for (int kt = 0; kt < KT1; ++kt) {
+      const int g = jc * KT1 + kt;
+      if (kt == 0 && jc + 1 < NCH) load_cd(jc + 1);                          // (older than the DMAs: vmcnt(1) below keeps only a slice in flight)
+      if (g + 1 < NCH * KT1) issue_w1(g + 1);
+      issue_w2_slice(jc, kt, OFF_W2A);
+      const unsigned char* sa = sa_x + kt * XIMG;
+      const unsigned char* sw = smem + OFF_RING + (g & 1) * XIMG + (wn * 32) * 128;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        typename T::v8 fa[4], fw[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const typename T::v8*>(sa + lds_off(i * 16 + fr, ks * 4 + fq));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fw[j] = *reinterpret_cast<const typename T::v8*>(sw + lds_off(j * 16 + fr, ks * 4 + fq));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc1[i][j] = T::mfma16(fw[j], fa[i], acc1[i][j]);
+      }
+      // the ring k-tile (and every older request) has landed; this iteration's W2 slice may still be in flight
+      if (kt + 1 < KT1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // fragment reads done before the stage is refilled
+      __builtin_amdgcn_s_barrier();
+    }
+    // ---- GEGLU: LayerNorm fold, value * gelu(gate), 16 bit -> H (a k-tile image in the stage read last) ----
+    unsigned char* sh = smem + OFF_RING + ((jc * KT1 + KT1 - 1) & 1) * XIMG;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = wm * 64 + i * 16 + fr;
+      const float mu = ln_mu[i], rs = ln_rs[i];
+      const f32x4 hv = (acc1[i][0] - mu * cvn[0]) * rs + dvn[0], gv = (acc1[i][1] - mu * cvn[1]) * rs + dvn[1];
+      uint2 pk;
+      pk.x = T::pack2(hv[0] * gelu_erf(gv[0]), hv[1] * gelu_erf(gv[1]));
+      pk.y = T::pack2(hv[2] * gelu_erf(gv[2]), hv[3] * gelu_erf(gv[3]));
+      *reinterpret_cast<uint2*>(sh + lds_off(row, wn * 2 + (fq >> 1)) + (fq & 1) * 8) = pk;
+    }
+    __syncthreads();                                                         // H visible (no DMA outstanding: vmcnt(0) above)
+    // ---- contraction with this chunk's k-tile ----
+    {
+      const unsigned char* sa = sh + (wm * 64) * 128;
+      const unsigned char* sw = smem + OFF_W2A + (wn * 16 * NREP) * 128;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        typename T::v8 fa[4], fw[NREP];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const typename T::v8*>(sa + lds_off(i * 16 + fr, ks * 4 + fq));
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) fw[j] = *reinterpret_cast<const typename T::v8*>(sw + lds_off(j * 16 + fr, ks * 4 + fq));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < NREP; ++j) acc[i][j] = T::mfma16(fw[j], fa[i], acc[i][j]);
+      }
+    }
+    __syncthreads();                                                         // H's stage and the W2 buffer are free again
+  }
+
+  // ---- trailing k-tiles [h3 | Wpo]: A = X, weights double-buffered between the two 40 KB buffers ----
+#pragma unroll
+  for (int q = 0; q < 5; ++q) issue_w2_slice(NCH, q, OFF_W2A);
+#pragma unroll
+  for (int q = 0; q < 5; ++q) issue_w2_slice(NCH + 1, q, OFF_RING);
+#pragma unroll
+  for (int kt = 0; kt < KT1; ++kt) {
+    const int boff = (kt & 1) ? OFF_RING : OFF_W2A;
+    if (kt + 1 < KT1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");       // this tile landed; the next one may be in flight
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                            // (raw: __syncthreads would drain the tile in flight)
+    {
+      const unsigned char* sa = sa_x + kt * XIMG;
+      const unsigned char* sw = smem + boff + (wn * 16 * NREP) * 128;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        typename T::v8 fa[4], fw[NREP];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const typename T::v8*>(sa + lds_off(i * 16 + fr, ks * 4 + fq));
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) fw[j] = *reinterpret_cast<const typename T::v8*>(sw + lds_off(j * 16 + fr, ks * 4 + fq));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < NREP; ++j) acc[i][j] = T::mfma16(fw[j], fa[i], acc[i][j]);
+      }
+    }
+    if (kt + 2 < KT1) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                                          // every wave done with this buffer before it is refilled
+#pragma unroll
+      for (int q = 0; q < 5; ++q) issue_w2_slice(NCH + kt + 2, q, boff);
+    }
+  }
+  __syncthreads();                                                           // X and the weight buffers are dead: LDS becomes the staging slab
+
+  // ---- epilogue: + residual -> 16 bit, whole-row stores, GroupNorm column sums (the shared GEMM epilogue) ----
+  GemmArgs g{};
+  g.M = a.M; g.N = C; g.K = HID + C; g.ldc = C; g.n_valid = C; g.act = 0; g.out_kind = 0;
+  g.residual = (const __bf16*)a.residual; g.out = a.out; g.col_stats = a.col_stats; g.res_lds = 1;
+  g.res_bytes = (unsigned)((long)a.M * C * 2); g.rows_per_batch = 0; g.residual_bcast = 0;
+  constexpr int LNF = 0, WGM = 2, NSTAGE = 2, STAGE = LDS_BYTES / 2;
+  constexpr int CW_PAD = (BN + 8) * 2;
+  const bool staged = true;
+  const int out_cols = BN;
+  const bool res_lds = true;
+  const int CW = BN * 2;
+  const bool lean = true, lean_gelu = false, lean_gate = false;
+  const __amdgpu_buffer_rsrc_t rs_res = make_rsrc(a.residual, g.res_bytes);
+  constexpr int PASSES = 1, WM_PER_PASS = WGM / PASSES, ROWS_PER_PASS = 64 * WM_PER_PASS;
+  static_assert(BM * CW_PAD <= NSTAGE * STAGE - 8 * BN * 8, "staged tile and the column-sum scratch must fit the LDS");
+#define SDN_PASS 0
+#include "sdn_gemm_epilogue.inc"
+#undef SDN_PASS
+  (void)WGM; (void)lean_gelu; (void)lean_gate; (void)staged; (void)CW_PAD; (void)KT2;
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+}  // namespace sdn_gemm_detail
+using namespace sdn_gemm_detail;
+
+// C must be 320 (the instantiated width: SD-v1.4's 64 x 64 level); other widths keep the two-launch path.
+extern "C" int sdn_ffn_geglu_fused(int32_t dtype, int64_t M, int32_t C, const void* x, const float* row_stats, const void* w1_folded, const float* c1,
+                        const float* d1, const void* w_cat, const float* b_cat, const void* residual, void* out, float* col_stats,
+                        void* stream) {
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  if (dtype < 0 || dtype > 1 || C != 320 || M < 0 || !x || !row_stats || !w1_folded || !c1 || !d1 || !w_cat || !b_cat || !residual || !out)
+    return SDN_E_INVALID;
+  if (!al16(x) || !al16(w1_folded) || !al16(c1) || !al16(d1) || !al16(w_cat) || !al16(b_cat) || !al16(residual) || !al16(out) ||
+      (reinterpret_cast<uintptr_t>(row_stats) & 7) || (reinterpret_cast<uintptr_t>(col_stats) & 7))
+    return SDN_E_INVALID;
+  if (M * C * 2 >= (1L << 31)) return SDN_E_INVALID;          // LDS-DMA offsets are 31 bit
+  if (M == 0) return SDN_OK;
+  FfnArgs a{x, row_stats, w1_folded, c1, d1, w_cat, b_cat, residual, out, col_stats, (int)M};
+  const unsigned grid = (unsigned)((M + 127) / 128);
+  if (dtype == 1) hipLaunchKernelGGL((k_ffn320<SdnF16>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((k_ffn320<SdnBF16>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+  return sdn_launch_status();
+}

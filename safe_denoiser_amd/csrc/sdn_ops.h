@@ -21,3 +21,4 @@ int sdn_temb_f32(float timestep, const float* t_dev, int batch, int dim, void* o
 // wa [C][K], wb [C][C] in the plan's 16-bit dtype (0 = bf16, 1 = f16).  Prepare-time helper (sdn_unet_prepare).
 int sdn_linear_pair_fold(int dtype, const void* wa, const void* wb, const float* ba, const float* bb, int C, int K, void* w_cat,
                          float* b_cat, void* stream);
+

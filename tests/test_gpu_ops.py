@@ -443,3 +443,42 @@ def test_geglu_epilogue_gelu_is_within_the_16_bit_output_rounding():
     print(f"GEGLU f16: rel L2 {r:.2e}, gate range [{float(gate.min()):.1f}, {float(gate.max()):.1f}]")
     assert r <= 4e-4                                                            # fp16 rounding alone: ~2.9e-4
     assert float(gate.abs().max()) > 10.0
+
+
+# ------------------------------------------------------------------------------------------ fused GEGLU feed-forward
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M", [128 * 5 + 37, 4096 * 6])
+def test_fused_geglu_feed_forward_is_bit_identical_to_the_two_launches(dt, M):
+    """sdn_ffn_geglu_fused (csrc/sdn_ffn.hip): LayerNorm-folded GEGLU projection + the [ff | h3] . [Wpo W2 | Wpo]^T contraction
+    + residual + GroupNorm column sums with the hidden activation kept in LDS.  Same k order, same epilogue expressions ->
+    the SAME BITS as sdn_gemm_ln_* (GEGLU, pre-pass statistics) followed by the two-source sdn_gemm_stats_*, including a
+    ragged last row block; and within 16-bit rounding of plain fp32 arithmetic."""
+    from safe_denoiser_amd.unet import _interleave16
+    Cc = 320
+    g = torch.Generator().manual_seed(11)
+    x = ((torch.randn(M, Cc, generator=g) * 1.5 + torch.randn(M, 1, generator=g) * 2.0)).to(dt).cuda()
+    w1 = (torch.randn(8 * Cc, Cc, generator=g) * Cc ** -0.5).to(dt)
+    b1 = torch.randn(8 * Cc, generator=g)
+    gamma = 1 + 0.2 * torch.randn(Cc, generator=g); beta = 0.3 * torch.randn(Cc, generator=g)
+    wcat = (torch.randn(Cc, 5 * Cc, generator=g) * (5 * Cc) ** -0.5).to(dt).cuda()
+    bcat = torch.randn(Cc, generator=g).cuda()
+    res = torch.randn(M, Cc, generator=g).to(dt).cuda()
+    w1i, b1i = _interleave16(w1).contiguous().cuda(), _interleave16(b1).contiguous().cuda()
+    nblk = (M + 127) // 128
+    cs_a = torch.zeros(nblk, Cc, 2, device="cuda"); cs_b = torch.zeros_like(cs_a)
+    ff = ops.gemm_ln(x, w1i, gamma.cuda(), beta.cuda(), b1i, act=2, prepass=True)
+    want = ops.gemm(ff, wcat, a2=x, bias=bcat, residual=res, col_stats=cs_a)
+    got = ops.ffn_fused(x, w1i, gamma.cuda(), beta.cuda(), b1i, wcat, bcat, res, col_stats=cs_b)
+    torch.cuda.synchronize()
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16)), float((got.float() - want.float()).abs().max())
+    assert torch.equal(cs_a, cs_b)
+    # fp32 arithmetic on the same 16-bit operands (hidden activation NOT rounded): bounded by the 16-bit roundings
+    y = F.linear(F.layer_norm(x.float().cpu(), (Cc,), gamma, beta, 1e-5), w1.float(), b1)
+    hid = y[:, :4 * Cc] * F.gelu(y[:, 4 * Cc:])
+    ref = res.float().cpu() + torch.cat([hid, x.float().cpu()], 1) @ wcat.float().cpu().T + bcat.cpu()
+    assert rel_l2(got, ref) <= (6e-3 if dt == torch.bfloat16 else 8e-4)
+    # no column sums requested; other widths are refused (the caller keeps the two-launch form)
+    assert torch.equal(ops.ffn_fused(x, w1i, gamma.cuda(), beta.cuda(), b1i, wcat, bcat, res).view(torch.int16), want.view(torch.int16))
+    rc = sda.lib().sdn_ffn_geglu_fused(0, 128, 640, x.data_ptr(), cs_a.data_ptr(), w1i.data_ptr(), b1i.data_ptr(), b1i.data_ptr(),
+                                       wcat.data_ptr(), bcat.data_ptr(), res.data_ptr(), got.data_ptr(), None, None)
+    assert rc == sda.SDN_E_INVALID if hasattr(sda, "SDN_E_INVALID") else rc != 0
