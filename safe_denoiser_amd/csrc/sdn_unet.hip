@@ -37,7 +37,7 @@ enum Space { SP_NONE = 0, SP_W = 1, SP_WS = 2, SP_LATENTS = 3, SP_TEXT = 4, SP_O
 struct Ref { int space = SP_NONE; int64_t off = 0; };
 
 enum OpKind { OP_TEMB, OP_CONV_IN, OP_GEMM, OP_GN, OP_LN, OP_ATTN, OP_PATCHIFY, OP_UNPATCHIFY, OP_LATENT_MIX, OP_SOFTMAX,
-              OP_TRANSPOSE, OP_GAUSS, OP_REPEAT, OP_CLIP_EMBED, OP_MATTN, OP_ROWSTATS };
+              OP_TRANSPOSE, OP_GAUSS, OP_REPEAT, OP_CLIP_EMBED, OP_MATTN, OP_ROWSTATS, OP_FFN };
 
 struct Op {
   int kind;
@@ -142,6 +142,7 @@ struct sdn_unet {
   bool ln_fold = true;                  // BasicTransformerBlock LayerNorms folded into their consumer GEMMs where it pays
   int ln_prepass_all = 0;               // debug A/B: 1 = every folded LayerNorm takes its row statistics from the pre-pass
   bool ff_fuse = true;                  // FeedForward's output linear and the block's proj_out (no nonlinearity between them)
+  bool ffn_fuse = true;                 // ... and the GEGLU projection in front of them: one launch, hidden activation in LDS (C = 320)
                                         // contracted into ONE GEMM over [ff | h3] with the product weight (sdn_linear_pair_fold)
   struct FoldJob { int64_t w, gamma, beta, bias, wf, c, d; int rows, cols; int kind = 0; };   // kind 0: LayerNorm fold; 1: linear pair
   std::vector<FoldJob> fold_jobs;       // what sdn_unet_prepare has to compute into the SDN_P_DERIVED regions
@@ -479,6 +480,32 @@ struct Builder {
     gemm(rows, C, C, R(at), o2w, o2b, R(h3), SDN_ACT_NONE, R(h2));
     drop(h2); drop(at);
     // GEGLU feed-forward
+    if (fold3 && u->ff_fuse && u->ffn_fuse && C == 320) {
+      // norm3 -> GEGLU projection -> [ff | h3] . [Wpo W2 | Wpo]^T + residual as ONE launch (sdn_ffn.hip): the [rows, 4C] hidden
+      // activation stays in LDS.  Same derived weights as the two launches below, same bits.
+      if (ln.off >= 0) drop(ln);
+      const std::string wname = tb + ".ff.net.0.proj.weight";
+      const bool fresh1 = u->param_index.find(wname + "#ln") == u->param_index.end();
+      Ref wf = derived(wname + "#ln", (int64_t)8 * C * C * 2), c1 = derived(wname + "#ln_c", (int64_t)8 * C * 4), d1 = derived(wname + "#ln_d", (int64_t)8 * C * 4);
+      if (fresh1) u->fold_jobs.push_back({f1w.off, l3g.off, l3b.off, f1b.off, wf.off, c1.off, d1.off, 8 * C, C});
+      const bool fresh2 = u->param_index.find(pfx + ".proj_out.weight#ff") == u->param_index.end();
+      Ref wcat = derived(pfx + ".proj_out.weight#ff", (int64_t)C * 5 * C * 2), bcat = derived(pfx + ".proj_out.bias#ff", (int64_t)C * 4);
+      if (fresh2) { sdn_unet::FoldJob j{f2w.off, pow_.off, f2b.off, pob.off, wcat.off, bcat.off, -1, C, 4 * C}; j.kind = 1; u->fold_jobs.push_back(j); }
+      Act st = act(rows, 2, 0, 0, 4);
+      { Op o; o.kind = OP_ROWSTATS; o.a = R(h3); o.rows = rows; o.c1 = C; o.eps = 1e-5f; o.out = R(st);
+        o.bytes = 2.0 * rows * C; snprintf(o.label, sizeof(o.label), "k_row_stats"); plan->ops.push_back(o); }
+      want_stats(out);
+      Op o; o.kind = OP_FFN; o.a = R(h3); o.ln_stats = R(st); o.w = wf; o.ln_c = c1; o.ln_d = d1; o.a2 = wcat; o.bias = bcat;
+      o.residual = R(rep > 1 ? *x_full : x); o.out = R(out); o.rows = rows; o.c1 = C;
+      o.col = pending_cols; pending_cols = Ref();
+      o.flops = 2.0 * (double)rows * ((double)8 * C * C + (double)C * 5 * C);
+      o.bytes = 2.0 * ((double)rows * C * 3 + (double)8 * C * C + (double)5 * C * C);
+      snprintf(o.label, sizeof(o.label), "k_ffn320");
+      plan->ops.push_back(o);
+      plan->flops += o.flops;
+      drop(st); drop(h3);
+      return;
+    }
     Act ff = act(rows, 4 * C, hw, x.side);
     if (fold3) {
       gemm_ln(h3, rows, 8 * C, C, tb + ".ff.net.0.proj.weight", f1w, l3g, l3b, f1b, R(ff), SDN_ACT_GEGLU, true);
@@ -1447,6 +1474,11 @@ static int launch_ops(sdn_unet* u, Plan* p, const char* W, const char* WS, const
       case OP_ROWSTATS:
         rc = (f16 ? sdn_row_stats_f16 : sdn_row_stats_bf16)(P(o.a), o.rows, o.c1, o.eps, (float*)P(o.out), stream);
         break;
+      case OP_FFN:
+        rc = sdn_ffn_geglu_fused(f16 ? 1 : 0, o.rows, o.c1, P(o.a), (const float*)P(o.ln_stats), P(o.w), (const float*)P(o.ln_c),
+                                 (const float*)P(o.ln_d), P(o.a2), (const float*)P(o.bias), P(o.residual), (void*)P(o.out),
+                                 o.col.space != SP_NONE ? (float*)P(o.col) : nullptr, stream);
+        break;
       case OP_GEMM:
         if (o.ln) {
           rc = (f16 ? sdn_gemm_ln_f16 : sdn_gemm_ln_bf16)(&o.gd, P(o.a), P(o.w), (const float*)P(o.ln_c), (const float*)P(o.ln_d), o.eps,
@@ -1628,6 +1660,12 @@ extern "C" void sdn_debug_set_ln_prepass_all(sdn_unet* u, int on) {
   u->plans.clear();
 }
 
+extern "C" void sdn_debug_set_ffn_fuse(sdn_unet* u, int on) {   // one-launch GEGLU feed-forward (C = 320) on / off: A/B and equality tests
+  if (!u) return;
+  u->ffn_fuse = on != 0;
+  drop_graphs(u);
+  u->plans.clear();
+}
 extern "C" void sdn_debug_set_ff_fuse(sdn_unet* u, int on) {
   if (!u) return;
   u->ff_fuse = on != 0;

@@ -183,3 +183,30 @@ def test_small_unet_fp16_storage_meets_fp16_tolerance():
     r32 = rel_l2(y, OracleUNet(sd, SMALL_O, act_dtype=None)(x, 781.0, e))
     print(f"small unet fp16 storage: rel L2 vs fp16-emulating oracle {r16:.3e}, vs fp32 oracle {r32:.3e}")
     assert r16 <= 4e-3 and r32 <= 4e-3
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_one_launch_feed_forward_plan_gives_the_same_bits(dt):
+    """The C = 320 blocks run norm3 -> GEGLU -> ff.net.2 -> proj_out -> residual as ONE launch (csrc/sdn_ffn.hip, plan op
+    k_ffn320).  Switching it off (sdn_debug_set_ffn_fuse) falls back to the LayerNorm-folded GEGLU GEMM + the two-source
+    contraction; both forms must give a forward the same bits, with and without a shared-latent (latent_repeat) plan."""
+    import safe_denoiser_amd as sda
+    for rep in (1, 2):
+        u = UNet2DConditionModel(text_len=77, dtype=dt, latent_repeat=rep, **SMALL)
+        u.load_state_dict(u.synthetic_state_dict(7))
+        g = torch.Generator().manual_seed(3)
+        B = 4
+        x = torch.randn(B // rep, 4, 16, 16, generator=g).cuda()
+        e = torch.randn(B, 77, 768, generator=g).cuda()
+        outs, kernels = [], []
+        for on in (1, 0, 1):
+            sda.lib().sdn_debug_set_ffn_fuse(u._h, on)
+            u._ws = {}
+            u.profile_next()
+            outs.append(u(x, 781.0, encoder_hidden_states=e).sample.clone())
+            torch.cuda.synchronize()
+            kernels.append({r["kernel"] for r in u.profile_read()})
+        assert "k_ffn320" in kernels[0] and "k_ffn320" not in kernels[1]        # the switch really selects the plan form
+        assert torch.isfinite(outs[0]).all()
+        torch.testing.assert_close(outs[0], outs[1], rtol=0, atol=0)
+        torch.testing.assert_close(outs[0], outs[2], rtol=0, atol=0)
