@@ -36,6 +36,25 @@
 namespace sdn_gemm_detail {
 
 #define SDN_STAMP(IDX) {}
+// Diagnostics build (-DSDN_FFN_STAMPS, `make stamps`, tools/ffn_stamps.py): per-wave cycle sums of the chunk loop's phases.
+#ifdef SDN_FFN_STAMPS
+__device__ unsigned long long* g_ffn_stamps = nullptr;
+#define SDN_FTS_DECL unsigned long long fts_prev = 0, fts_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define SDN_FTS_MARK(I)                                                                         \
+  {                                                                                             \
+    unsigned long long t_;                                                                      \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
+    if ((I) >= 0) fts_sum[(I) < 0 ? 0 : (I)] += t_ - fts_prev;                                  \
+    fts_prev = t_;                                                                              \
+  }
+#define SDN_FTS_FLUSH                                                                           \
+  if (g_ffn_stamps && lane == 0)                                                                \
+    for (int i_ = 0; i_ < 8; ++i_) g_ffn_stamps[((long)blockIdx.x * 8 + wid) * 8 + i_] = fts_sum[i_];
+#else
+#define SDN_FTS_DECL
+#define SDN_FTS_MARK(I)
+#define SDN_FTS_FLUSH
+#endif
 
 struct FfnArgs {
   const void* x;            // h3 [M, C] 16 bit
@@ -66,6 +85,8 @@ k_ffn320(const FfnArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  SDN_FTS_DECL
+  SDN_FTS_MARK(-1)
   const int wm = wid >> 2, wn = wid & 3;
   const int lrow = lane >> 3, lchunk = (lane & 7) ^ lrow;
   const int fr = lane & 15, fq = lane >> 4;
@@ -119,7 +140,7 @@ k_ffn320(const FfnArgs a) {
     const float2 st2 = *reinterpret_cast<const float2*>(a.stats + 2 * (long)(m < a.M ? m : 0));
     ln_mu[i] = st2.x; ln_rs[i] = st2.y;
   }
-  // fold coefficients of this wave's value / gate fragment pair, one chunk ahead
+  // fold coefficients of this wave's value / gate fragment pair
   f32x4 cv[2], dv[2];
   auto load_cd = [&](int jc) {
 #pragma unroll
@@ -128,21 +149,21 @@ k_ffn320(const FfnArgs a) {
       cv[j] = *reinterpret_cast<const f32x4*>(a.c1 + n); dv[j] = *reinterpret_cast<const f32x4*>(a.d1 + n);
     }
   };
-  load_cd(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   const unsigned char* sa_x = smem + (wm * 64) * 128;                       // + kt * XIMG
+  SDN_FTS_MARK(0)                                                           // prologue: X + first W1 k-tile landed
   for (int jc = 0; jc < NCH; ++jc) {
     f32x4 acc1[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { acc1[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-    f32x4 cvn[2] = {cv[0], cv[1]}, dvn[2] = {dv[0], dv[1]};                 // this chunk's coefficients (cv / dv are refilled below)
     // ---- projection: 5 k-tiles ----
 #pragma unroll
     for (int kt = 0; kt < KT1; ++kt) {
       const int g = jc * KT1 + kt;
-      if (kt == 0 && jc + 1 < NCH) load_cd(jc + 1);                          // (older than the DMAs: vmcnt(1) below keeps only a slice in flight)
+      if (kt == 0) load_cd(jc);                                              // used after the k loop (older than the DMAs: vmcnt(1) below
+                                                                             // keeps only a slice in flight)
       if (g + 1 < NCH * KT1) issue_w1(g + 1);
       issue_w2_slice(jc, kt, OFF_W2A);
       const unsigned char* sa = sa_x + kt * XIMG;
@@ -160,10 +181,13 @@ k_ffn320(const FfnArgs a) {
           for (int j = 0; j < 2; ++j) acc1[i][j] = T::mfma16(fw[j], fa[i], acc1[i][j]);
       }
       // the ring k-tile (and every older request) has landed; this iteration's W2 slice may still be in flight
+      SDN_FTS_MARK(1)                                                        // projection: DMA issue + fragment reads + MFMAs issued
       if (kt + 1 < KT1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // fragment reads done before the stage is refilled
+      SDN_FTS_MARK(2)                                                        // ... wait for the next k-tile
       __builtin_amdgcn_s_barrier();
+      SDN_FTS_MARK(3)                                                        // ... barrier
     }
     // ---- GEGLU: LayerNorm fold, value * gelu(gate), 16 bit -> H (a k-tile image in the stage read last) ----
     unsigned char* sh = smem + OFF_RING + ((jc * KT1 + KT1 - 1) & 1) * XIMG;
@@ -171,13 +195,15 @@ k_ffn320(const FfnArgs a) {
     for (int i = 0; i < 4; ++i) {
       const int row = wm * 64 + i * 16 + fr;
       const float mu = ln_mu[i], rs = ln_rs[i];
-      const f32x4 hv = (acc1[i][0] - mu * cvn[0]) * rs + dvn[0], gv = (acc1[i][1] - mu * cvn[1]) * rs + dvn[1];
+      const f32x4 hv = (acc1[i][0] - mu * cv[0]) * rs + dv[0], gv = (acc1[i][1] - mu * cv[1]) * rs + dv[1];
       uint2 pk;
       pk.x = T::pack2(hv[0] * gelu_erf(gv[0]), hv[1] * gelu_erf(gv[1]));
       pk.y = T::pack2(hv[2] * gelu_erf(gv[2]), hv[3] * gelu_erf(gv[3]));
       *reinterpret_cast<uint2*>(sh + lds_off(row, wn * 2 + (fq >> 1)) + (fq & 1) * 8) = pk;
     }
+    SDN_FTS_MARK(4)                                                          // GEGLU epilogue (waits for the MFMAs)
     __syncthreads();                                                         // H visible (no DMA outstanding: vmcnt(0) above)
+    SDN_FTS_MARK(5)                                                          // barrier
     // ---- contraction with this chunk's k-tile ----
     {
       const unsigned char* sa = sh + (wm * 64) * 128;
@@ -195,10 +221,26 @@ k_ffn320(const FfnArgs a) {
           for (int j = 0; j < NREP; ++j) acc[i][j] = T::mfma16(fw[j], fa[i], acc[i][j]);
       }
     }
+    SDN_FTS_MARK(6)                                                          // contraction: fragment reads + MFMAs issued
     __syncthreads();                                                         // H's stage and the W2 buffer are free again
+    SDN_FTS_MARK(5)
   }
 
-  // ---- trailing k-tiles [h3 | Wpo]: A = X, weights double-buffered between the two 40 KB buffers ----
+  // ---- trailing k-tiles [h3 | Wpo]: A = X, weights double-buffered between the two 40 KB buffers.  The residual tile (80 KB of
+  //      HBM reads the shared epilogue would only start after the last MFMA) is DMA'd into the staging slab piecewise: the slab
+  //      is the X region, and X image kt is dead as soon as trailing k-tile kt has been consumed by every wave.
+  const __amdgpu_buffer_rsrc_t rs_res = make_rsrc(a.residual, (unsigned)((long)a.M * C * 2));
+  auto issue_residual = [&](int img) {                      // pieces 16 img .. 16 img + 15 of the linear [128][640 B] slab, 2 per wave
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int piece = img * 16 + wid * 2 + q;
+      const int e = piece * 64 + lane;
+      const int r = e / (BN / 8), c = e - r * (BN / 8);
+      const int m = m0 + r;
+      const unsigned off = m < a.M ? (unsigned)(((long)m * C + c * 8) * 2) : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_res, (lds_ptr_t)(smem + piece * 1024), 16, off, 0, 0, 0);
+    }
+  };
 #pragma unroll
   for (int q = 0; q < 5; ++q) issue_w2_slice(NCH, q, OFF_W2A);
 #pragma unroll
@@ -206,9 +248,13 @@ k_ffn320(const FfnArgs a) {
 #pragma unroll
   for (int kt = 0; kt < KT1; ++kt) {
     const int boff = (kt & 1) ? OFF_RING : OFF_W2A;
-    if (kt + 1 < KT1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");       // this tile landed; the next one may be in flight
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                                            // (raw: __syncthreads would drain the tile in flight)
+    // this k-tile's weights have landed; what was issued after them may stay in flight (in issue order: kt = 0: W2[1] |
+    // 1: W2[2], res0 | 2: res0?, W2[3], res1 | 3: res1, W2[4], res2 | 4: res2, res3)
+    if (kt == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if (kt == 1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else if (kt == 2 || kt == 3) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                            // (raw: __syncthreads would drain what is in flight)
     {
       const unsigned char* sa = sa_x + kt * XIMG;
       const unsigned char* sw = smem + boff + (wn * 16 * NREP) * 128;
@@ -225,14 +271,16 @@ k_ffn320(const FfnArgs a) {
           for (int j = 0; j < NREP; ++j) acc[i][j] = T::mfma16(fw[j], fa[i], acc[i][j]);
       }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                            // every wave done with this weight buffer and with X image kt
     if (kt + 2 < KT1) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                                          // every wave done with this buffer before it is refilled
 #pragma unroll
       for (int q = 0; q < 5; ++q) issue_w2_slice(NCH + kt + 2, q, boff);
     }
+    issue_residual(kt);
   }
-  __syncthreads();                                                           // X and the weight buffers are dead: LDS becomes the staging slab
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                                           // residual slab complete; weight buffers dead
 
   // ---- epilogue: + residual -> 16 bit, whole-row stores, GroupNorm column sums (the shared GEMM epilogue) ----
   GemmArgs g{};
@@ -246,13 +294,16 @@ k_ffn320(const FfnArgs a) {
   const bool res_lds = true;
   const int CW = BN * 2;
   const bool lean = true, lean_gelu = false, lean_gate = false;
-  const __amdgpu_buffer_rsrc_t rs_res = make_rsrc(a.residual, g.res_bytes);
   constexpr int PASSES = 1, WM_PER_PASS = WGM / PASSES, ROWS_PER_PASS = 64 * WM_PER_PASS;
   static_assert(BM * CW_PAD <= NSTAGE * STAGE - 8 * BN * 8, "staged tile and the column-sum scratch must fit the LDS");
+#define SDN_EPI_RES_PRELOADED
 #define SDN_PASS 0
 #include "sdn_gemm_epilogue.inc"
 #undef SDN_PASS
-  (void)WGM; (void)lean_gelu; (void)lean_gate; (void)staged; (void)CW_PAD; (void)KT2;
+#undef SDN_EPI_RES_PRELOADED
+  SDN_FTS_MARK(7)                                                           // trailing k-tiles + epilogue
+  SDN_FTS_FLUSH
+  (void)NWAVES; (void)WGM; (void)lean_gelu; (void)lean_gate; (void)staged; (void)CW_PAD; (void)KT2;
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
@@ -260,6 +311,9 @@ k_ffn320(const FfnArgs a) {
 using namespace sdn_gemm_detail;
 
 // C must be 320 (the instantiated width: SD-v1.4's 64 x 64 level); other widths keep the two-launch path.
+#ifdef SDN_FFN_STAMPS
+extern "C" int sdn_debug_set_ffn_stamps(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(sdn_gemm_detail::g_ffn_stamps), &p, sizeof(p)); }
+#endif
 extern "C" int sdn_ffn_geglu_fused(int32_t dtype, int64_t M, int32_t C, const void* x, const float* row_stats, const void* w1_folded, const float* c1,
                         const float* d1, const void* w_cat, const float* b_cat, const void* residual, void* out, float* col_stats,
                         void* stream) {
