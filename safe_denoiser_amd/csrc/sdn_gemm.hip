@@ -382,7 +382,7 @@ k_splitk_reduce(const float* __restrict__ part, int splits, long slice, int M, i
 // is long enough for a slice to amortise its prologue; the plan builder sizes the partial buffer from this.
 int sdn_gemm_pick_split(int M, int N, int K, int act, int out_kind) {
   if (out_kind != SDN_OUT_BF16 || act == SDN_ACT_GEGLU || (N & 3)) return 1;
-  const int nrep = sdn_gemm_pick_tile(M, N, K, act);
+  const int nrep = sdn_gemm_pick_tile(M, N, K, act, 0);
   const int bm = nrep >= 8 ? 256 : 128;
   const long tiles = (long)((M + bm - 1) / bm) * (N / (32 * nrep));
   const int nk = K / 64;
@@ -407,6 +407,7 @@ template <typename T>
 int dispatch_dma(int nrep, const GemmArgs& g, hipStream_t st) {
   if (g.ln_c && g.ln_stats) {                                // LayerNorm-folded form, row statistics from the pre-pass
     switch (nrep) {
+      case 10: return launch_dma<T, 10, 4, 2, 2>(g, st);
       case 5: return launch_dma<T, 5, 2, 2, 2>(g, st);
       case 4: return launch_dma<T, 4, 2, 2, 2>(g, st);
       case 2: return launch_dma<T, 2, 2, 2, 2>(g, st);
@@ -415,6 +416,7 @@ int dispatch_dma(int nrep, const GemmArgs& g, hipStream_t st) {
   }
   if (g.ln_c) {                                              // ... statistics from the A fragments (narrow N)
     switch (nrep) {
+      case 10: return launch_dma<T, 10, 4, 2, 1>(g, st);
       case 5: return launch_dma<T, 5, 2, 2, 1>(g, st);
       case 2: return launch_dma<T, 2, 2, 2, 1>(g, st);
       default: return SDN_E_INVALID;
@@ -454,16 +456,21 @@ extern "C" void sdn_debug_set_gemm_stamps(void* p) { g_gemm_stamps = (unsigned l
 
 // Tile choice with the grid in mind: when the widest tile leaves the 256 CUs (x2 resident blocks) underfilled
 // (the 8x8 / 16x16 levels at small batch), fall back to BN = 64 to multiply the number of workgroups.
-int sdn_gemm_pick_tile(int M, int N, int K, int act) {
+int sdn_gemm_pick_tile(int M, int N, int K, int act, int epilogue_reads) {
   int nrep = sdn_gemm_pick_nrep(N, act);
   if (g_gemm_variant == 2) return nrep;                      // debug: heuristics off
   // big tile (256 rows, 8 waves, 1 block/CU) when it still fills the chip: >= ~3/4 of the 256 CUs get a tile
   if (g_gemm_variant != 3) {
     const int big = (N % 320 == 0) ? 10 : ((N % 256 == 0) ? 8 : 0);
-    // ... and only for long k loops: with one block per CU nothing hides a tile's prologue/epilogue, so short-K
-    // projections (K = 320 .. 1280) stay on the 2-blocks-per-CU tile (measured: tools/bench_gemm.py, VARIANTS=0,3)
+    // Round 1 kept short k loops (K = 320 .. 1280) on the 2-blocks-per-CU tile: with one block per CU nothing hides a tile's
+    // epilogue, and that epilogue was then as long as the k loop.  After the lean epilogues and the cheaper GELU the picture
+    // (tools/bench_gemm.py, round 2, B = 128) is: the big tile WINS 17-30 % on every short-K shape whose epilogue only computes
+    // and stores (qkv, proj_in, GEGLU at K >= 640: half the L2 -> LDS bytes per FLOP) and LOSES 5-17 % where the epilogue has
+    // to fetch a residual tile first (two staging passes, each an exposed HBM round trip) -- those stay on the small tile
+    // until the k loop is long enough to amortise it.
     const bool long_k = K >= 2048 || (K >= 1280 && act == SDN_ACT_GEGLU) || (K >= 1536 && (act == SDN_ACT_NONE || act == SDN_ACT_GELU_TANH));
-    if (big && long_k) {
+    const bool short_ok = !epilogue_reads && K >= 320 && g_gemm_variant != 9;   // variant 9: round-1 rule (A/B)
+    if (big && (long_k || short_ok)) {
       const long tiles = (long)((M + 255) / 256) * (N / (32 * big));
       if (tiles >= 192) return big;
     }
@@ -483,7 +490,7 @@ static int sdn_gemm_impl(int dtype, const sdn_gemm_desc* d, const void* a, const
   const int n_valid = d->n_valid > 0 ? d->n_valid : d->N;
   if (n_valid > d->N) return SDN_E_INVALID;
   if (sdn_gemm_pick_nrep(d->N, d->act) == 0) return SDN_E_INVALID;
-  const int nrep = sdn_gemm_pick_tile(d->M, d->N, d->K, d->act);
+  const int nrep = sdn_gemm_pick_tile(d->M, d->N, d->K, d->act, (residual || rowgate) ? 1 : 0);
   if (!al16(a) || !al16(w) || (a2 && !al16(a2)) || (residual && (reinterpret_cast<uintptr_t>(residual) & 7)) ||
       (reinterpret_cast<uintptr_t>(out) & 7) || (bias && !al16(bias)) || (rowbias && !al16(rowbias)))
     return SDN_E_INVALID;
@@ -537,7 +544,7 @@ static int sdn_gemm_impl(int dtype, const sdn_gemm_desc* d, const void* a, const
     if (!ln_c || !ln_d || !al16(ln_c) || !al16(ln_d) || d->a_mode != SDN_A_PLAIN || g.K1 != d->K || bias || rowbias || rowgate ||
         residual || d->out_kind != SDN_OUT_BF16 || n_valid != d->N || d->split_k > 1 ||
         (d->act != SDN_ACT_NONE && d->act != SDN_ACT_GEGLU) || (ln_stats && (reinterpret_cast<uintptr_t>(ln_stats) & 7)) ||
-        (ln_stats ? (nrep != 5 && nrep != 4 && nrep != 2) : (nrep != 5 && nrep != 2)))
+        (ln_stats ? (nrep != 10 && nrep != 5 && nrep != 4 && nrep != 2) : (nrep != 10 && nrep != 5 && nrep != 2)))
       return SDN_E_INVALID;
     g.ln_c = ln_c; g.ln_d = ln_d; g.ln_eps = ln_eps; g.ln_stats = ln_stats;
   }

@@ -4,7 +4,8 @@
 
 int sdn_gemm_pick_nrep(int n_padded, int act);
 // NREP actually launched for this shape (10 / 8 = the 256-row, 8-wave tile; 5 / 4 / 2 / 1 = the 128-row tile).
-int sdn_gemm_pick_tile(int M, int N, int K, int act);
+// epilogue_reads: the epilogue fetches a residual tile / row gates (keeps short k loops on the 2-blocks-per-CU tile).
+int sdn_gemm_pick_tile(int M, int N, int K, int act, int epilogue_reads = 0);
 
 // graph mode of the plan runner: the step's timestep lives in device memory so that a captured forward can be replayed
 int sdn_temb_from_device(int dtype, const float* t_dev, int batch, int dim, void* out, void* stream);

@@ -240,7 +240,7 @@ struct Builder {
     o.a = a; o.a2 = a2; o.w = w; o.bias = bias; o.rowbias = rowbias; o.residual = residual; o.out = out;
     o.flops = 2.0 * (double)M * (double)(n_valid > 0 ? n_valid : N) * (double)K;
     o.bytes = 2.0 * ((double)M * K + (double)N * K + (double)M * (act_ == SDN_ACT_GEGLU ? N / 2 : N));
-    snprintf(o.label, sizeof(o.label), "k_gemm<%d>", sdn_gemm_pick_tile((int)M, N, K, act_));
+    snprintf(o.label, sizeof(o.label), "k_gemm<%d>", sdn_gemm_pick_tile((int)M, N, K, act_, residual.space != SP_NONE));
     push_gemm(o);
   }
   // Small-M / long-K GEMMs (one-prompt batches) run in split-K form: the partial buffer lives only for this op.
@@ -549,7 +549,7 @@ struct Builder {
     o.a = a; o.w = w; o.bias = bias; o.rowbias = rowbias; o.rowgate = rowgate; o.residual = residual; o.out = out;
     o.flops = 2.0 * (double)M * N * K;
     o.bytes = 2.0 * ((double)M * K + (double)N * K + (double)M * N);
-    snprintf(o.label, sizeof(o.label), "k_gemm<%d>", sdn_gemm_pick_tile((int)M, N, K, act_));
+    snprintf(o.label, sizeof(o.label), "k_gemm<%d>", sdn_gemm_pick_tile((int)M, N, K, act_, residual.space != SP_NONE || rowgate.space != SP_NONE));
     push_gemm(o);
   }
   void ln_mod(const Act& x, int64_t rows, int rows_per_batch, Ref scale, Ref shift, int ld, const Act& out) {

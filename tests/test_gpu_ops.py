@@ -482,3 +482,46 @@ def test_fused_geglu_feed_forward_is_bit_identical_to_the_two_launches(dt, M):
     rc = sda.lib().sdn_ffn_geglu_fused(0, 128, 640, x.data_ptr(), cs_a.data_ptr(), w1i.data_ptr(), b1i.data_ptr(), b1i.data_ptr(),
                                        wcat.data_ptr(), bcat.data_ptr(), res.data_ptr(), got.data_ptr(), None, None)
     assert rc == sda.SDN_E_INVALID if hasattr(sda, "SDN_E_INVALID") else rc != 0
+
+
+# ------------------------------------------------------------------------------------------ tile choice for short k loops
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_big_tile_on_short_k_projections_gives_the_small_tile_bits(dt):
+    """Round 2 moved the short-K projections whose epilogue only computes and stores (qkv, proj_in, GEGLU, LayerNorm-folded
+    forms) onto the 256 x 320 tile (sdn_gemm_pick_tile; variant 9 = the round-1 rule).  The tile must not change a single bit
+    (same k order per output element), whatever the epilogue: plain, bias, LayerNorm fold with fragment or pre-pass statistics,
+    GEGLU; a residual keeps the small tile either way.  Also checked against fp32 arithmetic."""
+    from safe_denoiser_amd.unet import _interleave16
+    g = torch.Generator().manual_seed(21)
+    t = lambda *s, scale=1.0: (torch.randn(*s, generator=g) * scale).to(dt).cuda()
+    M = 256 * 70 + 19                                                # 71 row tiles of 256, ragged tail
+    a3, a6 = t(M, 320), t(M, 640)
+    gam3 = (1 + 0.2 * torch.randn(320, generator=g)).cuda(); bet3 = (0.3 * torch.randn(320, generator=g)).cuda()
+    gam6 = (1 + 0.2 * torch.randn(640, generator=g)).cuda(); bet6 = (0.3 * torch.randn(640, generator=g)).cuda()
+    w960, b960 = t(960, 320, scale=320 ** -0.5), torch.randn(960, generator=g).cuda()
+    w1920, b1920 = t(1920, 640, scale=640 ** -0.5), torch.randn(1920, generator=g).cuda()
+    wg = _interleave16(t(2560, 320, scale=320 ** -0.5)).contiguous(); bg = _interleave16(torch.randn(2560, generator=g).cuda()).contiguous()
+    wg6 = _interleave16(t(5120, 640, scale=640 ** -0.5)).contiguous(); bg6 = _interleave16(torch.randn(5120, generator=g).cuda()).contiguous()
+    res = t(M, 960)
+    cases = [("qkv 320 plain", lambda: ops.gemm(a3, w960, bias=b960)),
+             ("qkv 320 LN fold, fragment statistics", lambda: ops.gemm_ln(a3, w960, gam3, bet3, b960, prepass=False)),
+             ("qkv 640 LN fold, pre-pass statistics", lambda: ops.gemm_ln(a6, w1920, gam6, bet6, b1920, prepass=True)),
+             ("GEGLU 320 LN fold", lambda: ops.gemm_ln(a3, wg, gam3, bet3, bg, act=2, prepass=True)),
+             ("GEGLU 640", lambda: ops.gemm(a6, wg6, bias=bg6, act=2)),
+             ("qkv 320 + residual (small tile either way)", lambda: ops.gemm(a3, w960, bias=b960, residual=res))]
+    try:
+        for name, fn in cases:
+            _variant(9); want = fn(); torch.cuda.synchronize()
+            _variant(0); got = fn(); torch.cuda.synchronize()
+            assert torch.isfinite(got.float()).all(), name
+            assert torch.equal(got.view(torch.int16), want.view(torch.int16)), (name, float((got.float() - want.float()).abs().max()))
+    finally:
+        _variant(0)
+    ref = (a3.float() @ w960.float().T + b960).cpu()
+    assert rel_l2(ops.gemm(a3, w960, bias=b960), ref) <= (4e-3 if dt == torch.bfloat16 else 6e-4)
+    y = F.linear(F.layer_norm(a6.float().cpu(), (640,), gam6.cpu(), bet6.cpu(), 1e-5), w1920.float().cpu(), b1920.cpu())
+    assert rel_l2(ops.gemm_ln(a6, w1920, gam6, bet6, b1920, prepass=True), y) <= (6e-3 if dt == torch.bfloat16 else 8e-4)
+
+
+def _variant(v):
+    sda.lib().sdn_debug_set_gemm_variant(int(v))
