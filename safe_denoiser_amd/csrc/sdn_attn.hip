@@ -84,7 +84,11 @@ __device__ __forceinline__ const unsigned short* row_ptr(const unsigned short* p
 
 // MASK (CLIP text encoder): causal mask (key <= query) and an optional per-sample key-padding mask; a separate
 // instantiation so that the UNet / MMDiT kernels carry no trace of it.
-template <typename T, int HD, bool SEG, bool MASK = false, bool DMA = !SEG>
+// QS = query sets per wave (32 queries each).  QS = 2 (d = 40 self-attention): every K / V fragment read from LDS feeds TWO
+// MFMAs, halving the LDS bytes per FLOP, and the softmax VALU of one set can issue under the MFMAs of the other inside ONE
+// wave -- the d = 40 loop is bound by vector issue + LDS + matrix pipe all at ~60 %, at a clock the chip holds
+// down; less LDS traffic per MFMA is the lever that raises it.  Costs registers: 2 waves per SIMD instead of 4.
+template <typename T, int HD, bool SEG, bool MASK = false, bool DMA = !SEG, int QS = 1>
 __global__ void __launch_bounds__(THREADS)
 k_attn(const AttnArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -142,8 +146,10 @@ k_attn(const AttnArgs a) {
     }
   }
   const int head = pair % a.heads, b = pair / a.heads;
-  const int q0 = qblk * QB + wid * 32;
-  const bool qvalid = q0 + r < a.nq;             // per lane: the query tail (nq % 32 != 0) is clamped, not stored
+  const int q0 = qblk * (QB * QS) + wid * (32 * QS);
+  bool qvalid[QS];                               // per lane: the query tail (nq % 32 != 0) is clamped, not stored
+#pragma unroll
+  for (int qs = 0; qs < QS; ++qs) qvalid[qs] = q0 + 32 * qs + r < a.nq;
 
   // ---- one-time LDS init: zero the padding columns, plant the ones column (both stages) ----
   if constexpr (DMA) {
@@ -159,13 +165,15 @@ k_attn(const AttnArgs a) {
   }
 
   // ---- Q fragments (B operand: lane (r,h) holds Q[q0+r][16s + 8h .. +8)) ----
-  typename T::v8 qf[KQ];
+  typename T::v8 qf[QS][KQ];
+#pragma unroll
+  for (int qs = 0; qs < QS; ++qs)
 #pragma unroll
   for (int s = 0; s < KQ; ++s) {
     const int dc = 16 * s + 8 * h;
     u32x4 v = (u32x4){0u, 0u, 0u, 0u};
-    if (qvalid && dc < HD)
-      v = *reinterpret_cast<const u32x4*>(row_ptr<SEG>(a.q, a.q2, a.ldq, a.ldq2, a.n1, a.nq, b, q0 + r) + head * HD + dc);
+    if (qvalid[qs] && dc < HD)
+      v = *reinterpret_cast<const u32x4*>(row_ptr<SEG>(a.q, a.q2, a.ldq, a.ldq2, a.n1, a.nq, b, q0 + 32 * qs + r) + head * HD + dc);
     // fold scale * log2(e) into Q once (re-rounded to the storage type): the MFMA then yields scores already in
     // log2 units, and the per-score FMA of the softmax disappears (VALU is this kernel's bound for d = 40)
     if (OFFSET_FREE) {
@@ -174,7 +182,7 @@ k_attn(const AttnArgs a) {
       v.z = T::pack2(T::to_f(v.z & 0xffff) * a.c, T::to_f(v.z >> 16) * a.c);
       v.w = T::pack2(T::to_f(v.w & 0xffff) * a.c, T::to_f(v.w >> 16) * a.c);
     }
-    qf[s] = *reinterpret_cast<typename T::v8*>(&v);
+    qf[qs][s] = *reinterpret_cast<typename T::v8*>(&v);
   }
 
   // ---- register-staged K/V tile loads: chunk e -> (matrix, row, 16-B chunk) ----
@@ -267,13 +275,17 @@ k_attn(const AttnArgs a) {
     }
   };
 
-  f32x16 o[NDB];
+  f32x16 o[QS][NDB];
+  float m_run[QS], l_run[QS];                              // bf16: per-query exponent offset (0 = none); fp16: running max
+  float m_hi[QS];                                          // bf16: running max of the scores (decides re-centring)
 #pragma unroll
-  for (int d = 0; d < NDB; ++d)
+  for (int qs = 0; qs < QS; ++qs) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) o[d][i] = 0.f;
-  float m_run = OFFSET_FREE ? 0.f : -1e30f, l_run = 0.f;   // bf16: per-query exponent offset (0 = none); fp16: running max
-  float m_hi = -1e30f;                                     // bf16: running max of the scores (decides re-centring)
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[qs][d][i] = 0.f;
+    m_run[qs] = OFFSET_FREE ? 0.f : -1e30f; l_run[qs] = 0.f; m_hi[qs] = -1e30f;
+  }
 
   // tr-read lane geometry
   const int gi = lane & 15, gq = gi >> 2, gp = gi & 3, gcol = 16 * ((lane >> 4) & 1);
@@ -301,17 +313,20 @@ k_attn(const AttnArgs a) {
     }
 
     // ---- S^T = K Q^T : two 32-key blocks ----
-    f32x16 st[2];
+    f32x16 st[QS][2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) st[kb][i] = 0.f;
+      for (int qs = 0; qs < QS; ++qs)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st[qs][kb][i] = 0.f;
 #pragma unroll
       for (int s = 0; s < KQ; ++s) {
         const unsigned char* kp = sK + (32 * kb + r) * KSTR + (16 * s + 8 * h) * 2;
         if (DMA && 16 * s + 16 > HD) { if (16 * s + 8 * h >= HD) kp = smem + ZOFF + 16; }   // zero padding of d
         const typename T::v8 kf = *reinterpret_cast<const typename T::v8*>(kp);
-        st[kb] = T::mfma32(kf, qf[s], st[kb]);
+#pragma unroll
+        for (int qs = 0; qs < QS; ++qs) st[qs][kb] = T::mfma32(kf, qf[qs][s], st[qs][kb]);
       }
     }
     if constexpr (MASK) {
@@ -321,9 +336,12 @@ k_attn(const AttnArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int key = k0 + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
-          bool off = key >= a.nk || (a.causal && key > q0 + r);
-          if (!off && a.kmask) off = a.kmask[(long)b * a.nk + key] == 0;
-          if (off) st[kb][i] = -1e30f;
+#pragma unroll
+          for (int qs = 0; qs < QS; ++qs) {
+            bool off = key >= a.nk || (a.causal && key > q0 + 32 * qs + r);
+            if (!off && a.kmask) off = a.kmask[(long)b * a.nk + key] == 0;
+            if (off) st[qs][kb][i] = -1e30f;
+          }
         }
     } else if ((t + 1) * KV > a.nk) {             // ragged last tile (cross-attention: 77 keys)
       const int k0 = t * KV;
@@ -332,14 +350,19 @@ k_attn(const AttnArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int key = k0 + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
-          if (key >= a.nk) st[kb][i] = -1e30f;
+          if (key >= a.nk) {
+#pragma unroll
+            for (int qs = 0; qs < QS; ++qs) st[qs][kb][i] = -1e30f;
+          }
         }
     }
     // ---- online softmax: the query is on the lane, its 32 keys of this tile are in st[0], st[1] ----
     SDN_ATS_MARK(0)                               // DMA issue + K reads + S MFMAs issued
-    float mx = fmaxf(st[0][0], st[1][0]);
 #pragma unroll
-    for (int i = 1; i < 16; ++i) mx = fmaxf(fmaxf(mx, st[0][i]), st[1][i]);
+    for (int qs = 0; qs < QS; ++qs) {
+    float mx = fmaxf(st[qs][0][0], st[qs][1][0]);
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mx = fmaxf(fmaxf(mx, st[qs][0][i]), st[qs][1][i]);
     {
       const unsigned u = __float_as_uint(mx);
       const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // both halves of the same query
@@ -351,73 +374,78 @@ k_attn(const AttnArgs a) {
     // common case needs NO subtraction and NO rescale of O -- softmax is invariant to the offset, the result is exact.
     // A tile whose maximum leaves the window re-centres that query's offset (O and the row sum are rescaled once).
     constexpr float kGuard = 64.f;
-    m_hi = fmaxf(m_hi, mx);                                    // running maximum of the scores seen so far
-    const float drift = m_hi - m_run;                          // m_run holds the current offset (0 until re-centred)
+    m_hi[qs] = fmaxf(m_hi[qs], mx);                                    // running maximum of the scores seen so far
+    const float drift = m_hi[qs] - m_run[qs];                          // m_run[qs] holds the current offset (0 until re-centred)
     if (__builtin_amdgcn_ballot_w64(fabsf(drift) > kGuard) != 0) {       // wave-uniform, rare
-      // upward: the old sums shrink by 2^-(>64).  Downward can only happen on the first tile (m_hi never decreases),
+      // upward: the old sums shrink by 2^-(>64).  Downward can only happen on the first tile (m_hi[qs] never decreases),
       // when the sums are still zero -- the exponent is clamped so that 0 * alpha stays 0 instead of 0 * inf.
-      const float m_new = fabsf(drift) > kGuard ? m_hi : m_run;
-      const float alpha = __builtin_amdgcn_exp2f(fminf(m_run - m_new, 126.f));
-      if (!ONES) l_run *= alpha;
+      const float m_new = fabsf(drift) > kGuard ? m_hi[qs] : m_run[qs];
+      const float alpha = __builtin_amdgcn_exp2f(fminf(m_run[qs] - m_new, 126.f));
+      if (!ONES) l_run[qs] *= alpha;
 #pragma unroll
       for (int d = 0; d < NDB; ++d)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
-      m_run = m_new;
+        for (int i = 0; i < 16; ++i) o[qs][d][i] *= alpha;
+      m_run[qs] = m_new;
     }
-    if (__builtin_amdgcn_ballot_w64(m_run != 0.f) != 0) {                 // some query of this wave has an offset
+    if (__builtin_amdgcn_ballot_w64(m_run[qs] != 0.f) != 0) {                 // some query of this wave has an offset
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) st[kb][i] = __builtin_amdgcn_exp2f(st[kb][i] - m_run);
+        for (int i = 0; i < 16; ++i) st[qs][kb][i] = __builtin_amdgcn_exp2f(st[qs][kb][i] - m_run[qs]);
     } else {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) st[kb][i] = __builtin_amdgcn_exp2f(st[kb][i]);
+        for (int i = 0; i < 16; ++i) st[qs][kb][i] = __builtin_amdgcn_exp2f(st[qs][kb][i]);
     }
     if (!ONES) {
       float ps = 0.f;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) ps += st[0][i] + st[1][i];
-      l_run += ps;
+      for (int i = 0; i < 16; ++i) ps += st[qs][0][i] + st[qs][1][i];
+      l_run[qs] += ps;
     }
     } else {                                          // fp16: classic running-max form (fp16 P needs p <= 1)
-    const float m_new = fmaxf(m_run, mx);
+    const float m_new = fmaxf(m_run[qs], mx);
     const float mc = m_new * a.c;
-    if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {              // wave-uniform: rescale only when needed
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * a.c);
-      if (!ONES) l_run *= alpha;
+    if (__builtin_amdgcn_ballot_w64(m_new != m_run[qs]) != 0) {              // wave-uniform: rescale only when needed
+      const float alpha = __builtin_amdgcn_exp2f((m_run[qs] - m_new) * a.c);
+      if (!ONES) l_run[qs] *= alpha;
 #pragma unroll
       for (int d = 0; d < NDB; ++d)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
-      m_run = m_new;
+        for (int i = 0; i < 16; ++i) o[qs][d][i] *= alpha;
+      m_run[qs] = m_new;
     }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) st[kb][i] = __builtin_amdgcn_exp2f(fmaf(st[kb][i], a.c, -mc));
+      for (int i = 0; i < 16; ++i) st[qs][kb][i] = __builtin_amdgcn_exp2f(fmaf(st[qs][kb][i], a.c, -mc));
     if (!ONES) {
       float ps = 0.f;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) ps += st[0][i] + st[1][i];
-      l_run += ps;
+      for (int i = 0; i < 16; ++i) ps += st[qs][0][i] + st[qs][1][i];
+      l_run[qs] += ps;
     }
     }
 
+    }  // query sets
     SDN_ATS_MARK(1)                               // max, exp (waits for the S MFMAs)
     // ---- O^T += V^T P^T ----
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        u32x4 pw;
-        pw.x = T::pack2(st[kb][8 * s2 + 0], st[kb][8 * s2 + 1]);
-        pw.y = T::pack2(st[kb][8 * s2 + 2], st[kb][8 * s2 + 3]);
-        pw.z = T::pack2(st[kb][8 * s2 + 4], st[kb][8 * s2 + 5]);
-        pw.w = T::pack2(st[kb][8 * s2 + 6], st[kb][8 * s2 + 7]);
-        const typename T::v8 pf = *reinterpret_cast<typename T::v8*>(&pw);
+        typename T::v8 pf[QS];
+#pragma unroll
+        for (int qs = 0; qs < QS; ++qs) {
+          u32x4 pw;
+          pw.x = T::pack2(st[qs][kb][8 * s2 + 0], st[qs][kb][8 * s2 + 1]);
+          pw.y = T::pack2(st[qs][kb][8 * s2 + 2], st[qs][kb][8 * s2 + 3]);
+          pw.z = T::pack2(st[qs][kb][8 * s2 + 4], st[qs][kb][8 * s2 + 5]);
+          pw.w = T::pack2(st[qs][kb][8 * s2 + 6], st[qs][kb][8 * s2 + 7]);
+          pf[qs] = *reinterpret_cast<typename T::v8*>(&pw);
+        }
         const int keyb = 32 * kb + 16 * s2 + 4 * h + gq;
 #pragma unroll
         for (int d = 0; d < NDB; ++d) {
@@ -430,7 +458,8 @@ k_attn(const AttnArgs a) {
           union { s16x4 hlf[2]; typename T::v8 full; } vf;
           vf.hlf[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pa));
           vf.hlf[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pb));
-          o[d] = T::mfma32(vf.full, pf, o[d]);
+#pragma unroll
+          for (int qs = 0; qs < QS; ++qs) o[qs][d] = T::mfma32(vf.full, pf[qs], o[qs][d]);
         }
       }
 
@@ -445,18 +474,20 @@ k_attn(const AttnArgs a) {
     SDN_ATS_MARK(4)                               // barrier
   }
   // ---- epilogue: normalise by the row sum ----
+#pragma unroll
+  for (int qs = 0; qs < QS; ++qs) {
   float l_tot;
   if (ONES) {
     constexpr int row = HD % 32;                  // row of the last O^T block that accumulated sum_k p
     constexpr int ri = (row >> 3) * 4 + (row & 3);
     static_assert(((row >> 2) & 1) == 0, "ones row must live in lane half 0");
-    l_tot = __shfl(o[NDB - 1][ri], r, 64);        // lane r (half 0) holds it for query r
+    l_tot = __shfl(o[qs][NDB - 1][ri], r, 64);        // lane r (half 0) holds it for query r
   } else {
-    l_tot = l_run + __shfl_xor(l_run, 32, 64);    // both halves hold partial sums of the same query
+    l_tot = l_run[qs] + __shfl_xor(l_run[qs], 32, 64);    // both halves hold partial sums of the same query
   }
   const float inv = 1.f / l_tot;
-  if (qvalid) {
-    unsigned short* orow = const_cast<unsigned short*>(row_ptr<SEG>(a.out, a.out2, a.ldo, a.ldo2, a.n1, a.nq, b, q0 + r)) + head * HD;
+  if (qvalid[qs]) {
+    unsigned short* orow = const_cast<unsigned short*>(row_ptr<SEG>(a.out, a.out2, a.ldo, a.ldo2, a.n1, a.nq, b, q0 + 32 * qs + r)) + head * HD;
 #pragma unroll
     for (int d = 0; d < NDB; ++d)
 #pragma unroll
@@ -464,16 +495,19 @@ k_attn(const AttnArgs a) {
         const int dc = 32 * d + 8 * tq + 4 * h;
         if (dc < HD) {
           uint2 pk;
-          pk.x = T::pack2(o[d][4 * tq + 0] * inv, o[d][4 * tq + 1] * inv);
-          pk.y = T::pack2(o[d][4 * tq + 2] * inv, o[d][4 * tq + 3] * inv);
+          pk.x = T::pack2(o[qs][d][4 * tq + 0] * inv, o[qs][d][4 * tq + 1] * inv);
+          pk.y = T::pack2(o[qs][d][4 * tq + 2] * inv, o[qs][d][4 * tq + 3] * inv);
           *reinterpret_cast<uint2*>(orow + dc) = pk;
         }
       }
+  }
   }
   SDN_ATS_MARK(6)                                 // epilogue: normalise + store
   SDN_ATS_FLUSH
 #endif  // __HIP_DEVICE_COMPILE__
 }
+
+static int g_attn_qs2 = 1;           // debug A/B switch (sdn_debug_set_attn_qs2)
 
 template <typename T, int HD>
 int launch(const AttnArgs& a, int batch, int heads, hipStream_t st) {
@@ -495,6 +529,15 @@ int launch(const AttnArgs& a, int batch, int heads, hipStream_t st) {
     }
     hipLaunchKernelGGL((k_attn<T, HD, true>), dim3(a.nqb * a.npairs), dim3(THREADS), 0, st, a);
   } else {
+    if constexpr (HD == 40) {
+      // long key sets at d = 40 (the 64 x 64 self-attention, 15 % of the forward): two query sets per wave (see QS)
+      if (a.nk > 2 * KV && a.nq >= 2 * QB && g_attn_qs2) {
+        AttnArgs a2 = a;
+        a2.nqb = (a.nq + 2 * QB - 1) / (2 * QB);
+        hipLaunchKernelGGL((k_attn<T, HD, false, false, true, 2>), dim3(a2.nqb * a2.npairs), dim3(THREADS), 0, st, a2);
+        return sdn_launch_status();
+      }
+    }
     hipLaunchKernelGGL((k_attn<T, HD, false>), dim3(a.nqb * a.npairs), dim3(THREADS), 0, st, a);
   }
   return sdn_launch_status();
@@ -543,6 +586,7 @@ extern "C" int sdn_debug_set_attn_stamps(void* p) {
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(sdn_attn_detail::g_attn_stamps), &p, sizeof(p));
 }
 #endif
+extern "C" void sdn_debug_set_attn_qs2(int on) { sdn_attn_detail::g_attn_qs2 = on; }
 extern "C" int sdn_attention_bf16(const void* q, const void* k, const void* v, void* out, int32_t batch,
                                   int32_t heads, int32_t nq, int32_t nk, int32_t head_dim, int32_t ldq,
                                   int32_t ldk, int32_t ldv, int32_t ldo, float scale, void* stream) {

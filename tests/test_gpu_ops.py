@@ -290,7 +290,7 @@ def test_layernorm(rows, C):
 # ------------------------------------------------------------------------------------------ attention
 @pytest.mark.parametrize("B,H,Nq,Nk,d", [(2, 8, 256, 256, 40), (1, 8, 1024, 1024, 80), (2, 8, 64, 64, 160),
                                          (2, 8, 256, 77, 40), (1, 8, 64, 77, 160), (1, 4, 128, 200, 64),
-                                         (1, 8, 4096, 4096, 40),
+                                         (1, 8, 4096, 4096, 40), (1, 8, 300, 300, 40),   # d = 40, long keys: two query sets per wave (+ ragged tails)
                                          (8, 8, 300, 77, 40), (16, 8, 128, 77, 80)])   # batch % 8 == 0, short keys: head-innermost block order
 def test_attention_vs_sdpa(B, H, Nq, Nk, d):
     q, k, v = rnd(B, Nq, H * d, seed=28), rnd(B, Nk, H * d, seed=29), rnd(B, Nk, H * d, seed=30)
