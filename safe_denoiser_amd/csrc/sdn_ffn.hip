@@ -175,10 +175,12 @@ k_ffn320(const FfnArgs a) {
         for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const typename T::v8*>(sa + lds_off(i * 16 + fr, ks * 4 + fq));
 #pragma unroll
         for (int j = 0; j < 2; ++j) fw[j] = *reinterpret_cast<const typename T::v8*>(sw + lds_off(j * 16 + fr, ks * 4 + fq));
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc1[i][j] = T::mfma16(fw[j], fa[i], acc1[i][j]);
+        __builtin_amdgcn_s_setprio(0);
       }
       // the ring k-tile (and every older request) has landed; this iteration's W2 slice may still be in flight
       SDN_FTS_MARK(1)                                                        // projection: DMA issue + fragment reads + MFMAs issued
@@ -215,10 +217,12 @@ k_ffn320(const FfnArgs a) {
         for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const typename T::v8*>(sa + lds_off(i * 16 + fr, ks * 4 + fq));
 #pragma unroll
         for (int j = 0; j < NREP; ++j) fw[j] = *reinterpret_cast<const typename T::v8*>(sw + lds_off(j * 16 + fr, ks * 4 + fq));
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < NREP; ++j) acc[i][j] = T::mfma16(fw[j], fa[i], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
       }
     }
     SDN_FTS_MARK(6)                                                          // contraction: fragment reads + MFMAs issued
@@ -265,10 +269,12 @@ k_ffn320(const FfnArgs a) {
         for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const typename T::v8*>(sa + lds_off(i * 16 + fr, ks * 4 + fq));
 #pragma unroll
         for (int j = 0; j < NREP; ++j) fw[j] = *reinterpret_cast<const typename T::v8*>(sw + lds_off(j * 16 + fr, ks * 4 + fq));
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < NREP; ++j) acc[i][j] = T::mfma16(fw[j], fa[i], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

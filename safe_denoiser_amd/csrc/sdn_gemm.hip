@@ -279,8 +279,10 @@ k_gemm_dma(const GemmArgs g) {
           _Pragma("unroll") for (int j = 0; j < JC; ++j)                                                               \
             acc[i][(J0) + j] = T::mfma16(fw[j], fa[i], acc[i][(J0) + j]);                                              \
       }
-      SDN_MMA_PART(0)
+      __builtin_amdgcn_s_setprio(1);                        // the wave that has its fragments issues MFMAs ahead of its SIMD
+      SDN_MMA_PART(0)                                        // partner's DMA / fragment-read stream (+0.3 ... 1.1 % on every shape)
       if constexpr (NREP > JC) SDN_MMA_PART(JC)
+      __builtin_amdgcn_s_setprio(0);
 #undef SDN_MMA_PART
     }
     if constexpr (NSTAGE == 2) {
