@@ -314,6 +314,7 @@ k_attn(const AttnArgs a) {
 
     // ---- S^T = K Q^T : two 32-key blocks ----
     f32x16 st[QS][2];
+    __builtin_amdgcn_s_setprio(1);                // (MFMA clusters issue ahead of the SIMD's other waves: +3-4 % at d = 80, neutral at d = 40)
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
@@ -329,6 +330,7 @@ k_attn(const AttnArgs a) {
         for (int qs = 0; qs < QS; ++qs) st[qs][kb] = T::mfma32(kf, qf[qs][s], st[qs][kb]);
       }
     }
+    __builtin_amdgcn_s_setprio(0);
     if constexpr (MASK) {
       const int k0 = t * KV;
 #pragma unroll
@@ -432,6 +434,7 @@ k_attn(const AttnArgs a) {
     }  // query sets
     SDN_ATS_MARK(1)                               // max, exp (waits for the S MFMAs)
     // ---- O^T += V^T P^T ----
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -463,6 +466,7 @@ k_attn(const AttnArgs a) {
         }
       }
 
+    __builtin_amdgcn_s_setprio(0);
     SDN_ATS_MARK(2)                               // pack, V tr reads, PV MFMAs issued
     if constexpr (DMA) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // next tile landed; the barrier publishes it
