@@ -256,7 +256,15 @@ k_gemm_dma(const GemmArgs g) {
   }
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & (NSTAGE - 1);
-    if (kt + NSTAGE - 1 < nk && !(g.dbg & 2)) issue((kt + NSTAGE - 1) & (NSTAGE - 1));
+    // WHERE the next k-tile's DMA is issued.  At the top of the iteration both waves of a SIMD come out of the barrier and spend
+    // their first ~1 k cycles issuing 9 DMA pieces each (100-185 cycles apiece next to fragment reads; the conv form adds a
+    // halo select per piece) with the matrix pipe idle.  On the 256-row tile the pieces go out BEHIND MFMAs already in the
+    // pipe instead: after the first half of the first k-step's MFMAs (plain A: +3...9 % on the K = 640...2560 shapes, neutral
+    // at K = 320) or after the whole first k-step (3x3 conv: +7...9 %; tools/bench_gemm.py VARIANTS=0,64,128,192 sweeps the
+    // four positions).  The 128-row tile (two workgroups per CU cover each other) loses 2-7 % with any late position.
+    const int ipos = (NSTAGE == 2 && WGM == 4 && !(g.dbg & 8)) ? (g.a_mode == 1 ? 2 : 1) : 0;   // dbg 8: top of the iteration (A/B)
+    const bool more = kt + NSTAGE - 1 < nk && !(g.dbg & 2);
+    if (ipos == 0 && more) issue((kt + NSTAGE - 1) & (NSTAGE - 1));
     const unsigned char* sa = smem + buf * STAGE + (wm * 64) * 128;
     const unsigned char* sw = smem + buf * STAGE + BM * 128 + (wn * 16 * NREP) * 128;
 #pragma unroll
@@ -281,9 +289,13 @@ k_gemm_dma(const GemmArgs g) {
       }
       __builtin_amdgcn_s_setprio(1);                        // the wave that has its fragments issues MFMAs ahead of its SIMD
       SDN_MMA_PART(0)                                        // partner's DMA / fragment-read stream (+0.3 ... 1.1 % on every shape)
+      __builtin_amdgcn_s_setprio(0);
+      if (ipos == 1 && ks == 0 && more) issue((kt + 1) & 1);
+      __builtin_amdgcn_s_setprio(1);
       if constexpr (NREP > JC) SDN_MMA_PART(JC)
       __builtin_amdgcn_s_setprio(0);
 #undef SDN_MMA_PART
+      if (ipos == 2 && ks == 0 && more) issue((kt + 1) & 1);
     }
     if constexpr (NSTAGE == 2) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
