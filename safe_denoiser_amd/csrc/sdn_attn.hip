@@ -121,6 +121,8 @@ k_attn(const AttnArgs a) {
   constexpr int NLOAD = (2 * KV * CH + THREADS - 1) / THREADS;   // staged chunks per thread per tile (register staging)
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE + 32];
 
+  // K/V tile DMA of the next tile: at the top of the iteration, or (d = 40: +1.5-3 %; d = 80 / 160 lose 3-6 %) after the QK^T MFMAs
+  constexpr bool kLateDma = HD == 40;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: LDS-DMA bases go to M0
   const int r = lane & 31, h = lane >> 5;
@@ -308,7 +310,7 @@ k_attn(const AttnArgs a) {
     const unsigned char* sK = smem + buf * STAGE;
     const unsigned char* sV = sK + KV * KSTR;
     if (t + 1 < ntiles) {                         // in flight during this tile's MFMAs / softmax (uniform branch)
-      if constexpr (DMA) dma_issue(buf ^ 1, t + 1);   // the other stage: last read before the previous barrier
+      if constexpr (DMA) { if (!kLateDma) dma_issue(buf ^ 1, t + 1); }   // the other stage: last read before the previous barrier
       else g_load(t + 1);
     }
 
@@ -331,6 +333,7 @@ k_attn(const AttnArgs a) {
       }
     }
     __builtin_amdgcn_s_setprio(0);
+    if constexpr (DMA && kLateDma) { if (t + 1 < ntiles) dma_issue(buf ^ 1, t + 1); }   // behind the QK^T MFMAs already in the pipe
     if constexpr (MASK) {
       const int k0 = t * KV;
 #pragma unroll
