@@ -150,7 +150,7 @@ k_gemm_dma(const GemmArgs g) {
   // split-K: this workgroup's slice of the k loop starts at k-tile kt0 (k order of a conv = channel chunk outer, tap inner)
   const int kt0 = g.kt_per_split > 0 ? (int)blockIdx.y * g.kt_per_split : 0;
   int cur_k0 = kt0 * BK, cur_c0 = (kt0 / 9) * BK, cur_ty = (kt0 % 9) / 3, cur_tx = kt0 % 3, w_k0 = 0;
-  auto issue = [&](int buf) {
+  auto issue_aw = [&](int buf, bool with_w) {
     unsigned char* sa = smem + buf * STAGE;
     unsigned char* sw = sa + BM * 128;
     if (g.a_mode == 1) {
@@ -189,6 +189,18 @@ k_gemm_dma(const GemmArgs g) {
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a1, (lds_ptr_t)(sa + (wid * A_PIECES + i) * 1024), 16, a_base[i] + kb, 0, 0, 0);
       }
     }
+    if (!with_w) return;
+#pragma unroll
+    for (int i = 0; i < W_PIECES; ++i) {
+      if (w_ok[i])
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(sw + (wid * W_PIECES + i) * 1024), 16,
+                                                 w_off[i] + (unsigned)((g.a_mode == 1 ? w_k0 : cur_k0) * 2), 0, 0, 0);
+    }
+    cur_k0 += BK;
+  };
+  auto issue = [&](int buf) { issue_aw(buf, true); };
+  auto issue_w_only = [&](int buf) {                        // second half of a split issue (issue_aw(buf, false) came first)
+    unsigned char* sw = smem + buf * STAGE + BM * 128;
 #pragma unroll
     for (int i = 0; i < W_PIECES; ++i) {
       if (w_ok[i])
@@ -259,10 +271,12 @@ k_gemm_dma(const GemmArgs g) {
     // WHERE the next k-tile's DMA is issued.  At the top of the iteration both waves of a SIMD come out of the barrier and spend
     // their first ~1 k cycles issuing 9 DMA pieces each (100-185 cycles apiece next to fragment reads; the conv form adds a
     // halo select per piece) with the matrix pipe idle.  On the 256-row tile the pieces go out BEHIND MFMAs already in the
-    // pipe instead: after the first half of the first k-step's MFMAs (plain A: +3...9 % on the K = 640...2560 shapes, neutral
-    // at K = 320) or after the whole first k-step (3x3 conv: +7...9 %; tools/bench_gemm.py VARIANTS=0,64,128,192 sweeps the
-    // four positions).  The 128-row tile (two workgroups per CU cover each other) loses 2-7 % with any late position.
-    const int ipos = (NSTAGE == 2 && WGM == 4 && !(g.dbg & 8)) ? (g.a_mode == 1 ? 2 : 1) : 0;   // dbg 8: top of the iteration (A/B)
+    // pipe instead: plain A: the A pieces after the first half of the first k-step's MFMAs and the W pieces after its second
+    // half (+3...9 % on the K = 640...2560 shapes over the top-of-iteration placement, +2...4 % more from the split); 3x3 conv:
+    // everything after the whole first k-step (+7...9 %; the split is neutral there).  Later positions lose.  The 128-row tile
+    // (two workgroups per CU cover each other) loses 2-7 % with any late position.  (tools/bench_gemm.py VARIANTS=0,64,128.)
+    const int ipos = (NSTAGE == 2 && WGM == 4 && !(g.dbg & 8)) ? ((g.dbg & 4) ? 1 : (g.a_mode == 1 ? 2 : ((g.act == 2 && g.K >= 1280) ? 1 : 4))) : 0;   // dbg 8: top of the iteration, 4: unsplit (A/B)
+    // (the long-K GEGLU projection of the 16 x 16 level is the one plain shape that prefers the unsplit form: 802 vs 852 us)
     const bool more = kt + NSTAGE - 1 < nk && !(g.dbg & 2);
     if (ipos == 0 && more) issue((kt + NSTAGE - 1) & (NSTAGE - 1));
     const unsigned char* sa = smem + buf * STAGE + (wm * 64) * 128;
@@ -291,11 +305,13 @@ k_gemm_dma(const GemmArgs g) {
       SDN_MMA_PART(0)                                        // partner's DMA / fragment-read stream (+0.3 ... 1.1 % on every shape)
       __builtin_amdgcn_s_setprio(0);
       if (ipos == 1 && ks == 0 && more) issue((kt + 1) & 1);
+      if (ipos == 4 && ks == 0 && more) issue_aw((kt + 1) & 1, false);     // split: A behind the first MFMA half ...
       __builtin_amdgcn_s_setprio(1);
       if constexpr (NREP > JC) SDN_MMA_PART(JC)
       __builtin_amdgcn_s_setprio(0);
 #undef SDN_MMA_PART
       if (ipos == 2 && ks == 0 && more) issue((kt + 1) & 1);
+      if (ipos == 4 && ks == 0 && more) issue_w_only((kt + 1) & 1);        // ... W behind the second
     }
     if constexpr (NSTAGE == 2) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
