@@ -316,6 +316,22 @@ k_attn(const AttnArgs a) {
 
     // ---- S^T = K Q^T : two 32-key blocks ----
     f32x16 st[QS][2];
+    // K fragments.  Left to itself hipcc reuses ONE 4-register fragment: read, wait, two MFMAs, read, wait ... -- every pair of
+    // MFMAs behind a fresh LDS round trip.  With registers to spare (QS = 2: two waves per SIMD) all 2 x KQ fragments are
+    // requested first, in one burst, and the scheduler is fenced from sinking them back.
+    constexpr bool kPreloadK = QS == 2;
+    typename T::v8 kfa[kPreloadK ? 2 : 1][kPreloadK ? KQ : 1];
+    if constexpr (kPreloadK) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s = 0; s < KQ; ++s) {
+          const unsigned char* kp = sK + (32 * kb + r) * KSTR + (16 * s + 8 * h) * 2;
+          if (DMA && 16 * s + 16 > HD) { if (16 * s + 8 * h >= HD) kp = smem + ZOFF + 16; }   // zero padding of d
+          kfa[kb][s] = *reinterpret_cast<const typename T::v8*>(kp);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
     __builtin_amdgcn_s_setprio(1);                // (MFMA clusters issue ahead of the SIMD's other waves: +3-4 % at d = 80, neutral at d = 40)
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -325,9 +341,14 @@ k_attn(const AttnArgs a) {
         for (int i = 0; i < 16; ++i) st[qs][kb][i] = 0.f;
 #pragma unroll
       for (int s = 0; s < KQ; ++s) {
-        const unsigned char* kp = sK + (32 * kb + r) * KSTR + (16 * s + 8 * h) * 2;
-        if (DMA && 16 * s + 16 > HD) { if (16 * s + 8 * h >= HD) kp = smem + ZOFF + 16; }   // zero padding of d
-        const typename T::v8 kf = *reinterpret_cast<const typename T::v8*>(kp);
+        typename T::v8 kf;
+        if constexpr (kPreloadK) {
+          kf = kfa[kb][s];
+        } else {
+          const unsigned char* kp = sK + (32 * kb + r) * KSTR + (16 * s + 8 * h) * 2;
+          if (DMA && 16 * s + 16 > HD) { if (16 * s + 8 * h >= HD) kp = smem + ZOFF + 16; }   // zero padding of d
+          kf = *reinterpret_cast<const typename T::v8*>(kp);
+        }
 #pragma unroll
         for (int qs = 0; qs < QS; ++qs) st[qs][kb] = T::mfma32(kf, qf[qs][s], st[qs][kb]);
       }
