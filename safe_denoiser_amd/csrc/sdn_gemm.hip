@@ -281,6 +281,44 @@ k_gemm_dma(const GemmArgs g) {
     if (ipos == 0 && more) issue((kt + NSTAGE - 1) & (NSTAGE - 1));
     const unsigned char* sa = smem + buf * STAGE + (wm * 64) * 128;
     const unsigned char* sw = smem + buf * STAGE + BM * 128 + (wn * 16 * NREP) * 128;
+#ifdef SDN_NO_FRAG_PIPE
+    constexpr bool kFragPipe = false;                          // A/B build: the compiler's own fragment schedule
+#else
+    constexpr bool kFragPipe = WGM == 4 && NREP == 10 && LNF != 1;
+#endif
+    if constexpr (kFragPipe) {
+      // 256 x 320 tile: the W fragments of a k-step are consumed in 5 groups of 2 (8 MFMAs = 128 matrix-pipe cycles each),
+      // and group g+1's two ds_reads are ISSUED BEFORE group g's MFMAs (two alternating 2-fragment buffers; the second
+      // k-step's A fragments ride along early), so no MFMA group starts behind a fresh LDS round trip.  Left to the
+      // compiler the schedule was "5 reads, wait, 20 MFMAs" four times per k-tile with the pipe draining in each wait.
+      typename T::v8 fa[2][4], fw[2][2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[0][i] = *reinterpret_cast<const typename T::v8*>(sa + lds_off(i * 16 + fr, fq));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fw[0][j] = *reinterpret_cast<const typename T::v8*>(sw + lds_off(j * 16 + fr, fq));
+#pragma unroll
+      for (int gi = 0; gi < 10; ++gi) {
+        const int ks = gi / 5, g = gi % 5;
+        if (gi + 1 < 10) {
+          const int ks1 = (gi + 1) / 5, g1 = (gi + 1) % 5;
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            fw[(gi + 1) & 1][j] = *reinterpret_cast<const typename T::v8*>(sw + lds_off((2 * g1 + j) * 16 + fr, ks1 * 4 + fq));
+        }
+        if (gi == 2) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) fa[1][i] = *reinterpret_cast<const typename T::v8*>(sa + lds_off(i * 16 + fr, 4 + fq));
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][2 * g + j] = T::mfma16(fw[gi & 1][j], fa[ks][i], acc[i][2 * g + j]);
+        __builtin_amdgcn_s_setprio(0);
+        if (gi == 2 && more) { if (ipos == 1) issue((kt + 1) & 1); else if (ipos == 4) issue_aw((kt + 1) & 1, false); }
+        if (gi == 4 && more) { if (ipos == 2) issue((kt + 1) & 1); else if (ipos == 4) issue_w_only((kt + 1) & 1); }
+      }
+    } else {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       constexpr int JC = NREP > 5 ? NREP / 2 : NREP;         // W fragments live at once (register budget of the big tile)
@@ -312,6 +350,7 @@ k_gemm_dma(const GemmArgs g) {
 #undef SDN_MMA_PART
       if (ipos == 2 && ks == 0 && more) issue((kt + 1) & 1);
       if (ipos == 4 && ks == 0 && more) issue_w_only((kt + 1) & 1);        // ... W behind the second
+    }
     }
     if constexpr (NSTAGE == 2) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
