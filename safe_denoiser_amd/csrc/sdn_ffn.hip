@@ -69,6 +69,34 @@ struct FfnArgs {
   int M;
 };
 
+// acc[4][5] += A[64 x 64] . W[80 x 64]^T for one k-tile: the W fragments are consumed in groups of two (2, 2, 1 per k-step) and
+// the next group's ds_reads are issued ahead of the current group's MFMAs (as in the 256 x 320 GEMM tile).
+#define SDN_FFN_CONTRACT(SA, SW)                                                                                           \
+      {                                                                                                                    \
+        typename T::v8 fa[2][4], fw[2][2];                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                      \
+          fa[0][i] = *reinterpret_cast<const typename T::v8*>((SA) + lds_off(i * 16 + fr, fq));                            \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                      \
+          fw[0][j] = *reinterpret_cast<const typename T::v8*>((SW) + lds_off(j * 16 + fr, fq));                            \
+        _Pragma("unroll") for (int gi = 0; gi < 6; ++gi) {                                                                 \
+          const int ks = gi / 3, g = gi % 3, nj = g == 2 ? 1 : 2;                                                          \
+          if (gi + 1 < 6) {                                                                                                \
+            const int ks1 = (gi + 1) / 3, g1 = (gi + 1) % 3, nj1 = g1 == 2 ? 1 : 2;                                        \
+            _Pragma("unroll") for (int j = 0; j < nj1; ++j)                                                                \
+              fw[(gi + 1) & 1][j] = *reinterpret_cast<const typename T::v8*>((SW) + lds_off((2 * g1 + j) * 16 + fr, ks1 * 4 + fq)); \
+          }                                                                                                                \
+          if (gi == 1) {                                                                                                   \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                  \
+              fa[1][i] = *reinterpret_cast<const typename T::v8*>((SA) + lds_off(i * 16 + fr, 4 + fq));                    \
+          }                                                                                                                \
+          __builtin_amdgcn_s_setprio(1);                                                                                   \
+          _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                    \
+            _Pragma("unroll") for (int j = 0; j < nj; ++j)                                                                 \
+              acc[i][2 * g + j] = T::mfma16(fw[gi & 1][j], fa[ks][i], acc[i][2 * g + j]);                                  \
+          __builtin_amdgcn_s_setprio(0);                                                                                   \
+        }                                                                                                                  \
+      }
+
 template <typename T>
 __global__ void __launch_bounds__(512, 1)
 k_ffn320(const FfnArgs a) {
@@ -210,20 +238,7 @@ k_ffn320(const FfnArgs a) {
     {
       const unsigned char* sa = sh + (wm * 64) * 128;
       const unsigned char* sw = smem + OFF_W2A + (wn * 16 * NREP) * 128;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        typename T::v8 fa[4], fw[NREP];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const typename T::v8*>(sa + lds_off(i * 16 + fr, ks * 4 + fq));
-#pragma unroll
-        for (int j = 0; j < NREP; ++j) fw[j] = *reinterpret_cast<const typename T::v8*>(sw + lds_off(j * 16 + fr, ks * 4 + fq));
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < NREP; ++j) acc[i][j] = T::mfma16(fw[j], fa[i], acc[i][j]);
-        __builtin_amdgcn_s_setprio(0);
-      }
+      SDN_FFN_CONTRACT(sa, sw)
     }
     SDN_FTS_MARK(6)                                                          // contraction: fragment reads + MFMAs issued
     __syncthreads();                                                         // H's stage and the W2 buffer are free again
@@ -262,20 +277,7 @@ k_ffn320(const FfnArgs a) {
     {
       const unsigned char* sa = sa_x + kt * XIMG;
       const unsigned char* sw = smem + boff + (wn * 16 * NREP) * 128;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        typename T::v8 fa[4], fw[NREP];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const typename T::v8*>(sa + lds_off(i * 16 + fr, ks * 4 + fq));
-#pragma unroll
-        for (int j = 0; j < NREP; ++j) fw[j] = *reinterpret_cast<const typename T::v8*>(sw + lds_off(j * 16 + fr, ks * 4 + fq));
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < NREP; ++j) acc[i][j] = T::mfma16(fw[j], fa[i], acc[i][j]);
-        __builtin_amdgcn_s_setprio(0);
-      }
+      SDN_FFN_CONTRACT(sa, sw)
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                            // every wave done with this weight buffer and with X image kt
