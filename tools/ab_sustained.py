@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""SUSTAINED A/B of a GEMM debug variant on the UNet forward at B = 128: N forwards back to back per arm (N = 150 is ~16 s), arms
+alternating.  Short interleaved rounds (tools/ab_gemm_variant.py) let a power-limited chip average its clock over both arms; this
+form lets each arm settle.  VARIANT via the loop below (128 = next k-tile's DMA at the top of the iteration).  To compare two
+BUILDS on one box run it twice in one gpurun call, the second time with SDN_LIB=<other libsdn.so>."""
+import os, sys, time, torch
+sys.path.insert(0, os.getcwd())
+import safe_denoiser_amd as sda
+from safe_denoiser_amd.unet import UNet2DConditionModel
+B = 128
+u = UNet2DConditionModel(latent_repeat=2)
+u.load_synthetic_on_device(1234)
+x = torch.randn(B // 2, 4, 64, 64, device="cuda")
+e = u.prepare_text(torch.randn(B, 77, 768, device="cuda"))
+y = torch.empty(B, 4, 64, 64, device="cuda")
+N = int(os.environ.get("N", "150"))
+for rnd in range(3):
+    for v in (0, 128):
+        sda.lib().sdn_debug_set_gemm_variant(v)
+        u._ws = {}
+        u.forward_into(x, 981.0, e, y); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(N): u.forward_into(x, 981.0, e, y)
+        torch.cuda.synchronize()
+        print(f"variant {v:3d}: {N} forwards back to back, {(time.perf_counter() - t0) / N * 1e3:7.2f} ms each", flush=True)
