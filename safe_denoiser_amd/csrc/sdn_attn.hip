@@ -123,6 +123,11 @@ k_attn(const AttnArgs a) {
 
   // K/V tile DMA of the next tile: at the top of the iteration, or (d = 40: +1.5-3 %; d = 80 / 160 lose 3-6 %) after the QK^T MFMAs
   constexpr bool kLateDma = HD == 40;
+#ifdef SDN_ATTN_NO_ASM_TR
+  constexpr bool kAsmTrOn = false;             // A/B build: the builtin tr reads (and the compiler's mid-loop vmcnt(0))
+#else
+  constexpr bool kAsmTrOn = true;
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: LDS-DMA bases go to M0
   const int r = lane & 31, h = lane >> 5;
@@ -458,7 +463,52 @@ k_attn(const AttnArgs a) {
     }  // query sets
     SDN_ATS_MARK(1)                               // max, exp (waits for the S MFMAs)
     // ---- O^T += V^T P^T ----
+    // kAsmTr (d = 40, two query sets, LDS-DMA tiles): the V fragments are read by inline-asm ds_read_b64_tr_b16 behind hand-counted
+    // lgkmcnt waits.  With the builtin, hipcc cannot prove that the next tile's LDS-DMA (in flight, other stage) does not alias
+    // the reads and drains it -- s_waitcnt vmcnt(0) in the middle of every iteration.  Item k+1's two reads are issued before
+    // item k is waited for: lgkmcnt(2) = "all but the two youngest LDS requests" (requests complete in order, so anything
+    // else the compiler has in flight only makes the wait stricter); the waited registers are tied through the wait statement so
+    // that no MFMA can be scheduled above it.
+    constexpr bool kAsmTr = DMA && kAsmTrOn;
     __builtin_amdgcn_s_setprio(1);
+    if constexpr (kAsmTr) {
+      auto v_addr = [&](int item, int half) -> unsigned {
+        const int kb = item / (2 * NDB), s2 = (item / NDB) & 1, d = item % NDB;
+        const int keyb = 32 * kb + 16 * s2 + 4 * h + gq;
+        const unsigned char* pa = sV + keyb * VSTR + (32 * d + gcol + 4 * gp) * 2;
+        const unsigned char* pb = pa + 8 * VSTR;
+        if (32 * d + 32 > HD) {
+          const int col = 32 * d + gcol + 4 * gp;
+          if (col >= HD) pa = pb = smem + ZOFF + (ONES && col == HD ? 0 : 8);
+        }
+        return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)(half ? pb : pa);
+      };
+      s16x4 va[2][2];
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(va[0][0]) : "v"(v_addr(0, 0)));
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(va[0][1]) : "v"(v_addr(0, 1)));
+#pragma unroll
+      for (int item = 0; item < 4 * NDB; ++item) {
+        const int kb = item / (2 * NDB), s2 = (item / NDB) & 1, d = item % NDB;
+        if (item + 1 < 4 * NDB) {
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(va[(item + 1) & 1][0]) : "v"(v_addr(item + 1, 0)));
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(va[(item + 1) & 1][1]) : "v"(v_addr(item + 1, 1)));
+          asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(va[item & 1][0]), "+v"(va[item & 1][1]));
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(va[item & 1][0]), "+v"(va[item & 1][1]));
+        }
+        union { s16x4 hlf[2]; typename T::v8 full; } vf;
+        vf.hlf[0] = va[item & 1][0]; vf.hlf[1] = va[item & 1][1];
+#pragma unroll
+        for (int qs = 0; qs < QS; ++qs) {
+          u32x4 pw;
+          pw.x = T::pack2(st[qs][kb][8 * s2 + 0], st[qs][kb][8 * s2 + 1]);
+          pw.y = T::pack2(st[qs][kb][8 * s2 + 2], st[qs][kb][8 * s2 + 3]);
+          pw.z = T::pack2(st[qs][kb][8 * s2 + 4], st[qs][kb][8 * s2 + 5]);
+          pw.w = T::pack2(st[qs][kb][8 * s2 + 6], st[qs][kb][8 * s2 + 7]);
+          o[qs][d] = T::mfma32(vf.full, *reinterpret_cast<typename T::v8*>(&pw), o[qs][d]);
+        }
+      }
+    } else {
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -489,6 +539,7 @@ k_attn(const AttnArgs a) {
           for (int qs = 0; qs < QS; ++qs) o[qs][d] = T::mfma32(vf.full, pf[qs], o[qs][d]);
         }
       }
+    }
 
     __builtin_amdgcn_s_setprio(0);
     SDN_ATS_MARK(2)                               // pack, V tr reads, PV MFMAs issued
