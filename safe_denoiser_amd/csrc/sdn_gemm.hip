@@ -653,6 +653,10 @@ static int sdn_gemm_impl(int dtype, const sdn_gemm_desc* d, const void* a, const
                          (const unsigned short*)residual, d->residual_bcast, g.ldc, d->act, (unsigned short*)out);
     return sdn_launch_status();
   }
+  if (nrep == 10 && g_gemm_variant != 13) {                    // variant 13: slab convolution off (A/B, equality tests)
+    const int rc = dispatch_conv_slab(dtype, g, st);
+    if (rc != SDN_GEMM_NOT_SLAB) return rc;
+  }
   return dtype == 0 ? dispatch_dma<SdnBF16>(nrep, g, st) : dispatch_dma<SdnF16>(nrep, g, st);
 }
 

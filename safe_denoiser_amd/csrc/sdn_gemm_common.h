@@ -90,4 +90,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #endif
 
+// sdn_conv.hip: 3x3 stride-1 convolution with the A operand served from an LDS slab ring; returns SDN_GEMM_NOT_SLAB when the
+// problem does not suit it (the caller then launches the implicit-GEMM kernel).  Same bits either way.
+constexpr int SDN_GEMM_NOT_SLAB = -1001;
+int dispatch_conv_slab(int dtype, const GemmArgs& g, hipStream_t st);
+
 }  // namespace sdn_gemm_detail

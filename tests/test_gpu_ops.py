@@ -525,3 +525,40 @@ def test_big_tile_on_short_k_projections_gives_the_small_tile_bits(dt):
 
 def _variant(v):
     sda.lib().sdn_debug_set_gemm_variant(int(v))
+
+
+# ------------------------------------------------------------------------------------------ slab-ring 3x3 convolution
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,H,Cin,Cout", [(13, 64, 320, 320), (12, 64, 640, 640), (26, 32, 640, 640), (48, 32, 320, 320),
+                                          (52, 16, 1280, 1280)])
+def test_slab_ring_convolution_gives_the_implicit_gemm_bits(dt, B, H, Cin, Cout):
+    """csrc/sdn_conv.hip: stride-1 3x3 convs on 64 / 32 / 16-wide maps read their A fragments from an LDS slab ring (the input
+    window DMA'd once per 64-channel chunk) instead of re-fetching a shifted A tile per tap.  Same k order, same MFMAs, same
+    epilogue -> the SAME BITS as the implicit-GEMM kernel (variant 13 switches the slab form off): plain, + per-sample row bias
+    (time embedding), + residual, + GroupNorm column sums; image borders (zero padding on all four sides), several samples per
+    launch, 5 ... 20 channel chunks through the ring.  And against torch's fp32 conv2d."""
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(B, H, H, Cin, generator=g).to(dt).cuda()
+    w = (torch.randn(Cout, 3, 3, Cin, generator=g) * (9 * Cin) ** -0.5).to(dt).cuda()
+    bias = torch.randn(Cout, generator=g).cuda()
+    rowbias = torch.randn(B, Cout, generator=g).cuda()
+    res = torch.randn(B * H * H, Cout, generator=g).to(dt).cuda()
+    conv = dict(Hs=H, Ws=H, Cin=Cin, Ho=H, Wo=H)
+    w2 = w.reshape(Cout, 9 * Cin)
+    nblk = (B * H * H + 127) // 128
+    cs_a = torch.zeros(nblk, Cout, 2, device="cuda"); cs_b = torch.zeros_like(cs_a)
+    cases = [("plain", lambda cs: ops.gemm(x, w2, bias=bias, conv=conv)),
+             ("row bias + residual", lambda cs: ops.gemm(x, w2, bias=bias, rowbias=rowbias, residual=res, conv=conv)),
+             ("residual + column sums", lambda cs: ops.gemm(x, w2, bias=bias, residual=res, conv=conv, col_stats=cs))]
+    try:
+        for name, fn in cases:
+            _variant(13); want = fn(cs_a); torch.cuda.synchronize()
+            _variant(0); got = fn(cs_b); torch.cuda.synchronize()
+            assert torch.isfinite(got.float()).all(), name
+            assert torch.equal(got.view(torch.int16), want.view(torch.int16)), (name, float((got.float() - want.float()).abs().max()))
+        assert torch.equal(cs_a, cs_b)
+    finally:
+        _variant(0)
+    ref = F.conv2d(x[:2].float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), bias, padding=1).permute(0, 2, 3, 1).reshape(-1, Cout)
+    out = ops.gemm(x, w2, bias=bias, conv=conv)[:2 * H * H]
+    assert rel_l2(out, ref.cpu()) <= (4e-3 if dt == torch.bfloat16 else 6e-4)

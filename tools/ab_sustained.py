@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """SUSTAINED A/B of a GEMM debug variant on the UNet forward at B = 128: N forwards back to back per arm (N = 150 is ~16 s), arms
 alternating.  Short interleaved rounds (tools/ab_gemm_variant.py) let a power-limited chip average its clock over both arms; this
-form lets each arm settle.  VARIANT via the loop below (128 = next k-tile's DMA at the top of the iteration).  To compare two
+form lets each arm settle.  VARIANT=128: next k-tile's DMA at the top of the iteration; 13: slab-ring convolution off.  To compare two
 BUILDS on one box run it twice in one gpurun call, the second time with SDN_LIB=<other libsdn.so>."""
 import os, sys, time, torch
 sys.path.insert(0, os.getcwd())
@@ -15,7 +15,7 @@ e = u.prepare_text(torch.randn(B, 77, 768, device="cuda"))
 y = torch.empty(B, 4, 64, 64, device="cuda")
 N = int(os.environ.get("N", "150"))
 for rnd in range(3):
-    for v in (0, 128):
+    for v in (0, int(os.environ.get("VARIANT", "128"))):
         sda.lib().sdn_debug_set_gemm_variant(v)
         u._ws = {}
         u.forward_into(x, 981.0, e, y); torch.cuda.synchronize()
