@@ -425,10 +425,15 @@ def main():
     if not os.path.exists(tpath):
         tpath = os.path.join(ROOT, "profiles", "round1_traffic.json")
     if os.path.exists(tpath):
-        want = dom.replace("k_gemm<", "k_gemm_dma<Sdn" + ("F16" if args.dtype == "f16" else "BF16") + ", ").replace(">", ",")
-        for kname, rec in json.load(open(tpath)).items():
-            if want in kname:
-                traffic, traffic_src = rec["hbm_bytes_per_launch"], f"profiles/{os.path.basename(tpath)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)"
+        tname = "F16" if args.dtype == "f16" else "BF16"
+        if dom == "k_conv_slab":      # one plan label, three instantiations (map width 64 / 32 / 16): launch-weighted mean
+            want = [f"k_conv_slab<Sdn{tname}, {w_}>" for w_ in (64, 32, 16)]
+        else:
+            want = [dom.replace("k_gemm<", f"k_gemm_dma<Sdn{tname}, ").replace(">", ",")]
+        hit = [rec for kname, rec in json.load(open(tpath)).items() if any(w_ in kname for w_ in want)]
+        if hit:
+            traffic = sum(r["hbm_bytes_per_launch"] * r["launches"] for r in hit) / sum(r["launches"] for r in hit)
+            traffic_src = f"profiles/{os.path.basename(tpath)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)"
     n_img = world * P * args.steps
     value = n_img / dt
     line = {
@@ -451,6 +456,9 @@ def main():
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": d["bytes"] / d["launches"], "kernel": dom,
+                     **({"kernel_instantiations": "k_conv_slab<T, 64>, <T, 32>, <T, 16> (one per map width): avg_launch_us and traffic "
+                                                  "are launch-weighted means over the three rows of the rocprof summaries"}
+                        if dom == "k_conv_slab" else {}),
                      "launches_per_forward": d["launches"] // 3, "avg_launch_us": d["ms"] / d["launches"] * 1e3,
                      "share_of_unet_time": d["ms"] / 3 / unet_ms},
         "attention_roofline": {"achieved": attn_tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",

@@ -241,13 +241,20 @@ static int launch_slab(const GemmArgs& g, hipStream_t st) {
 
 // Launches the slab form when the convolution suits it; SDN_GEMM_NOT_SLAB = the caller keeps the implicit-GEMM kernel.
 int dispatch_conv_slab(int dtype, const GemmArgs& g, hipStream_t st) {
-  if (g.a_mode != 1 || g.stride != 1 || g.upsample || g.conv_off || g.Hs != g.Ws || g.Ho != g.Hs || g.Wo != g.Ws) return SDN_GEMM_NOT_SLAB;
-  if (g.Ws != 64 && g.Ws != 32 && g.Ws != 16) return SDN_GEMM_NOT_SLAB;
-  if (g.N % 320 != 0 || g.Cin % BK != 0 || g.out_kind != 0 || g.n_valid != g.N || g.kt_per_split != 0 || g.rowgate || g.act != 0 ||
-      g.stamps || g.dbg || (g.residual && !g.res_lds) || g.M % 256 != 0 || (g.rowbias && g.rows_per_batch != g.Hs * g.Ws))
+  if (g.a_mode != 1 || g.Hs != g.Ws || g.Ho != g.Hs || g.Wo != g.Ws ||
+      !sdn_conv_slab_shape_ok(g.M, g.N, g.Cin, g.Ws, g.stride, g.upsample, g.conv_off, g.out_kind, g.n_valid))
     return SDN_GEMM_NOT_SLAB;
-  if ((long)g.tiles_m * g.tiles_n < 192) return SDN_GEMM_NOT_SLAB;
+  if (g.kt_per_split != 0 || g.rowgate || g.act != 0 || g.stamps || g.dbg || (g.residual && !g.res_lds) ||
+      (g.rowbias && g.rows_per_batch != g.Hs * g.Ws))
+    return SDN_GEMM_NOT_SLAB;
   return dtype == 0 ? launch_slab<SdnBF16>(g, st) : launch_slab<SdnF16>(g, st);
 }
 
 }  // namespace sdn_gemm_detail
+
+// Shape part of the slab form's applicability (the plan builder labels its launches with it; sdn_ops.h).
+int sdn_conv_slab_shape_ok(int M, int N, int Cin, int side, int stride, int upsample, int asym_pad, int out_kind, int n_valid) {
+  if (stride != 1 || upsample || asym_pad || (side != 64 && side != 32 && side != 16)) return 0;
+  if (N % 320 != 0 || Cin % 64 != 0 || out_kind != SDN_OUT_BF16 || (n_valid != 0 && n_valid != N) || M % 256 != 0) return 0;
+  return (long)(M / 256) * (N / 320) >= 192;
+}

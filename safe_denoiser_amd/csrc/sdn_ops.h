@@ -23,3 +23,7 @@ int sdn_temb_f32(float timestep, const float* t_dev, int batch, int dim, void* o
 int sdn_linear_pair_fold(int dtype, const void* wa, const void* wb, const float* ba, const float* bb, int C, int K, void* w_cat,
                          float* b_cat, void* stream);
 
+
+// 3x3 convolutions the slab-ring kernel (sdn_conv.hip) takes over from the implicit-GEMM tile: shape part of the test
+// (square side x side map, M = batch * side^2 output rows, N padded output channels).
+int sdn_conv_slab_shape_ok(int M, int N, int Cin, int side, int stride, int upsample, int asym_pad, int out_kind, int n_valid);

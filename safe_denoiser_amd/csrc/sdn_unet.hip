@@ -271,7 +271,11 @@ struct Builder {
     o.a = R(in); o.w = w; o.bias = bias; o.rowbias = rowbias; o.residual = residual; o.out = out;
     o.flops = 2.0 * (double)o.gd.M * (double)cout * (double)o.gd.K;
     o.bytes = 2.0 * ((double)B * in.side * in.side * in.C + (double)n_pad * o.gd.K + (double)o.gd.M * cout);
-    snprintf(o.label, sizeof(o.label), "k_gemm<%d>", sdn_gemm_pick_tile(o.gd.M, n_pad, o.gd.K, SDN_ACT_NONE));
+    if (Ho == in.side && sdn_conv_slab_shape_ok(o.gd.M, n_pad, in.C, in.side, stride, upsample, asym_pad, out_kind, n_valid) &&
+        sdn_gemm_pick_tile(o.gd.M, n_pad, o.gd.K, SDN_ACT_NONE) == 10)
+      snprintf(o.label, sizeof(o.label), "k_conv_slab");
+    else
+      snprintf(o.label, sizeof(o.label), "k_gemm<%d>", sdn_gemm_pick_tile(o.gd.M, n_pad, o.gd.K, SDN_ACT_NONE));
     push_gemm(o);
   }
   void groupnorm(const Act& x, const Act* x2, float eps, int silu, Ref gamma, Ref beta, const Act& out) {
