@@ -134,7 +134,7 @@ def measure_lra_b3(args, dev, proc, text_all, uncond, mine, P):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         pipe3(prompt_embeddings=E, num_inference_steps=args.inference_steps, guidance_scale=7.5, generator=gens,
-              repellency_processor=proc, safree_dict=dict(lra=True))
+              repellency_processor=proc, safree_dict=dict(lra=True), return_latents=True)
         torch.cuda.synchronize()
         out = {"value": P / (time.perf_counter() - t0), "unit": "images/sec", "branches": 3, "prompts_per_batch": P,
                "renoise_draws": pipe3.last_stats["renoise_draws"],

@@ -81,7 +81,7 @@ def kernel_fast_score(x: torch.Tensor, proj_refs: torch.Tensor, sigma: float, ep
     xq = x.reshape(n, -1)
     refs = proj_refs.reshape(m, -1)
     wts = rbf_weights(xq, refs, sigma)                                  # [N,M]
-    aug = torch.cat((refs, torch.ones(m, 1, dtype=refs.dtype)), dim=1)  # [M,D+1]
+    aug = torch.cat((refs, torch.ones(m, 1, dtype=refs.dtype, device=refs.device)), dim=1)  # [M,D+1]
     acc = (wts[:, :, None] * aug[None]).sum(dim=1)                      # [N,D+1]
     den = acc[:, -1] + epsilon
     num = acc[:, :-1]

@@ -27,21 +27,45 @@ SD14 = dict(in_channels=4, out_channels=4, sample_size=64, block_out_channels=(3
 
 
 class OracleUNet:
-    def __init__(self, state_dict: dict, config: dict | None = None, act_dtype=None):
+    # classes of rounding points (the precision ablation, tests/precision_ablation.py, promotes one class at a time):
+    #   "w" matrices; "text"/"temb" the conditioning inputs; "norm" GroupNorm/LayerNorm outputs (= GEMM A operands);
+    #   "stream" the residual / skip stream (resnet, attention, feed-forward and transformer outputs, conv_in, re-sampling
+    #   convs); "inner" tensors between two GEMMs inside a branch (conv1, proj_in, the 1x1 shortcut); "qkv" q, k, v and the
+    #   attention output; "ff" the GEGLU hidden activation; "opnd" the stream where a GEMM consumes it WITHOUT a norm in
+    #   between (1x1 shortcut, re-sampling convs; idempotent after "stream" when both round to the same type)
+    KINDS = ("w", "text", "temb", "norm", "stream", "inner", "qkv", "ff", "opnd")
+
+    def __init__(self, state_dict: dict, config: dict | None = None, act_dtype=None, q_map: dict | None = None,
+                 device=None):
+        """q_map: {kind: rounding} overrides `act_dtype` per class; a rounding is None (keep fp32), a torch dtype, or a
+        callable x -> x (e.g. a two-term bf16 split)."""
         self.cfg = dict(SD14)
         if config:
             self.cfg.update(config)
         self.q_dtype = act_dtype
+        self.q_map = {k: act_dtype for k in self.KINDS}
+        if q_map:
+            self.q_map.update(q_map)
         self.sd = {}
         for k, v in state_dict.items():
             v = v.detach().float()
-            if act_dtype is not None and v.dim() > 1:            # matrices are stored bf16 by the engine; vectors f32
-                v = v.to(act_dtype).float()
+            if device is not None:
+                v = v.to(device)
+            if v.dim() > 1:                                      # matrices are stored bf16 by the engine; vectors f32
+                v = self._round(v, self.q_map["w"])
             self.sd[k] = v
 
     # ---- helpers ---------------------------------------------------------------------------------
-    def q(self, x):
-        return x if self.q_dtype is None else x.to(self.q_dtype).float()
+    @staticmethod
+    def _round(x, how):
+        if how is None:
+            return x
+        if callable(how):
+            return how(x)
+        return x.to(how).float()
+
+    def q(self, x, kind="stream"):
+        return self._round(x, self.q_map[kind])
 
     def P(self, name):
         return self.sd[name]
@@ -51,17 +75,19 @@ class OracleUNet:
         half = dim // 2
         freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
         ang = torch.full((batch, 1), float(t), dtype=torch.float32) * freqs[None]
+        dev = self.sd["conv_in.weight"].device
+        freqs, ang = freqs.to(dev), ang.to(dev)
         return torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1)
 
     def resnet(self, pfx, x, semb):
         """ResnetBlock2D; `semb` = SiLU(temb) (temb enters only through SiLU -> Linear)."""
         g = self.cfg["norm_groups"]
-        h = self.q(F.silu(F.group_norm(x, g, self.P(pfx + ".norm1.weight"), self.P(pfx + ".norm1.bias"), eps=1e-5)))
+        h = self.q(F.silu(F.group_norm(x, g, self.P(pfx + ".norm1.weight"), self.P(pfx + ".norm1.bias"), eps=1e-5)), "norm")
         tp = F.linear(semb, self.P(pfx + ".time_emb_proj.weight"), self.P(pfx + ".time_emb_proj.bias"))   # stays f32
-        h = self.q(F.conv2d(h, self.P(pfx + ".conv1.weight"), self.P(pfx + ".conv1.bias"), padding=1) + tp[:, :, None, None])
-        h = self.q(F.silu(F.group_norm(h, g, self.P(pfx + ".norm2.weight"), self.P(pfx + ".norm2.bias"), eps=1e-5)))
+        h = self.q(F.conv2d(h, self.P(pfx + ".conv1.weight"), self.P(pfx + ".conv1.bias"), padding=1) + tp[:, :, None, None], "inner")
+        h = self.q(F.silu(F.group_norm(h, g, self.P(pfx + ".norm2.weight"), self.P(pfx + ".norm2.bias"), eps=1e-5)), "norm")
         if (pfx + ".conv_shortcut.weight") in self.sd:
-            sc = self.q(F.conv2d(x, self.P(pfx + ".conv_shortcut.weight"), self.P(pfx + ".conv_shortcut.bias")))
+            sc = self.q(F.conv2d(self.q(x, "opnd"), self.P(pfx + ".conv_shortcut.weight"), self.P(pfx + ".conv_shortcut.bias")), "inner")
         else:
             sc = x
         return self.q(F.conv2d(h, self.P(pfx + ".conv2.weight"), self.P(pfx + ".conv2.bias"), padding=1) + sc)
@@ -71,13 +97,13 @@ class OracleUNet:
         Returns the to_out output WITHOUT the residual."""
         nh = self.cfg["n_heads"]
         b, n, c = x.shape
-        q = self.q(F.linear(x, self.P(pfx + ".to_q.weight")))
-        k = self.q(F.linear(ctx, self.P(pfx + ".to_k.weight")))
-        v = self.q(F.linear(ctx, self.P(pfx + ".to_v.weight")))
+        q = self.q(F.linear(x, self.P(pfx + ".to_q.weight")), "qkv")
+        k = self.q(F.linear(ctx, self.P(pfx + ".to_k.weight")), "qkv")
+        v = self.q(F.linear(ctx, self.P(pfx + ".to_v.weight")), "qkv")
         d = c // nh
         q, k, v = (t.reshape(b, -1, nh, d).transpose(1, 2) for t in (q, k, v))
         a = F.scaled_dot_product_attention(q, k, v)
-        a = self.q(a.transpose(1, 2).reshape(b, n, c))
+        a = self.q(a.transpose(1, 2).reshape(b, n, c), "qkv")
         return F.linear(a, self.P(pfx + ".to_out.0.weight"), self.P(pfx + ".to_out.0.bias"))
 
     def transformer(self, pfx, x, text):
@@ -85,17 +111,17 @@ class OracleUNet:
         g = self.cfg["norm_groups"]
         b, c, hh, ww = x.shape
         tb = pfx + ".transformer_blocks.0"
-        h = self.q(F.group_norm(x, g, self.P(pfx + ".norm.weight"), self.P(pfx + ".norm.bias"), eps=1e-6))
-        h = self.q(F.conv2d(h, self.P(pfx + ".proj_in.weight"), self.P(pfx + ".proj_in.bias")))
+        h = self.q(F.group_norm(x, g, self.P(pfx + ".norm.weight"), self.P(pfx + ".norm.bias"), eps=1e-6), "norm")
+        h = self.q(F.conv2d(h, self.P(pfx + ".proj_in.weight"), self.P(pfx + ".proj_in.bias")), "stream")
         h = h.permute(0, 2, 3, 1).reshape(b, hh * ww, c)
-        ln = self.q(F.layer_norm(h, (c,), self.P(tb + ".norm1.weight"), self.P(tb + ".norm1.bias"), eps=1e-5))
+        ln = self.q(F.layer_norm(h, (c,), self.P(tb + ".norm1.weight"), self.P(tb + ".norm1.bias"), eps=1e-5), "norm")
         h = self.q(self.attention(tb + ".attn1", ln, ln) + h)
-        ln = self.q(F.layer_norm(h, (c,), self.P(tb + ".norm2.weight"), self.P(tb + ".norm2.bias"), eps=1e-5))
+        ln = self.q(F.layer_norm(h, (c,), self.P(tb + ".norm2.weight"), self.P(tb + ".norm2.bias"), eps=1e-5), "norm")
         h = self.q(self.attention(tb + ".attn2", ln, text) + h)
-        ln = self.q(F.layer_norm(h, (c,), self.P(tb + ".norm3.weight"), self.P(tb + ".norm3.bias"), eps=1e-5))
+        ln = self.q(F.layer_norm(h, (c,), self.P(tb + ".norm3.weight"), self.P(tb + ".norm3.bias"), eps=1e-5), "norm")
         proj = F.linear(ln, self.P(tb + ".ff.net.0.proj.weight"), self.P(tb + ".ff.net.0.proj.bias"))
         val, gate = proj.chunk(2, dim=-1)
-        ff = self.q(val * F.gelu(gate))                                   # exact (erf) GELU
+        ff = self.q(val * F.gelu(gate), "ff")                                   # exact (erf) GELU
         h = self.q(F.linear(ff, self.P(tb + ".ff.net.2.weight"), self.P(tb + ".ff.net.2.bias")) + h)
         h = h.reshape(b, hh, ww, c).permute(0, 3, 1, 2)
         return self.q(F.conv2d(h, self.P(pfx + ".proj_out.weight"), self.P(pfx + ".proj_out.bias")) + x)
@@ -107,10 +133,10 @@ class OracleUNet:
         boc = c["block_out_channels"]
         nl = len(boc)
         b = sample.shape[0]
-        text = self.q(encoder_hidden_states.float())
-        te = self.q(self.timestep_features(timestep, b, boc[0]))
-        te = self.q(F.silu(F.linear(te, self.P("time_embedding.linear_1.weight"), self.P("time_embedding.linear_1.bias"))))
-        semb = self.q(F.silu(F.linear(te, self.P("time_embedding.linear_2.weight"), self.P("time_embedding.linear_2.bias"))))
+        text = self.q(encoder_hidden_states.float(), "text")
+        te = self.q(self.timestep_features(timestep, b, boc[0]), "temb")
+        te = self.q(F.silu(F.linear(te, self.P("time_embedding.linear_1.weight"), self.P("time_embedding.linear_1.bias"))), "temb")
+        semb = self.q(F.silu(F.linear(te, self.P("time_embedding.linear_2.weight"), self.P("time_embedding.linear_2.bias"))), "temb")
 
         h = self.q(F.conv2d(sample.float(), self.P("conv_in.weight"), self.P("conv_in.bias"), padding=1))
         skips = [h]
@@ -122,7 +148,7 @@ class OracleUNet:
                 skips.append(h)
             if i + 1 < nl:
                 p = f"down_blocks.{i}.downsamplers.0.conv"
-                h = self.q(F.conv2d(h, self.P(p + ".weight"), self.P(p + ".bias"), stride=2, padding=1))
+                h = self.q(F.conv2d(self.q(h, "opnd"), self.P(p + ".weight"), self.P(p + ".bias"), stride=2, padding=1))
                 skips.append(h)
         h = self.resnet("mid_block.resnets.0", h, semb)
         h = self.transformer("mid_block.attentions.0", h, text)
@@ -136,7 +162,7 @@ class OracleUNet:
                     h = self.transformer(f"up_blocks.{i}.attentions.{j}", h, text)
             if i + 1 < nl:
                 p = f"up_blocks.{i}.upsamplers.0.conv"
-                h = F.interpolate(h, scale_factor=2.0, mode="nearest")
+                h = F.interpolate(self.q(h, "opnd"), scale_factor=2.0, mode="nearest")
                 h = self.q(F.conv2d(h, self.P(p + ".weight"), self.P(p + ".bias"), padding=1))
-        h = self.q(F.silu(F.group_norm(h, c["norm_groups"], self.P("conv_norm_out.weight"), self.P("conv_norm_out.bias"), eps=1e-5)))
+        h = self.q(F.silu(F.group_norm(h, c["norm_groups"], self.P("conv_norm_out.weight"), self.P("conv_norm_out.bias"), eps=1e-5)), "norm")
         return F.conv2d(h, self.P("conv_out.weight"), self.P("conv_out.bias"), padding=1)

@@ -4,14 +4,20 @@
 run_nudity.py:373-408 (`valid_case_numbers` slicing; `adv_prompt` (MMA-diffusion), `sensitive prompt` (concept removal),
 `prompt` + `case_number` (i2p / RECE tables); `guidance` column or the CLI default; `evaluation_seed` else `sd_seed` else
 42; `categories` split on ", " else "nudity"; rows whose prompt is not a string or whose seed is not an int are skipped,
-:411-413) and run_copro.py:436-448 (`unsafe_prompt` + `idx`).  `batches` groups them for the batched engine loop: prompts
+:411-413), run_copro.py:436-448 (`unsafe_prompt` + `idx`) and run_coco30k.py:410-425 (the COCO-30k table of BASELINE
+config 5: a row that HAS a `recaption` column takes its prompt from `caption` and its case number from `image_id`; rows
+without a `categories` column are labelled "coco" when the run's --category contains "coco").  `batches` groups them for the batched engine loop: prompts
 of one batch share the guidance scale (it is a scalar of sdn_cfg_combine) and each keeps its own seed -> generator.
 """
 from __future__ import annotations
 
 from typing import Iterable, List, Optional
 
-_PROMPT_COLUMNS = (("adv_prompt", None), ("sensitive prompt", None), ("prompt", "case_number"), ("unsafe_prompt", "idx"))
+# (column whose PRESENCE selects the dialect, prompt column, case-number column or None = the row index), in the reference's
+# if / elif order (run_nudity.py:379-388, run_coco30k.py:400-413, run_copro.py:442-445)
+_PROMPT_COLUMNS = (("adv_prompt", "adv_prompt", None), ("sensitive prompt", "sensitive prompt", None),
+                   ("prompt", "prompt", "case_number"), ("recaption", "caption", "image_id"),
+                   ("unsafe_prompt", "unsafe_prompt", "idx"))
 
 
 def _is_int(v) -> bool:
@@ -19,8 +25,9 @@ def _is_int(v) -> bool:
     return isinstance(v, numbers.Integral) and not isinstance(v, bool)
 
 
-def read_cases(table, valid_case_numbers: str = "0,100000", default_guidance: float = 7.5) -> List[dict]:
-    """`table`: path to a CSV or a pandas DataFrame.  Returns [{prompt, case_number, seed, guidance, categories, row}]."""
+def read_cases(table, valid_case_numbers: str = "0,100000", default_guidance: float = 7.5, category: str = "nudity") -> List[dict]:
+    """`table`: path to a CSV or a pandas DataFrame; `category`: the run's --category (only "coco" in it matters, see above).
+    Returns [{prompt, case_number, seed, guidance, categories, row}]."""
     import pandas as pd
     df = pd.read_csv(table) if isinstance(table, (str, bytes)) or hasattr(table, "__fspath__") else table
     vstart, vend = (int(x) for x in valid_case_numbers.split(","))
@@ -28,8 +35,8 @@ def read_cases(table, valid_case_numbers: str = "0,100000", default_guidance: fl
     out = []
     for it, data in df.iterrows():
         prompt = case = None
-        for col, case_col in _PROMPT_COLUMNS:
-            if col in data:
+        for key_col, col, case_col in _PROMPT_COLUMNS:
+            if key_col in data:
                 prompt = data[col]
                 case = it if case_col is None else data[case_col]
                 break
@@ -42,7 +49,10 @@ def read_cases(table, valid_case_numbers: str = "0,100000", default_guidance: fl
             seed = data["sd_seed"]
         else:
             seed = 42
-        cats = data["categories"].split(", ") if "categories" in data and isinstance(data["categories"], str) else "nudity"
+        if "categories" in data and isinstance(data["categories"], str):
+            cats = data["categories"].split(", ")
+        else:
+            cats = "coco" if "coco" in category else "nudity"        # run_coco30k.py:421-426
         if hasattr(seed, "item"):
             seed = seed.item()
         if hasattr(guidance, "item"):

@@ -297,7 +297,7 @@ def run_job(args, pipe, repellency_processor=None, task_config: Optional[Mapping
         log.log(f"SLD safe config: {safe_config}")
     if task_config is not None:
         log.log(f"Repellency method : {task_config['repellency']['method']}")
-    table = _cases.read_cases(args.data, args.valid_case_numbers, default_guidance=args.guidance_scale)
+    table = _cases.read_cases(args.data, args.valid_case_numbers, default_guidance=args.guidance_scale, category=args.category)
     for batch in _cases.batches(table, prompts_per_batch, rank, world):
         for c in batch:
             art.log_case(c)

@@ -65,14 +65,44 @@ class SafeDenoiserPipeline:
             return noise_fn(p, shape).to(device=device, dtype=torch.float32)
         return torch.randn(shape, generator=generators[p], device=device, dtype=torch.float32)
 
+    # keyword arguments the reference's __call__ variants read out of **kwargs (window bounds, the SLD SafetyConfig splat)
+    _KNOWN_KWARGS = ("negation_warmup_start", "negation_warmup_end", "negation_warmup_steps", "sld_guidance_scale",
+                     "sld_warmup_steps", "sld_threshold", "sld_momentum_scale", "sld_mom_beta", "safree")
+
     @torch.no_grad()
     def __call__(self, prompt=None, height: Optional[int] = None, width: Optional[int] = None,
                  num_inference_steps: int = 50, guidance_scale: float = 7.5, negative_prompt=None,
-                 negative_prompt_space=None, generator=None, latents=None,
-                 prompt_embeddings: Optional[torch.Tensor] = None, repellency_processor=None, safree_dict=None,
+                 negative_prompt_space=None, num_images_per_prompt: Optional[int] = 1, eta: float = 0.0, generator=None,
+                 latents=None, output_type: Optional[str] = "pil", return_dict: bool = True, callback=None,
+                 callback_steps: Optional[int] = 1, prompt_ids=None,
+                 prompt_embeddings: Optional[torch.Tensor] = None, return_latents: bool = False,
+                 repellency_processor=None, safree_dict=None,
                  rescaled_text_embeddings: Optional[torch.Tensor] = None, beta_adjusted=None,
-                 return_latents: bool = True, noise_fn: Optional[Callable] = None, output_type: str = "pil", **kwargs):
+                 noise_fn: Optional[Callable] = None, **kwargs):
+        """Argument order, names and defaults of the reference's __call__ (...threshold_time.py:352-375), so its call site
+        (run_nudity.py:439-460) works verbatim: `return_latents` defaults to False (images come back, :585-596).
+        `return_dict` is accepted and, as in the reference (:598: `return image`), does not change what is returned.
+        Honoured: `callback(i, t, latents)` every `callback_steps` (:580-582).  Rejected loudly instead of silently dropped:
+        `num_images_per_prompt` != 1 (the reference's repellency block is batch-1: `denominator.item()`, repellency_methods_
+        threshold.py:348 -- batch prompts instead), `eta` != 0 with DDIM (DDPM never receives eta: prepare_extra_step_kwargs),
+        `prompt_ids`, and keyword arguments no variant of the reference reads."""
         _lib.require_gpu()
+        if num_images_per_prompt not in (None, 1):
+            raise NotImplementedError("num_images_per_prompt > 1: the reference's repellency block handles one latent per call "
+                                      "(denominator.item(), repellency_methods_threshold.py:348); pass the prompt "
+                                      "num_images_per_prompt times with one generator each instead")
+        if eta and isinstance(self.scheduler, DDIMScheduler):
+            raise NotImplementedError("DDIM with eta != 0 is not implemented (the reference's live scheduler is DDPM, which "
+                                      "never receives eta)")
+        if prompt_ids is not None:
+            raise NotImplementedError("prompt_ids (the SLD pipelines' embedding-space prompt) is not on the benchmarked path")
+        if callback is not None and (not isinstance(callback_steps, int) or callback_steps <= 0):
+            raise ValueError(f"`callback_steps` has to be a positive integer but is {callback_steps} of type {type(callback_steps)}.")
+        unknown = sorted(k for k in kwargs if k not in self._KNOWN_KWARGS)
+        if unknown:
+            raise TypeError(f"SafeDenoiserPipeline.__call__: unknown keyword arguments {unknown}")
+        if output_type is None:
+            output_type = "np"
         sf = dict(safree=False, svf=False, lra=False, re_attn_t=(-1, -1), alpha=0.0, up_t=10, category="nudity", logger=None)
         if safree_dict:
             sf.update(safree_dict)
@@ -261,6 +291,8 @@ class SafeDenoiserPipeline:
                                         co["sigma"] if z is not None else 0.0, clip, nxt.data_ptr(), st),
                        "sdn_sched_step")
             lat, nxt = nxt, lat
+            if callback is not None and i % callback_steps == 0:
+                callback(i, t, lat)
 
         lat = lat.clone()                                              # the loop buffers are reused by the next call
         self.last_stats = {"renoise_draws": n_renoise, "window_steps": n_window, "prompts": P, "branches": nb}

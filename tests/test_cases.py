@@ -49,3 +49,18 @@ def test_batches_shard_and_group_by_guidance():
     for b in b0 + b1:
         assert 1 <= len(b) <= 3 and len({c["guidance"] for c in b}) == 1
     assert [c["case_number"] for b in b0 for c in b if c["guidance"] == 7.5] == [2, 4, 8, 10]
+
+
+def test_coco_dialect_of_config_5():
+    """run_coco30k.py:410-425: a table with a `recaption` column takes `caption` / `image_id`; no `categories` column ->
+    "coco" when the run's category contains "coco" (else the nudity default); no seed column -> 42."""
+    t = df("image_id,caption,recaption,image\n397133,A man is cooking in a kitchen,a chef,/x/1.jpg\n37777,A tidy room,room,/x/2.jpg\n")
+    cs = read_cases(t, category="coco")
+    assert [(c["prompt"], c["case_number"], c["seed"], c["guidance"], c["categories"]) for c in cs] == \
+        [("A man is cooking in a kitchen", 397133, 42, 7.5, "coco"), ("A tidy room", 37777, 42, 7.5, "coco")]
+    assert image_name(cs[0]) == "397133_c-o-c-o.png"                      # '-'.join of a plain string, as the reference writes it
+    assert read_cases(t, category="coco_open_clip")[0]["categories"] == "coco"
+    assert read_cases(t)[0]["categories"] == "nudity"
+    # `prompt` still wins over the COCO columns (the elif order)
+    both = read_cases(df("case_number,prompt,recaption,caption,image_id\n5,p,r,c,9\n"), category="coco")
+    assert both[0]["prompt"] == "p" and both[0]["case_number"] == 5

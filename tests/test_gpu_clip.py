@@ -87,9 +87,9 @@ def test_pipeline_accepts_prompt_strings_with_a_text_encoder_and_tokenizer():
     pipe = SafeDenoiserPipeline(u, DDIMScheduler(), text_encoder=te, tokenizer=tokenizer)
     gens = lambda: [torch.Generator(device="cuda").manual_seed(3 + i) for i in range(2)]
     prompts = ["a photo of a cat", "an oil painting of a ship"]
-    lat = pipe(prompt=prompts, num_inference_steps=3, generator=gens())
+    lat = pipe(prompt=prompts, num_inference_steps=3, generator=gens(), return_latents=True)
     E = pipe.encode_prompt(prompts)
     assert E.shape == (4, 77, 128)
-    torch.testing.assert_close(pipe(prompt_embeddings=E, num_inference_steps=3, generator=gens()), lat, rtol=0, atol=0)
+    torch.testing.assert_close(pipe(prompt_embeddings=E, num_inference_steps=3, generator=gens(), return_latents=True), lat, rtol=0, atol=0)
     with pytest.raises(NotImplementedError):
-        SafeDenoiserPipeline(u, DDIMScheduler())(prompt="x", num_inference_steps=1)
+        SafeDenoiserPipeline(u, DDIMScheduler())(prompt="x", num_inference_steps=1, return_latents=True)

@@ -189,7 +189,7 @@ def test_full_sd14_fp32_plan_forward_and_10_step_loop_meet_the_north_star_tolera
         t_p = Tape()
         pipe = SafeDenoiserPipeline(un, DDPMScheduler(), variant="threshold_time")
         lat = pipe(prompt_embeddings=E.cuda(), num_inference_steps=steps, guidance_scale=7.5, noise_fn=t_p,
-                   repellency_processor=_proc(refs, tmp_path, **params))
+                   repellency_processor=_proc(refs, tmp_path, **params), return_latents=True)
         res[name] = (rel_l2(lat, ref), pipe.last_stats["renoise_draws"], t_p.i)
         del un
     print(f"full SD-v1.4 10-step loop vs pure-fp32 oracle (re-noise draws {st['renoise_draws']}): " +

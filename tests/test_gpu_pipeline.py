@@ -153,13 +153,13 @@ def test_device_generators_are_per_prompt(world):
     u, sd, E, refs, P = world
     gens = lambda idx: [torch.Generator(device="cuda").manual_seed(1000 + i) for i in idx]
     pipe = SafeDenoiserPipeline(u, DDPMScheduler(), variant="threshold_time")
-    full = pipe(prompt_embeddings=E.cuda(), num_inference_steps=5, generator=gens(range(P)))
+    full = pipe(prompt_embeddings=E.cuda(), num_inference_steps=5, generator=gens(range(P)), return_latents=True)
     sel = [P - 1]
     Esel = torch.cat([E[:P][sel], E[P:][sel]])
-    one = pipe(prompt_embeddings=Esel.cuda(), num_inference_steps=5, generator=gens(sel))
+    one = pipe(prompt_embeddings=Esel.cuda(), num_inference_steps=5, generator=gens(sel), return_latents=True)
     assert rel_l2(one, full[P - 1:P]) <= 1e-6
     with pytest.raises(NotImplementedError):
-        pipe(prompt="a photo", num_inference_steps=5)
+        pipe(prompt="a photo", num_inference_steps=5, return_latents=True)
 
 
 def test_loop_with_engine_side_latent_repeat_is_bit_identical(world, tmp_path):
@@ -173,11 +173,11 @@ def test_loop_with_engine_side_latent_repeat_is_bit_identical(world, tmp_path):
         proc = make_proc(thr, refs, tmp_path, scale=0.03, sigma=1.0, epsilon=1e-8, beta_threshold=0.5, beta_threshold_margin=0.1)
         pipe = SafeDenoiserPipeline(unet, DDPMScheduler(), variant="threshold_time")
         gens = [torch.Generator(device="cuda").manual_seed(50 + i) for i in range(P)]
-        outs.append(pipe(prompt_embeddings=E.cuda(), num_inference_steps=8, generator=gens, repellency_processor=proc))
+        outs.append(pipe(prompt_embeddings=E.cuda(), num_inference_steps=8, generator=gens, repellency_processor=proc, return_latents=True))
     torch.testing.assert_close(outs[1], outs[0], rtol=0, atol=0)
     with pytest.raises(Exception):                                   # 3 branches on a repeat-2 plan
         SafeDenoiserPipeline(u2, DDPMScheduler())(prompt_embeddings=torch.cat([E, E[:P]]).cuda(), num_inference_steps=2,
-                                                   sld_guidance_scale=2000.0)
+                                                   sld_guidance_scale=2000.0, return_latents=True)
 
 
 def test_fp16_storage_loop_parity(tmp_path):
@@ -194,7 +194,7 @@ def test_fp16_storage_loop_parity(tmp_path):
     ref = torch.cat([opipe.denoise_one(unet_o, osch.DDPM(), torch.stack([E[p], E[P + p]]), p, t_o,
                                        num_inference_steps=STEPS)[0] for p in range(P)])
     t_p = Tapes(P, shape, 3 * STEPS + 4, seed=9)
-    lat = SafeDenoiserPipeline(u, DDPMScheduler())(prompt_embeddings=E.cuda(), num_inference_steps=STEPS, noise_fn=t_p)
+    lat = SafeDenoiserPipeline(u, DDPMScheduler())(prompt_embeddings=E.cuda(), num_inference_steps=STEPS, noise_fn=t_p, return_latents=True)
     errs = [rel_l2(lat[p:p + 1], ref[p:p + 1]) for p in range(P)]
     print(f"fp16 loop: per-prompt rel L2 {['%.2e' % e for e in errs]}")
     assert t_p.cur == t_o.cur and max(errs) <= 1.5e-2
@@ -219,7 +219,7 @@ def test_sld_family_loop_matches_oracle(world, tmp_path):
     pipe = SafeDenoiserPipeline(u, DDPMScheduler(), variant="threshold_time")
     lat = pipe(prompt_embeddings=E3.cuda(), num_inference_steps=STEPS, repellency_processor=make_proc(thr, refs, tmp_path, **params),
                noise_fn=t_p, sld_guidance_scale=sld["scale"], sld_warmup_steps=sld["warmup"], sld_threshold=sld["thr"],
-               sld_momentum_scale=sld["ms"], sld_mom_beta=sld["mb"])
+               sld_momentum_scale=sld["ms"], sld_mom_beta=sld["mb"], return_latents=True)
     errs = [rel_l2(lat[p:p + 1], ref[p:p + 1]) for p in range(P)]
     print(f"sld loop: per-prompt rel L2 {['%.2e' % e for e in errs]}")
     assert t_p.cur == t_o.cur and max(errs) <= 8e-2
@@ -268,7 +268,7 @@ def test_lra_and_safree_text_switch_match_oracle(world, tmp_path, mode):
     t_p = Tapes(P, shape, 3 * STEPS + 4, seed=21)
     pipe = SafeDenoiserPipeline(u, DDPMScheduler(), variant="threshold_time")
     lat = pipe(prompt_embeddings=E.cuda(), num_inference_steps=STEPS, repellency_processor=make_proc(thr, refs, tmp_path, **params),
-               noise_fn=t_p, safree_dict=sf, rescaled_text_embeddings=Es.cuda(), beta_adjusted=betas)
+               noise_fn=t_p, safree_dict=sf, rescaled_text_embeddings=Es.cuda(), beta_adjusted=betas, return_latents=True)
     assert pipe.last_stats["branches"] == (3 if lra else 2)
     assert t_p.cur == t_o.cur and pipe.last_stats["renoise_draws"] == draws > 0
     errs = [rel_l2(lat[p:p + 1], ref[p:p + 1]) for p in range(P)]
@@ -286,7 +286,7 @@ def test_window_kwargs_follow_each_variant(world, tmp_path):
     n = 10
     def windows(variant, **kw):
         pipe = SafeDenoiserPipeline(u, DDIMScheduler(), variant=variant)
-        pipe(prompt_embeddings=E.cuda(), num_inference_steps=n, repellency_processor=make_proc(thr, refs, tmp_path, **params), **kw)
+        pipe(prompt_embeddings=E.cuda(), num_inference_steps=n, repellency_processor=make_proc(thr, refs, tmp_path, **params), **kw, return_latents=True)
         return pipe.last_stats["window_steps"]
     assert windows("threshold", negation_warmup_start=1000, negation_warmup_end=780) == n       # kwargs ignored: every step
     assert windows("sd_threshold_time") == n                                                   # i = 0..9 all <= 11

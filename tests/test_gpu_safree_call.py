@@ -74,7 +74,7 @@ def test_prompt_call_with_safree_matches_oracle_stage_by_stage(stack, tmp_path):
     shape = (1, 4, 16, 16)
     t_p = Tapes(P, shape, 3 * STEPS + 4, seed=33)
     lat = pipe(PROMPTS, num_inference_steps=STEPS, negative_prompt=", ".join(NEG_SPACE), negative_prompt_space=NEG_SPACE,
-               repellency_processor=make_proc(thr, refs, tmp_path, **params), safree_dict=sf, noise_fn=t_p)
+               repellency_processor=make_proc(thr, refs, tmp_path, **params), safree_dict=sf, noise_fn=t_p, return_latents=True)
     prep = pipe.last_safree
     assert pipe.last_stats["branches"] == 3 and prep is not None
 
@@ -136,9 +136,9 @@ def test_prompt_call_requires_concept_space_and_keeps_plain_path(stack):
     u, sd, enc, csd, tok, refs = stack
     pipe = SafeDenoiserPipeline(u, DDPMScheduler(), text_encoder=enc, tokenizer=tok)
     with pytest.raises(Exception):
-        pipe(PROMPTS[:1], num_inference_steps=2, safree_dict=dict(safree=True))
-    a = pipe(PROMPTS[:1], num_inference_steps=3, noise_fn=Tapes(1, (1, 4, 16, 16), 16, seed=1))
-    b = pipe(prompt_embeddings=pipe.encode_prompt(PROMPTS[:1]), num_inference_steps=3, noise_fn=Tapes(1, (1, 4, 16, 16), 16, seed=1))
+        pipe(PROMPTS[:1], num_inference_steps=2, safree_dict=dict(safree=True), return_latents=True)
+    a = pipe(PROMPTS[:1], num_inference_steps=3, noise_fn=Tapes(1, (1, 4, 16, 16), 16, seed=1), return_latents=True)
+    b = pipe(prompt_embeddings=pipe.encode_prompt(PROMPTS[:1]), num_inference_steps=3, noise_fn=Tapes(1, (1, 4, 16, 16), 16, seed=1), return_latents=True)
     torch.testing.assert_close(a, b, rtol=0, atol=0)
     with pytest.raises(ValueError):
-        pipe(PROMPTS[:2], negative_prompt=["x"], num_inference_steps=1)
+        pipe(PROMPTS[:2], negative_prompt=["x"], num_inference_steps=1, return_latents=True)

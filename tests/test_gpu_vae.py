@@ -131,7 +131,7 @@ def test_pipeline_ends_like_the_reference_with_images():
     E = torch.randn(4, 77, 768, generator=torch.Generator().manual_seed(2)).cuda()
     gens = lambda: [torch.Generator(device="cuda").manual_seed(7 + i) for i in range(2)]
     pipe = SafeDenoiserPipeline(u, DDPMScheduler(), variant="threshold_time", vae=v)
-    lat = pipe(prompt_embeddings=E, num_inference_steps=4, generator=gens())
+    lat = pipe(prompt_embeddings=E, num_inference_steps=4, generator=gens(), return_latents=True)
     im_np = pipe(prompt_embeddings=E, num_inference_steps=4, generator=gens(), return_latents=False, output_type="np")
     im_u8 = pipe(prompt_embeddings=E, num_inference_steps=4, generator=gens(), return_latents=False, output_type="uint8")
     im_pil = pipe(prompt_embeddings=E, num_inference_steps=4, generator=gens(), return_latents=False)

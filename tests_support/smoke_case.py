@@ -62,7 +62,7 @@ def run_smoke():
     tp = Tape()
     pipe = SafeDenoiserPipeline(u, DDPMScheduler())
     lat = pipe(prompt_embeddings=E.cuda(), num_inference_steps=3, repellency_processor=_proc(refs, **params), noise_fn=tp,
-               negation_warmup_end=0)
+               negation_warmup_end=0, return_latents=True)
     torch.cuda.synchronize()
     rel = float((lat.cpu() - ref).norm() / ref.norm())
     assert pipe.last_stats["renoise_draws"] == st["renoise_draws"] > 0, (pipe.last_stats, st)
