@@ -302,6 +302,20 @@ int sdn_conv_in_f32(const float* latents_nchw, const void* w, const float* bias,
                     int32_t h, int32_t wd, int32_t cout, void* out_nhwc, void* stream);
 int sdn_timestep_embed_f32(float timestep, int32_t batch, int32_t dim, void* out, void* stream);
 
+/* ---- bf16x3 contractions on fp32 storage (dtype 3 of sdn_unet_config: the ACCURATE THROUGHPUT mode) ----
+ * Same operators, arguments and f32 storage as sdn_gemm_f32 / sdn_attention_f32; every operand element is split on the
+ * fly into bf16 hi + lo (16 mantissa bits) and each product runs as hi.hi + hi.lo + lo.hi on the bf16 matrix cores
+ * (3 x v_mfma_f32_16x16x32_bf16 per 16x16x32 block, f32 accumulation) instead of 8 f32-input MFMAs.  Norms, softmax,
+ * epilogues and storage stay f32.  Distance from the reference's fp32 arithmetic (run_nudity.py:277): ~1.5e-5 per UNet
+ * forward, 3.4e-5 over the 10-step loop -- inside the north star's 1e-3, which a single 16-bit rounding of the MFMA
+ * operands cannot meet (2.96e-3 fp16 / 2.3e-2 bf16: profiles/round3_precision_ablation.md). */
+int sdn_gemm_x3(const sdn_gemm_desc* d_host, const void* a, const void* a2, const void* w,
+                const float* bias, const float* rowbias, const float* rowgate, const void* residual, void* out,
+                void* stream);
+int sdn_attention_x3(const void* q, const void* k, const void* v, void* out, int32_t batch, int32_t heads,
+                     int32_t nq, int32_t nk, int32_t head_dim, int32_t ldq, int32_t ldk, int32_t ldv,
+                     int32_t ldo, float scale, void* stream);
+
 /* ---- whole-network entry: SD-v1.4-family UNet2DConditionModel forward -------------------------- */
 typedef struct sdn_unet_config {
   int32_t in_channels, out_channels, sample_size;      /* 4, 4, 64                                  */
@@ -314,7 +328,8 @@ typedef struct sdn_unet_config {
   int32_t norm_groups;                                 /* 32                                        */
   int32_t dtype;                                       /* 0 = bf16 storage, 1 = fp16 storage, 2 = fp32
                                                           storage (precision mode: weights, text and every
-                                                          activation f32; see sdn_gemm_f32)          */
+                                                          activation f32; see sdn_gemm_f32), 3 = fp32
+                                                          storage with bf16x3 contractions (sdn_gemm_x3) */
   int32_t latent_repeat;                               /* 0/1 = off.  r > 1: the batch is r guidance branches of the
                                                           SAME latents (`torch.cat([latents] * r)`, ...threshold_time.py
                                                           :535): sdn_unet_forward then takes latents [B / r, ...] and

@@ -12,6 +12,8 @@
 //   sdn_conv_in_f32, sdn_timestep_embed_f32
 // Kernels here favour plainness over the last 2x: tiles are small, staging is register -> LDS with one prefetched k-tile.
 #include <math.h>
+#include <stdlib.h>
+#include <type_traits>
 
 #include "sdn_common.h"
 #include "sdn_ops.h"
@@ -43,6 +45,58 @@ struct GemmArgsF {
   int act, out_kind, rows_per_batch, ld_rowbias, ld_rowgate, residual_bcast, n_valid, ldc;
   int tiles_n;
 };
+
+// One output row's share of a wave's 16 x 64 accumulator block: acc[j][e] <-> row m, column n0 + 16 j + 4 fq + e.  Bias,
+// per-sample row bias / gate, residual, activation (incl. the interleaved GEGLU pairs) and the three output layouts.
+template <int NJ = 4>
+__device__ __forceinline__ void gemm_row_epilogue(const GemmArgsF& g, const f32x4 (&acc)[NJ], const int m, const int n0, const int fq) {
+  if (m >= g.M) return;
+  const int b = g.rows_per_batch > 0 ? m / g.rows_per_batch : 0;
+  if (g.act == SDN_ACT_GEGLU) {                                              // blocks of 16 value columns, then their 16 gates
+#pragma unroll
+    for (int j = 0; j + 1 < NJ; j += 2) {
+      const int n = n0 + j * 16 + fq * 4;
+      if (n >= g.N) continue;
+      f32x4 hv = acc[j], gv = acc[j + 1];
+      if (g.bias) { hv += *reinterpret_cast<const f32x4*>(g.bias + n); gv += *reinterpret_cast<const f32x4*>(g.bias + n + 16); }
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = hv[e] * gelu_erf_f(gv[e]);
+      const int nc = ((n0 + j * 16) >> 1) + fq * 4;
+      *reinterpret_cast<f32x4*>(g.out + (long)m * g.ldc + nc) = o;
+    }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int n = n0 + j * 16 + fq * 4;
+    if (n >= g.N) continue;
+    f32x4 v = acc[j];
+    if (g.bias) v += *reinterpret_cast<const f32x4*>(g.bias + n);
+    if (g.rowbias) v += *reinterpret_cast<const f32x4*>(g.rowbias + (long)b * g.ld_rowbias + n);
+    if (g.rowgate) v *= *reinterpret_cast<const f32x4*>(g.rowgate + (long)b * g.ld_rowgate + n);
+    if (g.residual) {
+      const long rrow = g.residual_bcast ? (long)(m - b * g.rows_per_batch) : (long)m;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n + e < g.n_valid) v[e] += g.residual[rrow * g.ldc + n + e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float t = v[e];
+      if (g.act == SDN_ACT_SILU) t = silu_f(t);
+      else if (g.act == SDN_ACT_GELU_TANH) t = gelu_tanh_f(t);
+      else if (g.act == SDN_ACT_QUICK_GELU) t = quick_gelu_f(t);
+      if (n + e >= g.n_valid) continue;
+      if (g.out_kind == SDN_OUT_F32_NCHW) {
+        const int p = m - b * g.rows_per_batch;
+        g.out[((long)b * g.n_valid + n + e) * g.rows_per_batch + p] = t;
+      } else {
+        g.out[(long)m * g.ldc + n + e] = t;
+      }
+    }
+  }
+}
 
 __global__ void __launch_bounds__(256)
 k_gemm_f32(const GemmArgsF g) {
@@ -109,53 +163,7 @@ k_gemm_f32(const GemmArgsF g) {
   }
 
   // ---- epilogue: acc[j][e] <-> row m0 + 16w + fr, column n0 + 16j + 4fq + e ----
-  const int m = m0 + wid * 16 + fr;
-  if (m >= g.M) return;
-  const int b = g.rows_per_batch > 0 ? m / g.rows_per_batch : 0;
-  if (g.act == SDN_ACT_GEGLU) {                                              // blocks of 16 value columns, then their 16 gates
-#pragma unroll
-    for (int j = 0; j < 4; j += 2) {
-      const int n = n0 + j * 16 + fq * 4;
-      if (n >= g.N) continue;
-      f32x4 hv = acc[j], gv = acc[j + 1];
-      if (g.bias) { hv += *reinterpret_cast<const f32x4*>(g.bias + n); gv += *reinterpret_cast<const f32x4*>(g.bias + n + 16); }
-      f32x4 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = hv[e] * gelu_erf_f(gv[e]);
-      const int nc = ((n0 + j * 16) >> 1) + fq * 4;
-      *reinterpret_cast<f32x4*>(g.out + (long)m * g.ldc + nc) = o;
-    }
-    return;
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int n = n0 + j * 16 + fq * 4;
-    if (n >= g.N) continue;
-    f32x4 v = acc[j];
-    if (g.bias) v += *reinterpret_cast<const f32x4*>(g.bias + n);
-    if (g.rowbias) v += *reinterpret_cast<const f32x4*>(g.rowbias + (long)b * g.ld_rowbias + n);
-    if (g.rowgate) v *= *reinterpret_cast<const f32x4*>(g.rowgate + (long)b * g.ld_rowgate + n);
-    if (g.residual) {
-      const long rrow = g.residual_bcast ? (long)(m - b * g.rows_per_batch) : (long)m;
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (n + e < g.n_valid) v[e] += g.residual[rrow * g.ldc + n + e];
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float t = v[e];
-      if (g.act == SDN_ACT_SILU) t = silu_f(t);
-      else if (g.act == SDN_ACT_GELU_TANH) t = gelu_tanh_f(t);
-      else if (g.act == SDN_ACT_QUICK_GELU) t = quick_gelu_f(t);
-      if (n + e >= g.n_valid) continue;
-      if (g.out_kind == SDN_OUT_F32_NCHW) {
-        const int p = m - b * g.rows_per_batch;
-        g.out[((long)b * g.n_valid + n + e) * g.rows_per_batch + p] = t;
-      } else {
-        g.out[(long)m * g.ldc + n + e] = t;
-      }
-    }
-  }
+  gemm_row_epilogue(g, acc, m0 + wid * 16 + fr, n0, fq);
 }
 
 // ================================================================================================
@@ -337,11 +345,351 @@ __global__ void k_temb_f32(float t_val, const float* __restrict__ t_dev, int B, 
   }
 }
 
+// ================================================================================================
+// bf16x3 contractions on fp32 storage (dtype 3 of sdn_unet_config): every operand element x is split on the fly into
+// hi = bf16(x) and lo = bf16(x - hi) (x = hi + lo to 2^-17 relative: 16 mantissa bits) and every product a.w is formed as
+// a_hi w_hi + a_hi w_lo + a_lo w_hi on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16, f32 accumulation; the dropped
+// lo.lo term is below 2^-17 relative).  3 MFMAs at the 16-bit rate instead of 8 at the f32-input rate for the same
+// 16 x 16 x 32 block: the precision mode's contraction at ~5x the f32-MFMA throughput, with everything else (storage,
+// norms, softmax, epilogues) unchanged f32.  Measured distance from the pure-fp32 reference: ~1.5e-5 per UNet forward,
+// 3.4e-5 over the 10-step loop (profiles/round3_precision_ablation.md) against the north star's 1e-3.
+// ================================================================================================
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 v2;
+  v2 p = {(__bf16)a, (__bf16)b};                                             // v_cvt_pk_bf16_f32 (RNE)
+  return *reinterpret_cast<unsigned*>(&p);
+}
+// two f32 -> packed hi pair, packed lo pair (x - float(hi) is exact in f32)
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+  hi = pk_bf16(a, b);
+  lo = pk_bf16(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+}
+__device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, u32x4& hi, u32x4& lo) {
+  unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+  split2(v0[0], v0[1], h0, l0); split2(v0[2], v0[3], h1, l1);
+  split2(v1[0], v1[1], h2, l2); split2(v1[2], v1[3], h3, l3);
+  hi = (u32x4){h0, h1, h2, h3}; lo = (u32x4){l0, l1, l2, l3};
+}
+__device__ __forceinline__ f32x4 mfma_bf16(const u32x4& a, const u32x4& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a), *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
+}
+// acc += (ah + al) . (bh + bl) without the lo.lo term; small terms first
+__device__ __forceinline__ f32x4 mfma_x3(const u32x4& ah, const u32x4& al, const u32x4& bh, const u32x4& bl, f32x4 c) {
+  c = mfma_bf16(al, bh, c);
+  c = mfma_bf16(ah, bl, c);
+  return mfma_bf16(ah, bh, c);
+}
+
+// GEMM / implicit conv, same operator as k_gemm_f32.  128 x 160 tile (160 divides every SD-v1.4 width: 320, 640, 960, 1280,
+// 2560), BK = 32, 4 waves (2 x 2), each 64 rows x 80 columns = 4 x 5 accumulators in the swapped orientation (weights = A
+// operand).  Staging: thread -> (k chunk tid & 7 = 4 consecutive
+// k, rows tid / 8 + 32 i): a wave-instruction fetches 8 whole 128-byte row segments; the four (activations) + five (weights) float4 are
+// requested TWO k-tiles ahead into one of two register sets, and the tile one ahead is split into hi / lo and written into
+// the other LDS stage in instalments placed between the MFMA groups of the current tile (the split is ~100 VALU
+// operations per thread per k-tile: it has to run under the matrix pipe, not beside it).  LDS: 2 stages x (two images
+// [128][32] + two [160][32]) bf16 with unpadded 64-byte rows = 72 KB (two workgroups per CU); 16-byte chunk c of row r sits at chunk
+// c ^ (3 * ((r >> 2) & 1)): conflict-free for the four lane groups of ds_read_b128 on gfx950 (brute-forced).  One barrier
+// per k-tile.  The three MFMAs of one accumulator are issued four MFMAs apart (term-major order).
+constexpr int XM = 128, XK = 32;
+
+// Every global load of the main loop is UNCONDITIONAL and branch-free (row indices clamped into the matrix: rows past M / N
+// only feed outputs that are never stored; conv halo taps are fetched from a clamped pixel and zeroed by a select; the tile
+// index past the end re-reads the last tile), so the loop body is one basic block and the compiler's s_waitcnt vmcnt(N)
+// leaves the newest tile's requests in flight when the split consumes the older one.
+// XNJ = 5: the 160-column tile; XNJ = 4: 128 columns (GEGLU projections: their value / gate column pairs must not straddle
+// the two wave columns, and their widths are multiples of 128).
+template <bool CONV, int XNJ>
+__global__ void __launch_bounds__(256, 2)
+k_gemm_x3(const GemmArgsF g) {
+  constexpr int XN = 32 * XNJ;
+  __shared__ __attribute__((aligned(16))) unsigned short smem[2][2 * (XM + XN) * XK];   // [stage][A hi | A lo | W hi | W lo]
+  constexpr int IMG_AL = XM * XK, IMG_WH = 2 * XM * XK, IMG_WL = (2 * XM + XN) * XK;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid & 1, wn = wid >> 1;
+  const int tm = blockIdx.x / g.tiles_n, tn = blockIdx.x - tm * g.tiles_n;
+  const int m0 = tm * XM, n0 = tn * XN;
+  const int sc = tid & 7, sr = tid >> 3;                                     // staging role: k chunk, first row
+  int cy[4], cx[4];
+  long abase[4], wbase[XNJ];                                                 // element offset of (row, k chunk) in a / w
+#pragma unroll
+  for (int i = 0; i < XNJ; ++i) wbase[i] = (long)min(n0 + sr + 32 * i, g.N - 1) * g.K + 4 * sc;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int am = min(m0 + sr + 32 * i, g.M - 1);
+    if (CONV) {
+      const int hw = g.Ho * g.Wo;
+      const int pb = am / hw;
+      const int p = am - pb * hw;
+      const int oy = p / g.Wo, ox = p - oy * g.Wo;
+      cy[i] = oy * g.stride + g.conv_off; cx[i] = ox * g.stride + g.conv_off;
+      abase[i] = (long)pb * g.Hs * g.Ws * g.Cin + 4 * sc;
+    } else {
+      abase[i] = (long)am;
+    }
+  }
+  const int Hi = g.upsample ? 2 * g.Hs : g.Hs, Wi = g.upsample ? 2 * g.Ws : g.Ws;
+  const int ld1 = g.K1, ld2 = g.K - g.K1;
+  const int nkt = g.K / XK;
+
+  auto load_a = [&](int kt, f32x4 (&v)[4]) {
+    const int k0 = min(kt, nkt - 1) * XK;
+    if (CONV) {
+      const int tap = k0 / g.Cin, c0 = k0 - tap * g.Cin;                     // Cin % 64 == 0: a 32-wide k-tile lies inside one tap
+      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int y = cy[i] + dy, x = cx[i] + dx;
+        const bool in = y >= 0 && y < Hi && x >= 0 && x < Wi;
+        const int yc = min(max(y, 0), Hi - 1), xc = min(max(x, 0), Wi - 1);
+        const int sy = g.upsample ? yc >> 1 : yc, sx = g.upsample ? xc >> 1 : xc;
+        const f32x4 t = *reinterpret_cast<const f32x4*>(g.a + abase[i] + ((long)sy * g.Ws + sx) * g.Cin + c0);
+        v[i] = in ? t : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    } else {
+      const bool first = k0 < g.K1;                                          // wave-uniform: which of the two sources
+      const float* src = first ? g.a : g.a2;
+      const long ld = first ? ld1 : ld2;
+      const int kk = (first ? k0 : k0 - g.K1) + 4 * sc;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const f32x4*>(src + abase[i] * ld + kk);
+    }
+  };
+  auto load_w = [&](int kt, f32x4 (&v)[XNJ]) {
+    const int k0 = min(kt, nkt - 1) * XK;
+#pragma unroll
+    for (int i = 0; i < XNJ; ++i) v[i] = *reinterpret_cast<const f32x4*>(g.w + wbase[i] + k0);
+  };
+  // LDS element offset of (row r, k chunk of 8 elements q) under the swizzle
+  auto at = [](int r, int q) { return r * XK + ((q ^ (3 * ((r >> 2) & 1))) << 3); };
+  // one instalment of the split: one float4 (4 consecutive k of row sr + 32 i) -> the hi and lo images of `stage`
+  auto put = [&](int stage, int img_hi, int img_lo, const f32x4& v, int i) {
+    unsigned h0, l0, h1, l1;
+    split2(v[0], v[1], h0, l0); split2(v[2], v[3], h1, l1);
+    const int o = at(sr + 32 * i, sc >> 1) + 4 * (sc & 1);
+    *reinterpret_cast<uint2*>(&smem[stage][img_hi + o]) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(&smem[stage][img_lo + o]) = make_uint2(l0, l1);
+  };
+
+  f32x4 acc[4][XNJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < XNJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fq = lane >> 4;
+  f32x4 ra0[4], rw0[XNJ], ra1[4], rw1[XNJ];                                  // register set t & 1 carries k-tile t
+  load_a(0, ra0); load_w(0, rw0);
+  load_a(1, ra1); load_w(1, rw1);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) put(0, 0, IMG_AL, ra0[i], i);
+#pragma unroll
+  for (int i = 0; i < XNJ; ++i) put(0, IMG_WH, IMG_WL, rw0[i], i);
+  __syncthreads();
+
+  // k-tile kt from LDS stage CUR; meanwhile tile kt + 2 is requested into the register set tile kt has vacated and tile
+  // kt + 1 (register set NXT, requested one iteration ago) is split into stage NXT between the MFMA groups (past the last
+  // tile both are harmless repeats of the last tile into a stage nobody reads)
+  auto step = [&](auto CURc, int kt, f32x4 (&rac)[4], f32x4 (&rwc)[XNJ], f32x4 (&ran)[4], f32x4 (&rwn)[XNJ]) {
+    constexpr int CUR = decltype(CURc)::value, NXT = CUR ^ 1;
+    load_a(kt + 2, rac); load_w(kt + 2, rwc);
+    u32x4 ah[4], al[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int o = at(wm * 64 + i * 16 + fr, fq);
+      ah[i] = *reinterpret_cast<const u32x4*>(&smem[CUR][o]); al[i] = *reinterpret_cast<const u32x4*>(&smem[CUR][IMG_AL + o]);
+    }
+#pragma unroll
+    for (int j = 0; j < XNJ; ++j) {
+      const int o = at(wn * (XN / 2) + j * 16 + fr, fq);
+      const u32x4 wh = *reinterpret_cast<const u32x4*>(&smem[CUR][IMG_WH + o]), wl = *reinterpret_cast<const u32x4*>(&smem[CUR][IMG_WL + o]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][j] = mfma_bf16(wl, ah[i], acc[i][j]);
+      if (j < 4) put(NXT, 0, IMG_AL, ran[j], j);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][j] = mfma_bf16(wh, al[i], acc[i][j]);
+      put(NXT, IMG_WH, IMG_WL, rwn[j], j);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][j] = mfma_bf16(wh, ah[i], acc[i][j]);
+    }
+    __syncthreads();
+  };
+  for (int kt = 0; kt < nkt; kt += 2) {
+    step(std::integral_constant<int, 0>{}, kt, ra0, rw0, ra1, rw1);
+    if (kt + 1 < nkt) step(std::integral_constant<int, 1>{}, kt + 1, ra1, rw1, ra0, rw0);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) gemm_row_epilogue<XNJ>(g, acc[i], m0 + wm * 64 + i * 16 + fr, n0 + wn * (XN / 2), fq);
+}
+
+// Attention, flash form, bf16x3 products.  Workgroup = 4 waves = 64 QS queries of one (batch, head), wave w owning QS sets of 16
+// (query = block + 64 s + 16 w + lane % 16): every K / V fragment read from LDS feeds QS MFMAs and a staged tile serves
+// 64 QS queries (the f32 K / V tiles are twice the bytes of the 16-bit kernels': with 64 queries per workgroup the launch
+// was bound by re-fetching them).  Keys / values arrive in tiles of 32 (prefetched one tile ahead into registers, split into
+// hi / lo on their way into LDS).  Per query set:
+//   S^T[key][query] = K . Q^T per 16-key half tile: A = K fragment (8 consecutive dims of one key), B = Q fragment (scaled,
+//     split once per kernel); a lane ends with 4 keys' scores of ONE query -- the softmax bookkeeping of k_attention_f32;
+//   O^T[dim][query] += V^T . P^T as ONE 32-key contraction per 16-dim block: k slot (lane group g, s) <-> key 4 g + s (s < 4)
+//     or 16 + 4 g + (s - 4): exactly the eight probabilities the lane already holds, so P goes from the score accumulators to
+//     the B operand in registers; V^T sits in LDS [dim][32 key slots] in that slot order (transposed and permuted by staging).
+template <int HD, int QS>
+__global__ void __launch_bounds__(256)
+k_attention_x3(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, float* __restrict__ out,
+               int heads, int nq, int nk, int ldq, int ldk, int ldv, int ldo, float scale) {
+  constexpr int NB = (HD + 31) / 32, HDP = NB * 32;                         // score product: head dim in blocks of 32
+  constexpr int DB = (HD + 15) / 16, DP = DB * 16;                          // output dims in blocks of 16
+  constexpr int LK = HDP + 8, LV = 40;                                      // LDS row lengths (bf16 elements)
+  constexpr int NV4 = 32 * (HD / 4), NI = (NV4 + 255) / 256;                // float4 pieces of one K (or V) tile per thread
+  constexpr int QB = 64 * QS;
+  __shared__ __attribute__((aligned(16))) unsigned short sKh[32 * LK], sKl[32 * LK], sVh[DP * LV], sVl[DP * LV];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int qblocks = (nq + QB - 1) / QB;
+  const int bh = blockIdx.x / qblocks, qb = blockIdx.x - bh * qblocks;
+  const int b = bh / heads, h = bh - b * heads;
+  // scores are kept in log2 units (log2 e folded into the Q scale): the exponentials are single v_exp_f32 instructions (the
+  // library expf costs ~25 VALU operations; with 9 of them per 32 keys per query the kernel was bound by vector issue)
+  const float scale2 = scale * 1.4426950408889634f;
+  u32x4 qh[QS][NB], ql[QS][NB];                                             // B operand of block n: Q[query][32 n + 8 fq .. + 7] * scale
+  f32x4 o[QS][DB];
+  float mrun[QS], lrun[QS];
+#pragma unroll
+  for (int s = 0; s < QS; ++s) {
+    const int qi = qb * QB + 64 * s + wid * 16 + fr;
+    const float* qp = q + ((long)b * nq + (qi < nq ? qi : 0)) * ldq + h * HD;
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      const int d0 = 32 * n + 8 * fq;
+      f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = a;
+      if (qi < nq && d0 < HD) { a = *reinterpret_cast<const f32x4*>(qp + d0) * scale2; c = *reinterpret_cast<const f32x4*>(qp + d0 + 4) * scale2; }
+      split8(a, c, qh[s][n], ql[s][n]);
+    }
+#pragma unroll
+    for (int d = 0; d < DB; ++d) o[s][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    mrun[s] = -INFINITY; lrun[s] = 0.f;
+  }
+  for (int i = tid; i < 32 * LK; i += 256) { sKh[i] = 0; sKl[i] = 0; }      // padding dims HD..HDP stay zero
+  for (int i = tid; i < DP * LV; i += 256) { sVh[i] = 0; sVl[i] = 0; }      // padding dims HD..DP stay zero
+  const float* kb = k + (long)b * nk * ldk + h * HD;
+  const float* vb = v + (long)b * nk * ldv + h * HD;
+  f32x4 rk[NI], rv[NI];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const int i = tid + it * 256;
+      rk[it] = (f32x4){0.f, 0.f, 0.f, 0.f}; rv[it] = rk[it];
+      if (i < NV4) {
+        const int r = i / (HD / 4), c4 = (i - r * (HD / 4)) * 4;
+        if (k0 + r < nk) {
+          rk[it] = *reinterpret_cast<const f32x4*>(kb + (long)(k0 + r) * ldk + c4);
+          rv[it] = *reinterpret_cast<const f32x4*>(vb + (long)(k0 + r) * ldv + c4);
+        }
+      }
+    }
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < nk; k0 += 32) {
+    __syncthreads();                                                       // previous tile fully consumed (and the zero fill done)
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const int i = tid + it * 256;
+      if (i < NV4) {
+        const int r = i / (HD / 4), c4 = (i - r * (HD / 4)) * 4;
+        unsigned h0, l0, h1, l1;
+        split2(rk[it][0], rk[it][1], h0, l0); split2(rk[it][2], rk[it][3], h1, l1);
+        *reinterpret_cast<uint2*>(&sKh[r * LK + c4]) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(&sKl[r * LK + c4]) = make_uint2(l0, l1);
+        split2(rv[it][0], rv[it][1], h0, l0); split2(rv[it][2], rv[it][3], h1, l1);
+        const int slot = 8 * ((r & 15) >> 2) + 4 * (r >> 4) + (r & 3);     // key 16 t + 4 g + e -> slot 8 g + 4 t + e
+        sVh[(c4 + 0) * LV + slot] = (unsigned short)h0; sVh[(c4 + 1) * LV + slot] = (unsigned short)(h0 >> 16);
+        sVh[(c4 + 2) * LV + slot] = (unsigned short)h1; sVh[(c4 + 3) * LV + slot] = (unsigned short)(h1 >> 16);
+        sVl[(c4 + 0) * LV + slot] = (unsigned short)l0; sVl[(c4 + 1) * LV + slot] = (unsigned short)(l0 >> 16);
+        sVl[(c4 + 2) * LV + slot] = (unsigned short)l1; sVl[(c4 + 3) * LV + slot] = (unsigned short)(l1 >> 16);
+      }
+    }
+    __syncthreads();
+    if (k0 + 32 < nk) fetch(k0 + 32);                                      // next tile in flight under the MFMAs
+    f32x4 st[QS][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int s = 0; s < QS; ++s) st[s][t] = (f32x4){0.f, 0.f, 0.f, 0.f};  // register e <-> key k0 + 16 t + 4 fq + e, query fr
+#pragma unroll
+      for (int n = 0; n < NB; ++n) {
+        const int off = (16 * t + fr) * LK + 32 * n + 8 * fq;
+        const u32x4 kh = *reinterpret_cast<const u32x4*>(&sKh[off]), kl = *reinterpret_cast<const u32x4*>(&sKl[off]);
+#pragma unroll
+        for (int s = 0; s < QS; ++s) st[s][t] = mfma_bf16(kl, qh[s][n], st[s][t]);
+#pragma unroll
+        for (int s = 0; s < QS; ++s) st[s][t] = mfma_bf16(kh, ql[s][n], st[s][t]);
+#pragma unroll
+        for (int s = 0; s < QS; ++s) st[s][t] = mfma_bf16(kh, qh[s][n], st[s][t]);
+      }
+    }
+    u32x4 ph[QS], pl[QS];
+#pragma unroll
+    for (int s = 0; s < QS; ++s) {
+      if (k0 + 32 > nk) {                                                   // ragged last tile (wave-uniform)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (k0 + 16 * t + 4 * fq + e >= nk) st[s][t][e] = -INFINITY;
+      }
+      float tmax = fmaxf(fmaxf(fmaxf(st[s][0][0], st[s][0][1]), fmaxf(st[s][0][2], st[s][0][3])),
+                         fmaxf(fmaxf(st[s][1][0], st[s][1][1]), fmaxf(st[s][1][2], st[s][1][3])));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float mnew = fmaxf(mrun[s], tmax);
+      const float alpha = __builtin_amdgcn_exp2f(mrun[s] - mnew);             // first tile: 2^(-inf) = 0
+      float psum = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { st[s][t][e] = __builtin_amdgcn_exp2f(st[s][t][e] - mnew); psum += st[s][t][e]; }
+      psum += __shfl_xor(psum, 16, 64);
+      psum += __shfl_xor(psum, 32, 64);
+      lrun[s] = lrun[s] * alpha + psum;
+      mrun[s] = mnew;
+      split8(st[s][0], st[s][1], ph[s], pl[s]);                             // slots 8 fq + 0..3 = half tile 0, + 4..7 = half tile 1
+#pragma unroll
+      for (int d = 0; d < DB; ++d) o[s][d] *= alpha;
+    }
+#pragma unroll
+    for (int d = 0; d < DB; ++d) {
+      const int off = (d * 16 + fr) * LV + 8 * fq;
+      const u32x4 vh = *reinterpret_cast<const u32x4*>(&sVh[off]), vl = *reinterpret_cast<const u32x4*>(&sVl[off]);
+#pragma unroll
+      for (int s = 0; s < QS; ++s) o[s][d] = mfma_bf16(vl, ph[s], o[s][d]);
+#pragma unroll
+      for (int s = 0; s < QS; ++s) o[s][d] = mfma_bf16(vh, pl[s], o[s][d]);
+#pragma unroll
+      for (int s = 0; s < QS; ++s) o[s][d] = mfma_bf16(vh, ph[s], o[s][d]);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < QS; ++s) {
+    const int qi = qb * QB + 64 * s + wid * 16 + fr;
+    if (qi >= nq) continue;
+    const float inv = 1.0f / lrun[s];
+    float* op = out + ((long)b * nq + qi) * ldo + h * HD;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int dim = d * 16 + 4 * fq + e;
+        if (dim < HD) op[dim] = o[s][d][e] * inv;
+      }
+  }
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
 
-extern "C" int sdn_gemm_f32(const sdn_gemm_desc* d, const void* a, const void* a2, const void* w, const float* bias,
+// x3 = 0: f32-input MFMA (k_gemm_f32); 1: bf16x3 split products (k_gemm_x3).  Same validation, same GemmArgsF.
+static int gemm_f32_storage(int x3, const sdn_gemm_desc* d, const void* a, const void* a2, const void* w, const float* bias,
                             const float* rowbias, const float* rowgate, const void* residual, void* out, void* stream) {
   if (!d || !a || !w || !out) return SDN_E_INVALID;
   if (d->M < 0 || d->N <= 0 || d->K <= 0 || (d->K % 64) != 0 || (d->N % 32) != 0 || d->split_k > 1) return SDN_E_INVALID;
@@ -378,11 +726,36 @@ extern "C" int sdn_gemm_f32(const sdn_gemm_desc* d, const void* a, const void* a
   g.ld_rowgate = d->ld_rowgate; g.residual_bcast = d->residual_bcast; g.n_valid = n_valid;
   g.ldc = d->ldc > 0 ? d->ldc : (d->act == SDN_ACT_GEGLU ? d->N / 2 : n_valid);
   if (d->act == SDN_ACT_GEGLU && (g.ldc & 3)) return SDN_E_INVALID;
+  if (x3 && d->M >= 64) {                                                    // (a handful of rows: the small f32 tile is as fast and exact)
+    const bool wide = d->act != SDN_ACT_GEGLU && (d->N % 160 == 0 || d->N % 128 != 0);
+    const int xn = wide ? 160 : 128;
+    g.tiles_n = (d->N + xn - 1) / xn;
+    const long tiles = (long)((d->M + XM - 1) / XM) * g.tiles_n;
+    if (tiles > 0x7fffffffL) return SDN_E_INVALID;
+    const dim3 grid((unsigned)tiles), block(256);
+    if (g.a_mode == 1) {
+      if (wide) hipLaunchKernelGGL((k_gemm_x3<true, 5>), grid, block, 0, (hipStream_t)stream, g);
+      else hipLaunchKernelGGL((k_gemm_x3<true, 4>), grid, block, 0, (hipStream_t)stream, g);
+    } else {
+      if (wide) hipLaunchKernelGGL((k_gemm_x3<false, 5>), grid, block, 0, (hipStream_t)stream, g);
+      else hipLaunchKernelGGL((k_gemm_x3<false, 4>), grid, block, 0, (hipStream_t)stream, g);
+    }
+    return sdn_launch_status();
+  }
   g.tiles_n = (d->N + BN - 1) / BN;
   const long tiles = (long)((d->M + BM - 1) / BM) * g.tiles_n;
   if (tiles > 0x7fffffffL) return SDN_E_INVALID;
   hipLaunchKernelGGL(k_gemm_f32, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, g);
   return sdn_launch_status();
+}
+
+extern "C" int sdn_gemm_f32(const sdn_gemm_desc* d, const void* a, const void* a2, const void* w, const float* bias,
+                            const float* rowbias, const float* rowgate, const void* residual, void* out, void* stream) {
+  return gemm_f32_storage(0, d, a, a2, w, bias, rowbias, rowgate, residual, out, stream);
+}
+extern "C" int sdn_gemm_x3(const sdn_gemm_desc* d, const void* a, const void* a2, const void* w, const float* bias,
+                           const float* rowbias, const float* rowgate, const void* residual, void* out, void* stream) {
+  return gemm_f32_storage(1, d, a, a2, w, bias, rowbias, rowgate, residual, out, stream);
 }
 
 extern "C" int sdn_groupnorm_f32(const void* x, const void* x2, int32_t batch, int32_t hw, int32_t c1, int32_t c2,
@@ -407,27 +780,52 @@ extern "C" int sdn_layernorm_f32(const void* x, int64_t rows, int32_t c, float e
   return sdn_launch_status();
 }
 
-extern "C" int sdn_attention_f32(const void* q, const void* k, const void* v, void* out, int32_t batch, int32_t heads,
+static int attention_f32_storage(int x3, const void* q, const void* k, const void* v, void* out, int32_t batch, int32_t heads,
                                  int32_t nq, int32_t nk, int32_t head_dim, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo,
                                  float scale, void* stream) {
   if (!q || !k || !v || !out || batch < 0 || heads <= 0 || nq <= 0 || nk <= 0) return SDN_E_INVALID;
   if (!al16(k) || !al16(v) || (ldk & 3) || (ldv & 3)) return SDN_E_INVALID;
+  if (x3 && (!al16(q) || (ldq & 3))) return SDN_E_INVALID;                   // the split kernel fetches Q as float4
   if (batch == 0) return SDN_OK;
   const long grid = (long)batch * heads * ((nq + 63) / 64);
   if (grid > 0x7fffffffL) return SDN_E_INVALID;
   const float* qf = (const float*)q; const float* kf = (const float*)k; const float* vf = (const float*)v;
-#define SDN_ATTN_F32(HD)                                                                                              \
-  hipLaunchKernelGGL((k_attention_f32<HD>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, qf, kf, vf,      \
-                     (float*)out, heads, nq, nk, ldq, ldk, ldv, ldo, scale)
+  // query sets per wave of the split kernel: as many as the registers hold, but not more than the query count fills
+  static const int qs_cap = getenv("SDN_X3_QS") ? atoi(getenv("SDN_X3_QS")) : 2;      /* tuning knob (tools/bench_precision.py) */
+#define SDN_ATTN_F32(HD, QSMAX)                                                                                       \
+  if (x3) {                                                                                                           \
+    const int QS_ = QSMAX < qs_cap ? QSMAX : qs_cap;                                                                                        \
+    if (QS_ >= 4 && nq >= 256)                                                                                        \
+      hipLaunchKernelGGL((k_attention_x3<HD, (QSMAX >= 4 ? 4 : 1)>), dim3((unsigned)((long)batch * heads * ((nq + 255) / 256))),  \
+                         dim3(256), 0, (hipStream_t)stream, qf, kf, vf, (float*)out, heads, nq, nk, ldq, ldk, ldv, ldo, scale); \
+    else if (QS_ >= 2 && nq >= 128)                                                                                   \
+      hipLaunchKernelGGL((k_attention_x3<HD, (QSMAX >= 2 ? 2 : 1)>), dim3((unsigned)((long)batch * heads * ((nq + 127) / 128))),  \
+                         dim3(256), 0, (hipStream_t)stream, qf, kf, vf, (float*)out, heads, nq, nk, ldq, ldk, ldv, ldo, scale); \
+    else                                                                                                              \
+      hipLaunchKernelGGL((k_attention_x3<HD, 1>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, qf, kf, vf, \
+                         (float*)out, heads, nq, nk, ldq, ldk, ldv, ldo, scale);                                      \
+  } else hipLaunchKernelGGL((k_attention_f32<HD>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, qf, kf, vf, \
+                            (float*)out, heads, nq, nk, ldq, ldk, ldv, ldo, scale)
   switch (head_dim) {
-    case 40: SDN_ATTN_F32(40); break;
-    case 64: SDN_ATTN_F32(64); break;
-    case 80: SDN_ATTN_F32(80); break;
-    case 160: SDN_ATTN_F32(160); break;
+    case 40: SDN_ATTN_F32(40, 4); break;
+    case 64: SDN_ATTN_F32(64, 4); break;
+    case 80: SDN_ATTN_F32(80, 2); break;
+    case 160: SDN_ATTN_F32(160, 1); break;
     default: return SDN_E_INVALID;
   }
 #undef SDN_ATTN_F32
   return sdn_launch_status();
+}
+
+extern "C" int sdn_attention_f32(const void* q, const void* k, const void* v, void* out, int32_t batch, int32_t heads,
+                                 int32_t nq, int32_t nk, int32_t head_dim, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo,
+                                 float scale, void* stream) {
+  return attention_f32_storage(0, q, k, v, out, batch, heads, nq, nk, head_dim, ldq, ldk, ldv, ldo, scale, stream);
+}
+extern "C" int sdn_attention_x3(const void* q, const void* k, const void* v, void* out, int32_t batch, int32_t heads,
+                                int32_t nq, int32_t nk, int32_t head_dim, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo,
+                                float scale, void* stream) {
+  return attention_f32_storage(1, q, k, v, out, batch, heads, nq, nk, head_dim, ldq, ldk, ldv, ldo, scale, stream);
 }
 
 extern "C" int sdn_conv_in_f32(const float* latents_nchw, const void* w, const float* bias, int32_t batch, int32_t cin,

@@ -1174,7 +1174,7 @@ Plan* get_plan(sdn_unet* u, int batch) {
   p.batch = batch;
   Builder b{u, &p};
   b.B = batch;
-  b.es = (!u->is_clip && !u->is_vae && !u->is_mmdit && u->cfg.dtype == 2) ? 4 : 2;
+  b.es = (!u->is_clip && !u->is_vae && !u->is_mmdit && u->cfg.dtype >= 2) ? 4 : 2;
   if (u->is_clip) b.build_clip(); else if (u->is_vae_encoder) b.build_vae_encoder(); else if (u->is_vae) b.build_vae(); else if (u->is_mmdit) b.build_mmdit(); else b.build();
   return &p;
 }
@@ -1201,7 +1201,7 @@ int sdn_unet_create(const sdn_unet_config* cfg, sdn_unet** out) {
   if (cfg->n_levels < 1 || cfg->n_levels > 4 || cfg->layers_per_block < 1 || cfg->n_heads <= 0 ||
       cfg->in_channels <= 0 || cfg->in_channels > 16 || cfg->out_channels <= 0 || cfg->out_channels > 32 ||
       cfg->sample_size <= 0 || (cfg->sample_size % (1 << (cfg->n_levels - 1))) != 0 || cfg->cross_dim % 64 != 0 ||
-      cfg->text_len <= 0 || cfg->norm_groups <= 0 || cfg->norm_groups > 64 || cfg->dtype < 0 || cfg->dtype > 2 ||
+      cfg->text_len <= 0 || cfg->norm_groups <= 0 || cfg->norm_groups > 64 || cfg->dtype < 0 || cfg->dtype > 3 ||
       cfg->latent_repeat < 0 || cfg->latent_repeat > 8)
     return SDN_E_INVALID;
   for (int i = 0; i < cfg->n_levels; ++i) {
@@ -1217,7 +1217,7 @@ int sdn_unet_create(const sdn_unet_config* cfg, sdn_unet** out) {
   }
   sdn_unet* u = new sdn_unet();
   u->cfg = *cfg;
-  if (cfg->dtype == 2) { u->gn_fuse = false; u->ln_fold = false; u->ff_fuse = false; }   // fp32 precision mode: the plain operator chain (sdn_f32.hip)
+  if (cfg->dtype >= 2) { u->gn_fuse = false; u->ln_fold = false; u->ff_fuse = false; }   // fp32-storage modes: the plain operator chain (sdn_f32.hip)
   get_plan(u, cfg->latent_repeat > 1 ? cfg->latent_repeat : 1);   // registers the parameter manifest (batch-independent)
   *out = u;
   return SDN_OK;
@@ -1425,7 +1425,8 @@ static int launch_ops(sdn_unet* u, Plan* p, const char* W, const char* WS, const
   auto P = [&](const Ref& r) { return resolve(r, W, WS, L, T, O, PL); };
   size_t opi = 0;
   const bool f16 = (u->is_mmdit ? u->mcfg.dtype : u->cfg.dtype) == 1;       // (VAE / CLIP creators mirror dtype into cfg)
-  const bool f32 = !u->is_mmdit && u->cfg.dtype == 2;                        // fp32 precision mode (SD-v1.4 UNet plans only)
+  const bool f32 = !u->is_mmdit && u->cfg.dtype >= 2;                        // fp32-storage modes (SD-v1.4 UNet plans only)
+  const bool x3 = f32 && u->cfg.dtype == 3;                                  // ... with bf16x3 contractions (sdn_gemm_x3 / sdn_attention_x3)
   for (const Op& o : p->ops) {
     int rc = SDN_OK;
     if (prof) (void)hipEventRecord(u->ev[2 * opi], (hipStream_t)stream);
@@ -1439,8 +1440,8 @@ static int launch_ops(sdn_unet* u, Plan* p, const char* W, const char* WS, const
           break;
         case OP_GEMM:
           rc = (o.ln || o.gd.split_k > 1) ? SDN_E_INVALID
-               : sdn_gemm_f32(&o.gd, P(o.a), P(o.a2), P(o.w), (const float*)P(o.bias), (const float*)P(o.rowbias),
-                              (const float*)P(o.rowgate), P(o.residual), (void*)P(o.out), stream);
+               : (x3 ? sdn_gemm_x3 : sdn_gemm_f32)(&o.gd, P(o.a), P(o.a2), P(o.w), (const float*)P(o.bias), (const float*)P(o.rowbias),
+                                                   (const float*)P(o.rowgate), P(o.residual), (void*)P(o.out), stream);
           break;
         case OP_GN:
           rc = sdn_groupnorm_f32(P(o.a), P(o.a2), o.batch, o.hw, o.c1, o.c2, o.groups, o.eps, o.silu, (const float*)P(o.w),
@@ -1452,8 +1453,8 @@ static int launch_ops(sdn_unet* u, Plan* p, const char* W, const char* WS, const
           break;
         case OP_ATTN:
           rc = o.n1 > 0 ? SDN_E_INVALID
-                        : sdn_attention_f32(P(o.a), P(o.k), P(o.v), (void*)P(o.out), o.batch, o.heads, o.nq, o.nk, o.hd, o.ldq, o.ldk,
-                                            o.ldv, o.ldo, o.scale, stream);
+                        : (x3 ? sdn_attention_x3 : sdn_attention_f32)(P(o.a), P(o.k), P(o.v), (void*)P(o.out), o.batch, o.heads, o.nq, o.nk,
+                                                                      o.hd, o.ldq, o.ldk, o.ldv, o.ldo, o.scale, stream);
           break;
         case OP_REPEAT:
           rc = sdn_repeat(P(o.a), (size_t)o.rows, o.c1, (void*)P(o.out), stream);
@@ -1636,7 +1637,7 @@ static void drop_graphs(sdn_unet* u) {
 
 void sdn_unet_set_split_k(sdn_unet* u, int32_t on) {
   if (!u || u->split_k == (on != 0)) return;
-  if (!u->is_mmdit && !u->is_vae && !u->is_clip && u->cfg.dtype == 2) return;   // fp32 mode has no split-K form
+  if (!u->is_mmdit && !u->is_vae && !u->is_clip && u->cfg.dtype >= 2) return;   // fp32-storage modes have no split-K form
   u->split_k = on != 0;
   drop_graphs(u);
   u->plans.clear();                                            // plans are rebuilt with / without partial buffers

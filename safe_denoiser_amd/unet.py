@@ -43,13 +43,21 @@ def _interleave16(t: torch.Tensor) -> torch.Tensor:
 
 
 class UNet2DConditionModel:
-    def __init__(self, text_len: int = 77, dtype=torch.bfloat16, latent_repeat: int = 1, **config):
-        """latent_repeat = r > 1: the engine-side form of `torch.cat([latents] * r)` (classifier-free guidance): `sample`
+    def __init__(self, text_len: int = 77, dtype=torch.bfloat16, latent_repeat: int = 1, precision: str | None = None, **config):
+        """precision = "bf16x3" (with dtype=torch.float32, or alone): fp32 storage with split-operand contractions on the bf16
+        matrix cores (sdn_unet_config.dtype 3, sdn_gemm_x3) -- the mode that meets the north star's 1e-3 at a multiple of the
+        f32-MFMA plan's speed.
+        latent_repeat = r > 1: the engine-side form of `torch.cat([latents] * r)` (classifier-free guidance): `sample`
         then holds B / r latents, `encoder_hidden_states` stays [B] branch-major, and everything up to the first
         cross-attention is computed once per latent (sdn_unet_config.latent_repeat).  Bit-identical results."""
+        if precision not in (None, "fp32", "bf16x3"):
+            raise _lib.SdnError('precision must be None, "fp32" or "bf16x3"')
+        if precision is not None:
+            dtype = torch.float32                                   # both precision modes store f32
         if dtype not in (torch.bfloat16, torch.float16, torch.float32):
             raise _lib.SdnError("storage dtype must be torch.bfloat16, torch.float16 or torch.float32 (the precision mode)")
         self.dtype = dtype
+        self.precision = precision or ("fp32" if dtype == torch.float32 else None)
         self.latent_repeat = max(1, int(latent_repeat))
         cfg = dict(SD14_CONFIG)
         cfg.update(config)
@@ -66,7 +74,7 @@ class UNet2DConditionModel:
                             layers_per_block=cfg["layers_per_block"], n_heads=cfg["attention_head_dim"],
                             cross_dim=cfg["cross_attention_dim"], text_len=text_len,
                             norm_groups=cfg["norm_num_groups"],
-                            dtype={torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}[dtype],
+                            dtype=3 if self.precision == "bf16x3" else {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}[dtype],
                             latent_repeat=self.latent_repeat)
         h = C.c_void_p()
         _lib.check(_lib.lib().sdn_unet_create(C.byref(c), C.byref(h)), "sdn_unet_create")

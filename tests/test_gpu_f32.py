@@ -20,6 +20,21 @@ from tests_support import ops
 
 pytestmark = pytest.mark.gpu
 TOL = 2e-5
+# the bf16x3 contraction mode (sdn_gemm_x3 / sdn_attention_x3: operands split into bf16 hi + lo, 16 mantissa bits, three
+# MFMAs per product): same operators on the same f32 storage; per-operator bound 3e-5 (measured ~1e-5: 2^-17 per operand,
+# averaged over the contraction), per network 1e-4, loop 1e-3 (the north star)
+TOL_X3 = 3e-5
+
+
+@pytest.fixture(params=["f32", "x3"])
+def mode(request):
+    ops.X3 = request.param == "x3"
+    yield request.param
+    ops.X3 = False
+
+
+def tol(mode):
+    return TOL_X3 if mode == "x3" else TOL
 
 
 def rnd(*shape, seed=0, scale=1.0):
@@ -31,8 +46,9 @@ def rel_l2(a, b):
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 320, 320), (100, 32, 64), (2, 1280, 320), (77 * 3, 640, 768), (1000, 960, 1280)])
-def test_gemm_f32_epilogues(M, N, K):
+@pytest.mark.parametrize("M,N,K", [(128, 320, 320), (100, 32, 64), (2, 1280, 320), (77 * 3, 640, 768), (1000, 960, 1280), (300, 2560, 320)])
+def test_gemm_f32_epilogues(M, N, K, mode):
+    TOL = tol(mode)
     a, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
     bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
     ref = a @ w.T + bias
@@ -44,7 +60,8 @@ def test_gemm_f32_epilogues(M, N, K):
         assert rel_l2(ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), n_valid=nv), ref[:, :nv]) <= TOL
 
 
-def test_gemm_f32_identity_asymmetric_and_dual_source_rowbias_nchw():
+def test_gemm_f32_identity_asymmetric_and_dual_source_rowbias_nchw(mode):
+    TOL = tol(mode)
     K = 128
     w = (torch.arange(160 * K).reshape(160, K) % 251 - 125).float()
     assert torch.equal(ops.gemm(torch.eye(K).cuda(), w.cuda()).cpu(), w.T.contiguous())      # exact: catches a transposed C
@@ -59,7 +76,8 @@ def test_gemm_f32_identity_asymmetric_and_dual_source_rowbias_nchw():
     assert rel_l2(out, ref[:, :, :N - 4].permute(0, 2, 1)) <= TOL
 
 
-def test_gemm_f32_geglu():
+def test_gemm_f32_geglu(mode):
+    TOL = tol(mode)
     M, C = 200, 320
     x, w, b = rnd(M, C, seed=12), rnd(8 * C, C, seed=13, scale=C ** -0.5), rnd(8 * C, seed=14)
     val, gate = (x @ w.T + b).chunk(2, -1)
@@ -70,7 +88,8 @@ def test_gemm_f32_geglu():
 @pytest.mark.parametrize("B,H,Cin,Cout,stride,ups,asym", [(2, 16, 320, 320, 1, 0, 0), (1, 16, 640, 320, 2, 0, 0),
                                                           (2, 8, 320, 640, 1, 1, 0), (3, 4, 64, 96, 1, 0, 0),
                                                           (2, 16, 128, 128, 2, 0, 1)])
-def test_conv3x3_f32(B, H, Cin, Cout, stride, ups, asym):
+def test_conv3x3_f32(B, H, Cin, Cout, stride, ups, asym, mode):
+    TOL = tol(mode)
     x, w, bias = rnd(B, Cin, H, H, seed=15), rnd(Cout, Cin, 3, 3, seed=16, scale=(9 * Cin) ** -0.5), rnd(Cout, seed=17)
     xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if ups else x
     ref = F.conv2d(F.pad(xin, (0, 1, 0, 1)), w, bias, stride=2) if asym else F.conv2d(xin, w, bias, stride=stride, padding=1)
@@ -97,7 +116,8 @@ def test_norms_f32():
 
 
 @pytest.mark.parametrize("nq,nk,d", [(256, 256, 40), (100, 77, 80), (64, 333, 160), (200, 77, 64)])
-def test_attention_f32(nq, nk, d):
+def test_attention_f32(nq, nk, d, mode):
+    TOL = tol(mode)
     B, H = 2, 8
     q, kv = rnd(B, nq, H * d, seed=30), rnd(B, nk, 2 * H * d, seed=31)       # k | v fused along the columns, as in the plan
     sp = lambda t: t.reshape(B, -1, H, d).transpose(1, 2).double()
@@ -120,9 +140,9 @@ SMALL_O = dict(block_out_channels=(320, 640), level_has_attn=(True, False), laye
                cross_dim=768, sample_size=16)
 
 
-@pytest.mark.parametrize("rep", [1, 2])
-def test_small_unet_f32_plan_matches_pure_fp32_oracle(rep):
-    u = UNet2DConditionModel(text_len=77, dtype=torch.float32, latent_repeat=rep, **SMALL)
+@pytest.mark.parametrize("rep,precision", [(1, "fp32"), (2, "fp32"), (1, "bf16x3"), (2, "bf16x3")])
+def test_small_unet_f32_plan_matches_pure_fp32_oracle(rep, precision):
+    u = UNet2DConditionModel(text_len=77, precision=precision, latent_repeat=rep, **SMALL)
     sd = u.synthetic_state_dict(11)
     u.load_state_dict(sd)
     x, E = rnd(2, 4, 16, 16, seed=1), rnd(4, 77, 768, seed=2)
@@ -130,7 +150,7 @@ def test_small_unet_f32_plan_matches_pure_fp32_oracle(rep):
     out = u((x if rep == 2 else xin).cuda(), 801.0, encoder_hidden_states=E.cuda()).sample
     ref = OracleUNet(sd, SMALL_O, act_dtype=None)(xin, 801.0, E)
     r = rel_l2(out, ref)
-    print(f"small UNet, fp32 plan (latent_repeat {rep}) vs pure-fp32 oracle: rel L2 {r:.2e}")
+    print(f"small UNet, {precision} plan (latent_repeat {rep}) vs pure-fp32 oracle: rel L2 {r:.2e}")
     assert r <= 1e-4
 
 
@@ -141,70 +161,95 @@ def _proc(refs, tmp_path, **params):
                                      n_embed=4, proj_ref_path=path, cache_proj_ref=True, **params)
 
 
-def test_full_sd14_fp32_plan_forward_and_10_step_loop_meet_the_north_star_tolerance(tmp_path):
-    """Full SD-v1.4 (859.5 M parameters, 64x64x4 latents), 1 prompt, CFG 7.5, DDPM, num_inference_steps=10 (t = 901, 801
-    in the repellency window), noise from a tape, repellency against 64 channel-normalised references with the gate
-    placed so that it fires: final latents of the HIP path vs the pure-fp32 CPU oracle, rel L2 <= 1e-3 (north star) with
-    identical re-noise draw counts; the 16-bit modes' distance from the same truth is printed beside it."""
-    u = UNet2DConditionModel(text_len=77, dtype=torch.float32, latent_repeat=2)
-    sd = u.synthetic_state_dict(1234)
+# Bounds of the full-size loop test = measured distance + 25 % (VERDICT r2 #1d).  Measured on MI355X (this file's own
+# record, gpurun_out/round3_parity.json -> profiles/): 10 steps fp32 1.25e-5, bf16x3 see record, fp16 4.5e-3, bf16 3.6e-2.
+LOOP10_BOUND = {"fp32": 1e-4, "bf16x3": 1e-3, "fp16": 5.7e-3, "bf16": 4.5e-2}
+LOOP50_BOUND = {"fp32": 1e-4, "bf16x3": 1e-3, "fp16": 1.2e-2, "bf16": 9e-2}
+
+
+def _unet_of(name, sd):
+    kw = dict(fp32=dict(precision="fp32"), bf16x3=dict(precision="bf16x3"), fp16=dict(dtype=torch.float16), bf16=dict(dtype=torch.bfloat16))[name]
+    u = UNet2DConditionModel(text_len=77, latent_repeat=2, **kw)
     u.load_state_dict(sd)
+    return u
+
+
+def test_full_sd14_every_mode_10_and_50_step_loops_against_the_fp32_oracle(tmp_path):
+    """Full SD-v1.4 (859.5 M parameters, 64x64x4 latents), 1 prompt, CFG 7.5, DDPM, noise from a tape, repellency against 64
+    channel-normalised references with the gate placed so that it fires.  Final latents of the HIP path in EVERY mode
+    (fp32 plan, bf16x3 plan, fp16 and bf16 storage) against the pure-fp32 oracle, with identical re-noise draw counts:
+      * num_inference_steps = 10 (t = 901, 801 in the repellency window) vs the oracle on the CPU;
+      * num_inference_steps = 50 (the benchmark's loop; 11 window steps) vs the same oracle code evaluated by torch on the
+        GPU (TF32 off; it matches its CPU evaluation to ~1e-6, checked on the 10-step run).
+    North star: rel L2 <= 1e-3 -- met by the fp32 and bf16x3 plans; the 16-bit storage modes are bounded at their measured
+    distance + 25 % (a single 16-bit rounding of the MFMA operands cannot do better than 3e-3: profiles/round3_precision_
+    ablation.md).  The record lands in gpurun_out/round3_parity.json."""
+    sd = UNet2DConditionModel(text_len=77).synthetic_state_dict(1234)
     oracle = OracleUNet(sd, None, act_dtype=None)
     g = torch.Generator().manual_seed(5)
     E = torch.randn(2, 77, 768, generator=g)
     x = torch.randn(1, 4, 64, 64, generator=g)
-    ref1 = oracle(torch.cat([x, x]), 901.0, E)
-    out1 = u(x.cuda(), 901.0, encoder_hidden_states=E.cuda()).sample
-    r_fwd = rel_l2(out1, ref1)
-    print(f"full SD-v1.4 UNet, fp32 plan vs pure-fp32 oracle: rel L2 {r_fwd:.2e}")
-    assert r_fwd <= 1e-4
-
     refs = orp.channel_normalise(torch.randn(64, 4, 64, 64, generator=g))
     tape = torch.randn(40, 1, 4, 64, 64, generator=g)
+    tape50 = torch.randn(140, 1, 4, 64, 64, generator=torch.Generator().manual_seed(6))
 
     class Tape:
-        def __init__(self):
-            self.i = 0
+        def __init__(self, t, dev=None):
+            self.i, self.t = 0, (t if dev is None else t.to(dev))
 
         def __call__(self, p, shape):
-            z = tape[self.i].reshape(shape).clone()
+            z = self.t[self.i].reshape(shape).clone()
             self.i += 1
             return z
 
     params = dict(sigma=3.15, scale=0.33, beta_threshold=1e-6, beta_threshold_margin=1e9)
-    steps = 10
-    t_o = Tape()
-    ref, st = opipe.denoise_one(oracle, osch.DDPM(), E, 0, t_o, num_inference_steps=steps,
-                                repel=dict(flavour="threshold", proj_refs=refs, **params))
+    ref1 = oracle(torch.cat([x, x]), 901.0, E)
+    t_o = Tape(tape)
+    ref10, st10 = opipe.denoise_one(oracle, osch.DDPM(), E, 0, t_o, num_inference_steps=10,
+                                    repel=dict(flavour="threshold", proj_refs=refs, **params))
+    # the same oracle evaluated on the GPU (plain torch ops; no libsdn kernel): the 50-step truth
+    torch.backends.cuda.matmul.allow_tf32 = False
+    torch.backends.cudnn.allow_tf32 = False
+    oracle_g = OracleUNet(sd, None, act_dtype=None, device="cuda")
+    t_g = Tape(tape, "cuda")
+    ref10_g, _ = opipe.denoise_one(oracle_g, osch.DDPM(), E.cuda(), 0, t_g, num_inference_steps=10,
+                                   repel=dict(flavour="threshold", proj_refs=refs.cuda(), **params))
+    r_dev = rel_l2(ref10_g, ref10)
+    t_g50 = Tape(tape50, "cuda")
+    ref50, st50 = opipe.denoise_one(oracle_g, osch.DDPM(), E.cuda(), 0, t_g50, num_inference_steps=50,
+                                    repel=dict(flavour="threshold", proj_refs=refs.cuda(), **params))
+    del oracle_g
+    torch.cuda.empty_cache()
+    print(f"oracle on GPU vs oracle on CPU, 10-step loop: rel L2 {r_dev:.2e}; re-noise draws 10 steps {st10['renoise_draws']}, "
+          f"50 steps {st50['renoise_draws']}")
+    assert r_dev <= 1e-4 and st10["renoise_draws"] == 2 and st50["renoise_draws"] == 11
+
     res = {}
-    import os
-    # the 16-bit arms (two more 860 M-parameter packs and loops) only when asked: SDN_PARITY_FULL=1 refreshes the record
-    # profiles/round2_parity.json; the default run asserts the fp32 plan alone
-    arms = (("fp32", torch.float32), ("fp16", torch.float16), ("bf16", torch.bfloat16)) if os.environ.get("SDN_PARITY_FULL") else \
-        (("fp32", torch.float32),)
-    for name, dt in arms:
-        un = u if dt == torch.float32 else UNet2DConditionModel(text_len=77, dtype=dt, latent_repeat=2)
-        if dt != torch.float32:
-            un.load_state_dict(sd)
-        t_p = Tape()
+    for name in ("fp32", "bf16x3", "fp16", "bf16"):
+        un = _unet_of(name, sd)
+        fwd = rel_l2(un(x.cuda(), 901.0, encoder_hidden_states=E.cuda()).sample, ref1)
         pipe = SafeDenoiserPipeline(un, DDPMScheduler(), variant="threshold_time")
-        lat = pipe(prompt_embeddings=E.cuda(), num_inference_steps=steps, guidance_scale=7.5, noise_fn=t_p,
-                   repellency_processor=_proc(refs, tmp_path, **params), return_latents=True)
-        res[name] = (rel_l2(lat, ref), pipe.last_stats["renoise_draws"], t_p.i)
-        del un
-    print(f"full SD-v1.4 10-step loop vs pure-fp32 oracle (re-noise draws {st['renoise_draws']}): " +
-          ", ".join(f"{k} {v[0]:.2e}" for k, v in res.items()))
+        out = {"forward": fwd}
+        for steps, tp, ref, st, t_ref in ((10, Tape(tape), ref10, st10, t_o), (50, Tape(tape50), ref50, st50, t_g50)):
+            lat = pipe(prompt_embeddings=E.cuda(), num_inference_steps=steps, guidance_scale=7.5, noise_fn=tp,
+                       repellency_processor=_proc(refs, tmp_path, **params), return_latents=True)
+            out[f"loop_{steps}"] = rel_l2(lat, ref)
+            assert pipe.last_stats["renoise_draws"] == st["renoise_draws"] and tp.i == t_ref.i, (name, steps)
+        res[name] = out
+        print(f"full SD-v1.4 vs pure-fp32 oracle, {name:6s}: forward {fwd:.2e}, 10-step loop {out['loop_10']:.2e}, "
+              f"50-step loop {out['loop_50']:.2e}")
+        del un, pipe
+        torch.cuda.empty_cache()
     import json
+    import os
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
-    if len(arms) == 3:
-        json.dump({"what": "full SD-v1.4 (859.5 M parameters), 1 prompt, CFG 7.5, DDPM, 10 steps (2 in the repellency window, gate "
-                       "fires both times), tape noise: rel L2 of the HIP path's final latents vs the pure-fp32 CPU oracle",
-               "source": "tests/test_gpu_f32.py::test_full_sd14_fp32_plan_forward_and_10_step_loop_meet_the_north_star_tolerance",
-               "unet_forward_fp32_plan": r_fwd, "loop_10_steps": {k: v[0] for k, v in res.items()},
-               "renoise_draws": {k: v[1] for k, v in res.items()}, "oracle_renoise_draws": st["renoise_draws"],
-               "north_star_bound": 1e-3}, open(os.path.join(out_dir, "round2_parity.json"), "w"), indent=1)
-    assert res["fp32"][1] == st["renoise_draws"] == 2 and res["fp32"][2] == t_o.i
-    assert res["fp32"][0] <= 1e-3                                        # the north-star bound
-    if len(arms) == 3:
-        assert res["fp16"][0] <= 3e-2 and res["bf16"][0] <= 2e-1          # 16-bit storage: reported, loosely bounded
+    json.dump({"what": "full SD-v1.4 (859.5 M parameters, synthetic weights seed 1234), 1 prompt, CFG 7.5, DDPM, tape noise, "
+                       "repellency gate firing at every window step: rel L2 of the HIP path's output vs the pure-fp32 oracle",
+               "source": "tests/test_gpu_f32.py::test_full_sd14_every_mode_10_and_50_step_loops_against_the_fp32_oracle",
+               "modes": res, "oracle_gpu_vs_cpu_10_steps": r_dev, "north_star_bound": 1e-3,
+               "bounds_10": LOOP10_BOUND, "bounds_50": LOOP50_BOUND}, open(os.path.join(out_dir, "round3_parity.json"), "w"), indent=1)
+    assert res["fp32"]["forward"] <= 1e-4 and res["bf16x3"]["forward"] <= 1e-4
+    for name in res:
+        assert res[name]["loop_10"] <= LOOP10_BOUND[name], (name, res[name])
+        assert res[name]["loop_50"] <= LOOP50_BOUND[name], (name, res[name])

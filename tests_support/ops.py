@@ -9,9 +9,14 @@ from safe_denoiser_amd import _lib
 BF = torch.bfloat16
 
 
+X3 = False      # tests of the bf16x3 contraction mode set this: f32 tensors then go to sdn_gemm_x3 / sdn_attention_x3
+
+
 def _fn(base: str, t: torch.Tensor):
-    """sdn_<base>_bf16, sdn_<base>_f16 or sdn_<base>_f32 by the tensor's storage dtype."""
+    """sdn_<base>_bf16, sdn_<base>_f16 or sdn_<base>_f32 (sdn_<base>_x3 under X3) by the tensor's storage dtype."""
     suffix = {torch.float16: "f16", torch.float32: "f32"}.get(t.dtype, "bf16")
+    if X3 and suffix == "f32" and base in ("gemm", "attention"):
+        suffix = "x3"
     return getattr(sda.lib(), f"sdn_{base}_{suffix}")
 
 
