@@ -48,11 +48,13 @@ def build_engine(args, rank, world, dev):
         g = torch.Generator().manual_seed(0)
         refs = torch.randn(args.refs, 4, 64, 64, generator=g)
         refs = refs / torch.norm(refs, dim=1, keepdim=True)
+    comm_ms = sdist.warm_up_communicator(dev)                          # RCCL's lazy communicator set-up, timed on its own
     sdist.barrier(); torch.cuda.synchronize()
     tb0 = time.perf_counter()
-    refs = sdist.broadcast_proj_ref(refs, dev)                         # RCCL broadcast, 33.75 MB
+    refs = sdist.broadcast_proj_ref(refs, dev)                         # RCCL broadcast, 33.75 MB (+ checksum all-reduces)
     torch.cuda.synchronize()
-    bcast_ms = (time.perf_counter() - tb0) * 1e3                       # includes RCCL's lazy communicator set-up
+    bcast_ms = (time.perf_counter() - tb0) * 1e3 if world > 1 else None    # N = 1: there is no broadcast (a host -> device copy)
+    sdist.heartbeat(f"communicator {comm_ms:.0f} ms, proj_ref broadcast {bcast_ms if bcast_ms is None else round(bcast_ms, 1)} ms")
     tmp = tempfile.mkdtemp(prefix=f"sdn_bench_r{rank}_")
     path = os.path.join(tmp, "repellency_proj_ref.pt")
     torch.save(refs.cpu(), path)
@@ -69,7 +71,7 @@ def build_engine(args, rank, world, dev):
     proc = thr.get_repellency_method("kernel_fast", torch.zeros(1, device=dev), None, None, 50, 1000, 0.00085, 0.012,
                                      n_embed=16, beta_threshold=beta, **knobs)
     pipe = SafeDenoiserPipeline(unet, sched, variant="threshold_time")
-    return unet, pipe, proc, beta, bcast_ms
+    return unet, pipe, proc, beta, bcast_ms, comm_ms
 
 
 def _attn_pad(label: str) -> float:
@@ -273,6 +275,8 @@ def main():
 
     # N > 1 without a launcher: become the launcher BEFORE anything touches the GPU (no re-exec of a GPU process)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if not args.launch_check and os.environ.get("SDN_SHARE_GPU") != "1" and torch.cuda.device_count() < args.gpus:
+            sys.exit(f"[bench] --gpus {args.gpus} but this node shows {torch.cuda.device_count()} GPU(s): one process per GPU")
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
         sys.exit(f"[bench] --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: start one process per GPU "
@@ -292,7 +296,7 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
-    unet, pipe, proc, beta, bcast_ms = build_engine(args, rank, world, dev)
+    unet, pipe, proc, beta, bcast_ms, comm_ms = build_engine(args, rank, world, dev)
     P = args.prompts_per_batch
     mine = sdist.shard_indices(args.total_prompts, rank, world)        # this rank's prompts of the 515-prompt job
     g = torch.Generator().manual_seed(7)
@@ -342,6 +346,7 @@ def main():
         beta = proc.beta_threshold
     for k in range(args.warmup):
         run(k)
+        sdist.heartbeat(f"warm-up batch {k + 1}/{args.warmup} done")
     sdist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     renoise = 0
@@ -352,9 +357,10 @@ def main():
         window_pairs += pipe.last_stats["window_steps"] * P
     torch.cuda.synchronize()
     dt_mine = time.perf_counter() - t0                                  # this rank's own clock, before the closing barrier
+    sdist.heartbeat(f"timed region done: {P * args.steps} images in {dt_mine:.1f} s")
     sdist.barrier()
-    dt = sdist.max_over_ranks(time.perf_counter() - t0, dev)
-    per_rank = [P * args.steps / d_ for d_ in sdist.gather_over_ranks(dt_mine, dev)]
+    agg = sdist.throughput_over_ranks(P * args.steps, dt_mine, time.perf_counter() - t0, dev)
+    dt, per_rank = agg["window_s"], agg["per_rank"]
     assert torch.isfinite(out).all()
 
     # ---- live kernel timing (HIP events on the launch stream) of one UNet forward at the benchmark shape ----
@@ -450,7 +456,7 @@ def main():
                             "placement": placement,
                             "fired_fraction_rank0": renoise / max(window_pairs, 1)},
                    "parallelism": f"prompt-shard x{world}",
-                   "per_rank_images_per_sec": per_rank, "proj_ref_broadcast_ms": bcast_ms,
+                   "per_rank_images_per_sec": per_rank, "proj_ref_broadcast_ms": bcast_ms, "communicator_setup_ms": comm_ms,
                    **({"rehearsal": "SDN_SHARE_GPU=1: ranks share the visible GPU(s) and talk over gloo -- a functional check of "
                                     "the N > 1 path, NOT a scaling measurement"} if os.environ.get("SDN_SHARE_GPU") == "1" else {})},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",

@@ -8,18 +8,49 @@ backend "nccl" is RCCL on ROCm; "gloo" is used for the CPU tests.
 """
 from __future__ import annotations
 
+import datetime
 import os
+import sys
+import time
 from typing import Optional
 
 import torch
 import torch.distributed as dist
 
+# A rank that never arrives must fail the job, not hang it: every collective of this module is an init-time or end-of-run
+# exchange, so a generous bound costs nothing (SDN_DIST_TIMEOUT_S overrides).
+DEFAULT_TIMEOUT_S = 900
 
-def init_from_env(backend: Optional[str] = None):
+
+def heartbeat(msg: str, rank: Optional[int] = None):
+    """One line on stderr, flushed: `[sdn rank r/W +12.3s] msg`.  Per-rank progress for multi-process runs (a stuck rank is
+    then visible in the launcher's log; stdout stays the JSON line)."""
+    r = (dist.get_rank() if dist.is_initialized() else int(os.environ.get("RANK", "0"))) if rank is None else rank
+    w = dist.get_world_size() if dist.is_initialized() else int(os.environ.get("WORLD_SIZE", "1"))
+    print(f"[sdn rank {r}/{w} +{time.perf_counter() - _T0:.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
+def check_device_count(world: int, local: int, share: bool = False):
+    """Fail fast, before any rendezvous, when this node cannot give every local rank its own GPU."""
+    if not torch.cuda.is_available() or share:
+        return
+    n = torch.cuda.device_count()
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if n < local_world or local >= n:
+        raise RuntimeError(f"{local_world} ranks on this node (LOCAL_RANK {local}) but only {n} GPU(s) visible: one process per "
+                           f"GPU is required (set SDN_SHARE_GPU=1 only for a functional rehearsal over gloo)")
+
+
+def init_from_env(backend: Optional[str] = None, timeout_s: Optional[float] = None):
     """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun contract).  Returns (rank, world, local_rank)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not (0 <= rank < world):
+        raise RuntimeError(f"RANK {rank} outside WORLD_SIZE {world}")
     # rehearsal on a box with fewer GPUs than ranks (SDN_SHARE_GPU=1): ranks share the devices round-robin and talk over gloo
     # (RCCL refuses two ranks on one device).  Functional check of the N > 1 path only -- never a scaling measurement.
     share = os.environ.get("SDN_SHARE_GPU") == "1" and torch.cuda.is_available()
@@ -32,8 +63,11 @@ def init_from_env(backend: Optional[str] = None):
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
+            check_device_count(world, local, share)
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if timeout_s is None:
+            timeout_s = float(os.environ.get("SDN_DIST_TIMEOUT_S", DEFAULT_TIMEOUT_S))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s))
     elif torch.cuda.is_available():
         torch.cuda.set_device(local)
     return rank, world, local
@@ -56,6 +90,21 @@ def valid_case_numbers(n_items: int, rank: int, world: int):
     """(start, end) as the reference's --valid_case_numbers would be given to rank r of W."""
     idx = shard_indices(n_items, rank, world, "contiguous")
     return (idx[0], idx[-1] + 1) if idx else (n_items, n_items)
+
+
+def warm_up_communicator(device) -> float:
+    """RCCL builds its communicator (rings over xGMI, IPC handles) lazily inside the FIRST collective; running a 1-element
+    all-reduce here keeps that one-off cost (seconds) out of whatever is timed next.  Returns its wall time in ms."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return 0.0
+    t0 = time.perf_counter()
+    t = torch.ones(1, dtype=torch.float32, device=_comm_device(device))
+    dist.all_reduce(t)
+    if t.is_cuda:
+        torch.cuda.synchronize()
+    if int(t.item()) != dist.get_world_size():
+        raise RuntimeError("communicator warm-up: all_reduce returned a wrong rank count")
+    return (time.perf_counter() - t0) * 1e3
 
 
 def _comm_device(device):
@@ -123,3 +172,14 @@ def gather_over_ranks(value: float, device) -> list:
     out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(out, t)
     return [float(o.item()) for o in out]
+
+
+def throughput_over_ranks(units_mine: int, dt_mine: float, dt_window_mine: float, device) -> dict:
+    """Whole-job throughput of a prompt-sharded run (bench.py's `value`): every rank reports the units it processed, its own
+    elapsed time and its view of the common timed window (barrier ... barrier).  value = all units / the LONGEST window
+    (MAX over ranks); per_rank = each rank's own units / its own time (N entries, rank order)."""
+    units = gather_over_ranks(float(units_mine), device)
+    times = gather_over_ranks(float(dt_mine), device)
+    window = max_over_ranks(float(dt_window_mine), device)
+    return {"value": sum(units) / window, "window_s": window, "units": [int(u) for u in units],
+            "per_rank": [u / t for u, t in zip(units, times)]}

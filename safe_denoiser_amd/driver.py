@@ -287,9 +287,16 @@ def run_job(args, pipe, repellency_processor=None, task_config: Optional[Mapping
     import time
 
     from . import cases as _cases
+    family, variant = ERASE_IDS[args.erase_id]
+    # SD_FUNCTIONS[erase_id] fixes the pipeline class, hence the gating window (run_nudity.py:56-73,277-279): a pipe built for
+    # another variant would silently run a different window than the reference does for this erase_id
+    if variant is not None and getattr(pipe, "variant", variant) != variant:
+        raise ValueError(f"erase_id {args.erase_id!r} maps to gating variant {variant!r} but the pipeline was built with "
+                         f"variant={pipe.variant!r}")
     art = RunArtifacts(args, task_config, rank=rank, world=world)
     log = art.logger
-    family, _variant = ERASE_IDS[args.erase_id]
+    # the vanilla families (std / esd) have no repellency block (VanillaStableDiffusionPipeline)
+    use_rep = args.task_config is not None and variant is not None
     space, neg = negative_prompts(args)
     safe_config = SLD_CONFIGS[args.safe_level] if "sld" in args.erase_id else None
     if safe_config is not None:
@@ -306,7 +313,7 @@ def run_job(args, pipe, repellency_processor=None, task_config: Optional[Mapping
         imgs = pipe([c["prompt"] for c in batch], num_inference_steps=args.num_inference_steps, guidance_scale=batch[0]["guidance"],
                     negative_prompt=neg, negative_prompt_space=space, height=args.image_length, width=args.image_length,
                     generator=_cases.generators(batch, device=device),
-                    repellency_processor=repellency_processor if args.task_config is not None else None,
+                    repellency_processor=repellency_processor if use_rep else None,
                     safree_dict=sf, return_latents=False, output_type="pil", **(safe_config or {}))
         dt = time.time() - t0
         for c, im in zip(batch, imgs):

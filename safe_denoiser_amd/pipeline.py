@@ -39,6 +39,10 @@ VARIANTS = {
 }
 
 
+SLD_SAFETY_CONCEPT = ("hate, harassment, violence, suffering, humiliation, harm, suicide, sexual, nudity, bodily fluids, blood, "
+                      "obscene gestures, illegal activity, drug use, theft, vandalism, weapons, child abuse, brutality, cruelty")
+
+
 class SafeDenoiserPipeline:
     GRAPH_MAX_BATCH = 16      # UNet rows (branches x prompts) up to which a forward is launch-bound and replayed as a hipGraph
 
@@ -58,8 +62,52 @@ class SafeDenoiserPipeline:
         self.last_safree = None
         self._bufs = {}
         self.record_den = False    # diagnostics: keep each window step's denominators (device tensors, no sync) in last_stats
+        # SLDPipeline._safety_text_concept: the default of the third-party base class the reference's SLD pipelines inherit
+        # (python_sld == 1.0.10, requirements.txt:16; not in /root/reference -- restated from the published package)
+        self.safety_concept = SLD_SAFETY_CONCEPT
 
     # ------------------------------------------------------------------------------------------------
+    @classmethod
+    def from_pretrained(cls, model_dir: str, scheduler=None, torch_dtype=torch.bfloat16, variant: str = "threshold_time",
+                        latent_repeat: int = 1, tokenizer=None, weights_variant: Optional[str] = None, precision: Optional[str] = None,
+                        device="cuda", **kwargs):
+        """`pipeline_func.from_pretrained(model_id, scheduler=scheduler, torch_dtype=weight_dtype, revision="fp16")`
+        (run_nudity.py:104-122) for a LOCAL diffusers-layout directory: unet / vae / text_encoder weights (safetensors or
+        .bin) are packed into the engine's layouts, `scheduler/scheduler_config.json` is honoured when no scheduler object is
+        passed (DDPMScheduler.from_pretrained, :108 -- including its clip_sample) and the tokenizer is
+        loaded when its vocabulary files are present.  `torch_dtype`: bf16 / fp16 storage, or float32 = the fp32 plan
+        (`precision="bf16x3"` = fp32 storage with split-operand contractions); the VAE and text encoder take the 16-bit type.
+        `variant` = the gating variant (SD_FUNCTIONS[erase_id], driver.ERASE_IDS); `latent_repeat` = guidance branches that
+        share their latents (2 = CFG, 3 = lra / SLD).  `revision` and other hub arguments are accepted and ignored."""
+        import os
+
+        from . import checkpoint as ck
+        from .clip import CLIPTextModel
+        from .unet import UNet2DConditionModel
+        from .vae import AutoencoderKL
+        if not os.path.isdir(model_dir):
+            raise FileNotFoundError(f"{model_dir}: not a local directory (there is no hub access; pass a diffusers-layout checkpoint directory)")
+        if scheduler is None:
+            scheduler = DDPMScheduler.from_pretrained(model_dir, subfolder="scheduler")
+        dt16 = torch_dtype if torch_dtype in (torch.bfloat16, torch.float16) else torch.bfloat16
+        unet = UNet2DConditionModel(dtype=torch_dtype, latent_repeat=latent_repeat, precision=precision,
+                                    **ck.unet_kwargs(ck.read_config(os.path.join(model_dir, "unet"))))
+        unet.load_state_dict(ck.load_weights(os.path.join(model_dir, "unet"), weights_variant), device=device)
+        vae = enc = None
+        if os.path.isdir(os.path.join(model_dir, "vae")):
+            vae = AutoencoderKL(dtype=dt16, **ck.vae_kwargs(ck.read_config(os.path.join(model_dir, "vae"))))
+            vae.load_state_dict(ck.load_weights(os.path.join(model_dir, "vae"), weights_variant), device=device)
+        if os.path.isdir(os.path.join(model_dir, "text_encoder")):
+            enc = CLIPTextModel(dtype=dt16, **ck.clip_kwargs(ck.read_config(os.path.join(model_dir, "text_encoder"))))
+            enc.load_state_dict(ck.load_weights(os.path.join(model_dir, "text_encoder"), weights_variant), device=device)
+        if tokenizer is None:
+            tokenizer = ck.load_tokenizer(model_dir)
+        return cls(unet, scheduler, variant=variant, vae=vae, text_encoder=enc, tokenizer=tokenizer)
+
+    def to(self, *args, **kwargs):
+        """`pipe.to(device)` of the reference's load_sd (run_nudity.py:131): the engine's weights already live on the GPU."""
+        return self
+
     def _noise(self, noise_fn, generators, p: int, shape, device):
         if noise_fn is not None:
             return noise_fn(p, shape).to(device=device, dtype=torch.float32)
@@ -106,12 +154,23 @@ class SafeDenoiserPipeline:
         sf = dict(safree=False, svf=False, lra=False, re_attn_t=(-1, -1), alpha=0.0, up_t=10, category="nudity", logger=None)
         if safree_dict:
             sf.update(safree_dict)
+        # SLD family (modified_sld_pipeline*.py): third branch = safety concept, guidance eq. 3-8 with momentum state
+        # (enable_safety_guidance = sld_guidance_scale >= 1, modified_sld_pipeline_threshold_time.py:402-405)
+        sld = None
+        if kwargs.get("sld_guidance_scale", 0) and kwargs["sld_guidance_scale"] >= 1:
+            sld = dict(scale=float(kwargs["sld_guidance_scale"]), warmup=int(kwargs.get("sld_warmup_steps", 10)),
+                       thr=float(kwargs.get("sld_threshold", 0.01)), ms=float(kwargs.get("sld_momentum_scale", 0.3)),
+                       mb=float(kwargs.get("sld_mom_beta", 0.4)))
+        if sld:                                    # the SLD pipelines take safree_dict / negative_prompt_space into **kwargs and never
+            sf.update(safree=False, svf=False, lra=False)       # read them (modified_sld_pipeline_threshold_time.py:285-311)
+        n_prompts = None if prompt is None else (1 if isinstance(prompt, str) else len(prompt))
         if prompt_embeddings is None:
             if prompt is None or self.text_encoder is None or self.tokenizer is None:
                 raise NotImplementedError("pass `prompt_embeddings` ([2P,77,768]), or construct the pipeline with text_encoder= "
                                           "(safe_denoiser_amd.clip.CLIPTextModel) and tokenizer= and pass `prompt` strings")
             # steps 3 of the reference's __call__ (...threshold_time.py:453-486): encode, then the SAFREE text projection
-            prompt_embeddings, _ids, attn_mask = self._new_encode_prompt(prompt, negative_prompt)
+            prompt_embeddings, _ids, attn_mask = self._new_encode_prompt(prompt, negative_prompt,
+                                                                         safety_concept=self.safety_concept if sld else None)
             if sf["safree"] and rescaled_text_embeddings is None:
                 if negative_prompt_space is None:
                     raise _lib.SdnError("safree_dict['safree'] needs negative_prompt_space (the concept phrases)")
@@ -126,12 +185,6 @@ class SafeDenoiserPipeline:
                                           "use return_latents=True (the reference's parity tap, ...threshold_time.py:585-586)")
             if output_type not in ("pil", "np", "uint8"):
                 raise _lib.SdnError("output_type must be 'pil', 'np' or 'uint8'")
-        # SLD family (modified_sld_pipeline*.py): third branch = safety concept, guidance eq. 3-8 with momentum state
-        sld = None
-        if kwargs.get("sld_guidance_scale", 0) and kwargs["sld_guidance_scale"] >= 1:
-            sld = dict(scale=float(kwargs["sld_guidance_scale"]), warmup=int(kwargs.get("sld_warmup_steps", 10)),
-                       thr=float(kwargs.get("sld_threshold", 0.01)), ms=float(kwargs.get("sld_momentum_scale", 0.3)),
-                       mb=float(kwargs.get("sld_mom_beta", 0.4)))
         kind, lo_default, hi_default, use_beta, use_flag = VARIANTS[self.variant]
         if self.variant == "threshold":                               # the reference assigns 0 / 50 and never reads the kwargs
             lo, hi = lo_default, hi_default
@@ -154,6 +207,9 @@ class SafeDenoiserPipeline:
             if E.shape[0] % 2 != 0:
                 raise _lib.SdnError("prompt_embeddings must be [2P,77,768]: P unconditional rows then P text rows")
             P = E.shape[0] // 2
+        if n_prompts is not None and E.shape[0] != (3 if sld else 2) * n_prompts:
+            raise _lib.SdnError(f"{E.shape[0]} text rows for {n_prompts} prompts: expected {(3 if sld else 2) * n_prompts} "
+                                f"([uncond | text{' | safety concept' if sld else ''}])")
         s = self.unet.config.sample_size
         height = height or s * self.vae_scale_factor
         width = width or s * self.vae_scale_factor
@@ -315,10 +371,12 @@ class SafeDenoiserPipeline:
             mask = (torch.arange(ids.shape[1])[None, :] <= ids.argmax(dim=-1, keepdim=True)).to(torch.int64)
         return ids, mask
 
-    def _new_encode_prompt(self, prompt, negative_prompt=None):
+    def _new_encode_prompt(self, prompt, negative_prompt=None, safety_concept: Optional[str] = None):
         """...threshold_time.py:231-349 for P prompts: tokenise with padding="max_length" / truncation, encode (no attention
         mask: the SD-v1.4 text encoder's config has no use_attention_mask), stack [unconditional | text] rows.
-        Returns (embeddings [2P,77,768], input ids [P,77], the tokenizer's attention mask [P,77])."""
+        With `safety_concept` (the SLD pipelines, modified_sld_pipeline_threshold_time.py:258-276) the concept text is encoded
+        the same way and appended once per prompt: [unconditional | text | safety concept].
+        Returns (embeddings [2P or 3P,77,768], input ids [P,77], the tokenizer's attention mask [P,77])."""
         prompts = [prompt] if isinstance(prompt, str) else list(prompt)
         if negative_prompt is None:
             neg = [""] * len(prompts)
@@ -331,8 +389,11 @@ class SafeDenoiserPipeline:
         dev = torch.device("cuda", torch.cuda.current_device())
         ids, mask = self._tok(prompts)
         nids, _ = self._tok(neg)
-        E = torch.cat([self.text_encoder(nids.to(dev))[0], self.text_encoder(ids.to(dev))[0]])
-        return E, ids, mask
+        parts = [self.text_encoder(nids.to(dev))[0], self.text_encoder(ids.to(dev))[0]]
+        if safety_concept is not None:
+            cids, _ = self._tok([safety_concept])
+            parts.append(self.text_encoder(cids.to(dev))[0].repeat(len(prompts), 1, 1))
+        return torch.cat(parts), ids, mask
 
     def encode_prompt(self, prompt, negative_prompt=None) -> torch.Tensor:
         return self._new_encode_prompt(prompt, negative_prompt)[0]

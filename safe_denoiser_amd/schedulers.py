@@ -58,6 +58,32 @@ class _DiscreteScheduler:
         self.timesteps = None
         self._stride = None
 
+    # -- construction from a checkpoint's scheduler_config.json (run_nudity.py:108) ------------------
+    # diffusers' from_config semantics: keys of the file that the class accepts are used, the others are ignored, and a key
+    # the file LACKS takes the class's own default -- which for clip_sample is True in DDPM / DDIM (the
+    # SD-v1.4 file is PNDM-authored; whether pred_original_sample is clipped to [-1, 1] is decided by that file, not here).
+    _CLASS_DEFAULTS = dict(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear", steps_offset=0,
+                           clip_sample=True, clip_sample_range=1.0, timestep_spacing="leading", prediction_type="epsilon")
+    _ACCEPTED = ("num_train_timesteps", "beta_start", "beta_end", "beta_schedule", "steps_offset", "clip_sample",
+                 "clip_sample_range", "timestep_spacing", "prediction_type", "set_alpha_to_one")
+
+    @classmethod
+    def from_config(cls, config: dict):
+        kw = dict(cls._CLASS_DEFAULTS)
+        kw.update({k: v for k, v in config.items() if k in cls._ACCEPTED})
+        if config.get("trained_betas") is not None:
+            raise NotImplementedError("trained_betas is not implemented")
+        for k, want in (("variance_type", "fixed_small"), ("thresholding", False), ("rescale_betas_zero_snr", False)):
+            if k in config and config[k] != want:
+                raise NotImplementedError(f"scheduler config {k} = {config[k]!r} is not implemented")
+        return cls(**kw)
+
+    @classmethod
+    def from_pretrained(cls, model_dir: str, subfolder: str = "scheduler"):
+        from .checkpoint import read_config
+        import os
+        return cls.from_config(read_config(os.path.join(model_dir, subfolder) if subfolder else model_dir, "scheduler_config.json"))
+
     # -- tables -----------------------------------------------------------------------------------
     def set_timesteps(self, num_inference_steps: int, device=None):
         T = self.config.num_train_timesteps
@@ -146,6 +172,8 @@ class DDPMScheduler(_DiscreteScheduler):
 
 class DDIMScheduler(_DiscreteScheduler):
     """DDIM, eta = 0, set_alpha_to_one = False (BASELINE.json names it; commented out at run_nudity.py:107)."""
+
+    _CLASS_DEFAULTS = dict(_DiscreteScheduler._CLASS_DEFAULTS, set_alpha_to_one=True)
 
     def __init__(self, *a, set_alpha_to_one=False, **kw):
         super().__init__(*a, **kw)

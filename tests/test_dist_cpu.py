@@ -47,7 +47,11 @@ def _worker(rank, world, port, q):
     sdist.barrier()
     slowest = sdist.max_over_ranks(1.0 + r, dev)
     total = sdist.sum_over_ranks(len(mine), dev)
-    q.put((r, float(got.double().sum()), tuple(got.shape), thr, mine, slowest, total))
+    warm = sdist.warm_up_communicator(dev)
+    sdist.heartbeat("worker done")
+    # rank r processed 10 (r + 1) images in (1 + r) s of its own clock; the common window is the slower rank's
+    tp = sdist.throughput_over_ranks(10 * (r + 1), 1.0 + r, 1.0 + r, dev)
+    q.put((r, float(got.double().sum()), tuple(got.shape), thr, mine, slowest, total, warm >= 0.0, tp))
     dist.destroy_process_group()
 
 
@@ -62,8 +66,27 @@ def test_world_size_2_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, s0, sh0, t0, m0, sl0, tot0), (r1, s1, sh1, t1, m1, sl1, tot1) = res
+    (r0, s0, sh0, t0, m0, sl0, tot0, w0, tp0), (r1, s1, sh1, t1, m1, sl1, tot1, w1, tp1) = res
+    assert w0 and w1
+    # bench.py's aggregation: N per-rank entries; value = all units over the common (longest) window
+    assert tp0 == tp1 and tp0["per_rank"] == [10.0, 10.0] and tp0["units"] == [10, 20] and tp0["window_s"] == 2.0
+    assert tp0["value"] == 15.0 == sum(tp0["units"]) / tp0["window_s"]
     assert s0 == s1 and sh0 == sh1 == (9, 4, 8, 8)                 # same proj_ref everywhere
     assert t0 == t1 == 3.25                                        # every rank gates identically
     assert m0 == [0, 2, 4, 6, 8, 10] and m1 == [1, 3, 5, 7, 9]
     assert sl0 == sl1 == 2.0 and tot0 == tot1 == 11.0
+
+
+def test_init_rejects_bad_rank_and_reports_missing_gpus(monkeypatch):
+    monkeypatch.setenv("WORLD_SIZE", "2"); monkeypatch.setenv("RANK", "5")
+    with pytest.raises(RuntimeError):
+        sdist.init_from_env(backend="gloo")
+    # one process per GPU: 4 local ranks on a node that shows fewer devices must fail before any rendezvous
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "4")
+    with pytest.raises(RuntimeError, match="only 2 GPU"):
+        sdist.check_device_count(4, 3)
+    sdist.check_device_count(4, 3, share=True)                      # the gloo rehearsal mode is allowed to share devices
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "2")
+    sdist.check_device_count(2, 1)

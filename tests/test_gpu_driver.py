@@ -71,3 +71,33 @@ def test_run_job_writes_the_reference_tree(tmp_path):
     assert "Repellency method : kernel_fast" in log and log.count("Wall-Clock Time for image generation") == 3
     assert "Among " in log and "adjusted_beta" in log                                # the SAFREE block logged through safree_dict["logger"]
     assert pipe.last_stats["branches"] == 3 and pipe.last_stats["renoise_draws"] > 0
+
+
+def test_run_job_with_an_sld_erase_id_builds_the_safety_concept_branch(tmp_path):
+    """erase_id 'sld' through run_job -- string prompts + **SLD_CONFIGS[safe_level]: the pipeline encodes the safety
+    concept itself ([uncond | text | concept], modified_sld_pipeline_threshold_time.py:258-276), a 2-prompt batch runs as 6 UNet
+    rows, and a pipe whose gating variant is not the erase_id's is refused."""
+    rows = ["case_number,prompt,categories,evaluation_seed,evaluation_guidance",
+            '21,"a painting of empty rooms","sexual",11,7', '296,"an oil portrait",shocking,12,7']
+    (tmp_path / "prompts.csv").write_text("\n".join(rows) + "\n")
+    cfg = {"erase_id": "sld", "safe_level": "MEDIUM", "nudity": "nudity", "data": str(tmp_path / "prompts.csv"),
+           "save_dir": str(tmp_path / "out"), "num_inference_steps": 12, "image_length": 128, "safree": True, "lra": True}
+    (tmp_path / "cfg.json").write_text(json.dumps(cfg))
+    args = driver.parse_args(["--config", str(tmp_path / "cfg.json")])
+    u = UNet2DConditionModel(text_len=77, latent_repeat=3, **SMALL)
+    u.load_state_dict(u.synthetic_state_dict(11))
+    enc = CLIPTextModel(dtype=torch.float16, **CLIP_CFG)
+    enc.load_state_dict(enc.synthetic_state_dict(31))
+    vae = AutoencoderKL(block_out_channels=(64, 128), layers_per_block=1, sample_size=32)
+    vae.load_state_dict(vae.synthetic_state_dict(5))
+    tok = FakeCLIPTokenizer(vocab_size=CLIP_CFG["vocab_size"])
+    with pytest.raises(ValueError):
+        driver.run_job(args, SafeDenoiserPipeline(u, DDPMScheduler(), variant="threshold_time", vae=vae, text_encoder=enc, tokenizer=tok))
+    pipe = SafeDenoiserPipeline(u, DDPMScheduler(), variant=driver.ERASE_IDS["sld"][1], vae=vae, text_encoder=enc, tokenizer=tok)
+    E3, _, _ = pipe._new_encode_prompt(["a", "b"], None, safety_concept=pipe.safety_concept)
+    assert E3.shape == (6, 77, 768) and torch.equal(E3[4], E3[5]) and not torch.equal(E3[2], E3[4])
+    driver.run_job(args, pipe, prompts_per_batch=2)
+    assert sorted(os.listdir(os.path.join(args.save_dir, "all"))) == ["21_sexual.png", "296_shocking.png"]
+    assert pipe.last_stats["branches"] == 3 and pipe.last_stats["prompts"] == 2
+    with pytest.raises(Exception):                                       # caller-supplied rows that do not match the prompt count
+        pipe(["a", "b"], prompt_embeddings=E3[:4], num_inference_steps=2, return_latents=True, **driver.SLD_CONFIGS["MEDIUM"])

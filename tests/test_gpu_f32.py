@@ -161,10 +161,12 @@ def _proc(refs, tmp_path, **params):
                                      n_embed=4, proj_ref_path=path, cache_proj_ref=True, **params)
 
 
-# Bounds of the full-size loop test = measured distance + 25 % (VERDICT r2 #1d).  Measured on MI355X (this file's own
-# record, gpurun_out/round3_parity.json -> profiles/): 10 steps fp32 1.25e-5, bf16x3 see record, fp16 4.5e-3, bf16 3.6e-2.
-LOOP10_BOUND = {"fp32": 1e-4, "bf16x3": 1e-3, "fp16": 5.7e-3, "bf16": 4.5e-2}
-LOOP50_BOUND = {"fp32": 1e-4, "bf16x3": 1e-3, "fp16": 1.2e-2, "bf16": 9e-2}
+# Bounds of the full-size loop test = measured distance + 25 % for the 16-bit storage modes (VERDICT r2 #1d); the two
+# fp32-storage modes get a few times their measured distance, far inside the north star's 1e-3.  Measured on MI355X (this
+# file's own record, profiles/round3_parity.json): 10 / 50 steps  fp32 1.25e-5 / 1.27e-5, bf16x3 5.1e-5 / 5.4e-5,
+# fp16 4.42e-3 / 4.88e-3, bf16 3.51e-2 / 3.83e-2.
+LOOP10_BOUND = {"fp32": 5e-5, "bf16x3": 2e-4, "fp16": 5.6e-3, "bf16": 4.4e-2}
+LOOP50_BOUND = {"fp32": 5e-5, "bf16x3": 2e-4, "fp16": 6.1e-3, "bf16": 4.8e-2}
 
 
 def _unet_of(name, sd):

@@ -1,0 +1,121 @@
+"""`SafeDenoiserPipeline.from_pretrained(local_dir)` + the reference's call site VERBATIM (run_nudity.py:104-131,439-460): a
+synthetic diffusers-layout directory written by the test (small UNet / VAE / CLIP configs, safetensors weights, the SD-v1.4
+scheduler file) -> PIL images, identical to the pipeline built directly from the same state dicts."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import repellency as orp
+from safe_denoiser_amd import driver
+from safe_denoiser_amd.clip import CLIPTextModel
+from safe_denoiser_amd.pipeline import SafeDenoiserPipeline
+from safe_denoiser_amd.repellency import repellency_methods_threshold as thr
+from safe_denoiser_amd.schedulers import DDPMScheduler
+from safe_denoiser_amd.unet import UNet2DConditionModel
+from safe_denoiser_amd.vae import AutoencoderKL
+from tests.test_checkpoint import SD14_SCHEDULER_JSON
+from tests.test_gpu_pipeline import SMALL
+from tests.test_gpu_safree_call import CLIP_CFG
+from tests_support.fake_tokenizer import FakeCLIPTokenizer
+
+pytestmark = pytest.mark.gpu
+VAE_CFG = dict(block_out_channels=(64, 128), layers_per_block=1, sample_size=32)
+
+
+def _write_checkpoint(root):
+    from safetensors.torch import save_file
+    u = UNet2DConditionModel(text_len=77, **SMALL)
+    usd = u.synthetic_state_dict(11)
+    v = AutoencoderKL(**VAE_CFG)
+    vsd = v.synthetic_state_dict(5)
+    c = CLIPTextModel(dtype=torch.float16, **CLIP_CFG)
+    csd = c.synthetic_state_dict(31)
+    for sub, cfg, sd, fname in (
+            ("unet", dict(SMALL, up_block_types=["UpBlock2D", "CrossAttnUpBlock2D"], act_fn="silu", in_channels=4, out_channels=4,
+                          norm_num_groups=32, _class_name="UNet2DConditionModel"), usd, "diffusion_pytorch_model.safetensors"),
+            ("vae", dict(VAE_CFG, act_fn="silu", latent_channels=4, scaling_factor=0.18215, _class_name="AutoencoderKL"), vsd,
+             "diffusion_pytorch_model.safetensors"),
+            ("text_encoder", dict(CLIP_CFG, hidden_act="quick_gelu", _class_name="CLIPTextModel"),
+             {"text_model." + k: t for k, t in csd.items()}, "model.safetensors")):
+        os.makedirs(os.path.join(root, sub))
+        json.dump({k: (list(x) if isinstance(x, tuple) else x) for k, x in cfg.items()}, open(os.path.join(root, sub, "config.json"), "w"))
+        save_file({k: t.contiguous() for k, t in sd.items()}, os.path.join(root, sub, fname))
+    os.makedirs(os.path.join(root, "scheduler"))
+    json.dump(SD14_SCHEDULER_JSON, open(os.path.join(root, "scheduler", "scheduler_config.json"), "w"))
+    return usd, vsd, csd
+
+
+def test_from_pretrained_then_the_reference_call_site_returns_pil_images(tmp_path):
+    root = str(tmp_path / "ckpt")
+    usd, vsd, csd = _write_checkpoint(root)
+    tok = FakeCLIPTokenizer(vocab_size=CLIP_CFG["vocab_size"])
+    # load_sd (run_nudity.py:104-131)
+    scheduler = DDPMScheduler.from_pretrained(root, subfolder="scheduler")
+    pipe = SafeDenoiserPipeline.from_pretrained(root, scheduler=scheduler, torch_dtype=torch.bfloat16, revision="fp16",
+                                                variant=driver.ERASE_IDS["safree_neg_prompt_rep_threshold_time"][1],
+                                                latent_repeat=3, tokenizer=tok)
+    pipe = pipe.to("cuda:0")
+    assert pipe.scheduler.config.clip_sample is False and pipe.vae is not None and pipe.text_encoder is not None
+    refs = orp.channel_normalise(torch.randn(12, 4, 16, 16, generator=torch.Generator().manual_seed(4)))
+    torch.save(refs, tmp_path / "proj_ref.pt")
+    proc = thr.get_repellency_method("kernel_fast", torch.zeros(1, device="cuda"), None, None, 6, 1000, 0.00085, 0.012, n_embed=4,
+                                     scale=0.33, sigma=3.15, proj_ref_path=str(tmp_path / "proj_ref.pt"), cache_proj_ref=True,
+                                     beta_threshold=1e-6, beta_threshold_margin=1e9)
+
+    class Args:                                                          # what the driver's argparse holds at the call site
+        num_samples, num_inference_steps, image_length, task_config = 1, 6, 128, "task.yaml"
+        re_attn_t, sf_alpha, safree, self_validation_filter, latent_re_attention, up_t, category = "-1,1001", 0.01, True, True, True, 10, "nudity"
+    args, logger, safe_config = Args(), None, None
+    target_prompt, guidance, seed = "a painting of a woman standing near the sea , lustful mood", 7.5, 2868251644
+    negative_prompt_space = driver.NUDITY_NEGATIVE_PROMPT_SPACE
+    negative_prompt = ", ".join(negative_prompt_space)
+    repellency_processor = proc
+    gen = torch.Generator(device="cuda")
+
+    def call(pipe):
+        # ---- run_nudity.py:439-460, verbatim ----
+        imgs = pipe(
+            target_prompt,
+            num_images_per_prompt=args.num_samples,
+            guidance_scale=guidance,
+            num_inference_steps=args.num_inference_steps,
+            negative_prompt=negative_prompt,
+            negative_prompt_space=negative_prompt_space,
+            height=args.image_length,
+            width=args.image_length,
+            generator=gen.manual_seed(seed),
+            repellency_processor=repellency_processor if args.task_config is not None else None,
+            safree_dict={"re_attn_t": [int(tr) for tr in args.re_attn_t.split(",")],
+                         "alpha": args.sf_alpha,
+                         "logger": logger,
+                         "safree": args.safree,
+                         "svf": args.self_validation_filter,
+                         "lra": args.latent_re_attention,
+                         "up_t": args.up_t,
+                         "category": args.category
+                         },
+            **(safe_config or {})
+        )
+        return imgs
+
+    imgs = call(pipe)
+    assert isinstance(imgs, list) and len(imgs) == 1 and imgs[0].size == (32, 32) and imgs[0].mode == "RGB"
+    assert pipe.last_stats["branches"] == 3 and pipe.last_stats["renoise_draws"] > 0
+    # the same stack built by hand from the same state dicts gives the same image, bit for bit
+    u = UNet2DConditionModel(text_len=77, latent_repeat=3, **SMALL); u.load_state_dict(usd)
+    v = AutoencoderKL(**VAE_CFG); v.load_state_dict(vsd)
+    c = CLIPTextModel(dtype=torch.bfloat16, **CLIP_CFG); c.load_state_dict(csd)
+    direct = SafeDenoiserPipeline(u, DDPMScheduler(), variant="threshold_time", vae=v, text_encoder=c, tokenizer=tok)
+    assert np.array_equal(np.asarray(call(direct)[0]), np.asarray(imgs[0]))
+    # what the call surface rejects instead of silently dropping
+    with pytest.raises(NotImplementedError):
+        pipe(target_prompt, num_images_per_prompt=2, num_inference_steps=2)
+    with pytest.raises(TypeError):
+        pipe(target_prompt, num_inference_steps=2, not_an_argument=1)
+    seen = []
+    out = pipe(target_prompt, num_inference_steps=3, callback=lambda i, t, lat: seen.append((i, int(t), tuple(lat.shape))),
+               callback_steps=2, output_type="np", return_dict=False, safree_dict={"lra": True})
+    assert seen == [(0, 667, (1, 4, 16, 16)), (2, 1, (1, 4, 16, 16))] and out.shape == (1, 32, 32, 3)
