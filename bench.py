@@ -4,14 +4,21 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One "step" = one batch of P prompts taken through the whole hot path: 50 denoising iterations, each = UNet forward on
-[2P,4,64,64] (CFG) + guidance combine + (t in 780..1000: x0 probe + repellency projection against proj_ref[515] +
-device-side re-noise select) + scheduler step.  Inputs are synthetic (no weights/datasets on the box) and resident in
-HBM before the timed region: SD-v1.4-architecture UNet with random weights (seed 1234, generated on the GPU), text
-states randn (seed 7),
-proj_ref = channel-normalised randn([515,4,64,64], seed 0), repellency knobs of configs/nudity/safe_denoiser.yaml,
-beta_threshold calibrated by the engine's own row-R5 path.  Prompts shard across ranks (no collective in the loop);
-rank 0 broadcasts proj_ref + threshold once over RCCL.  Prints ONE JSON line on rank 0.
+One "step" = one batch of P prompts taken END TO END through the README-default configuration of BASELINE config 2
+(configs/base/vanilla/safree_neg_prompt_config.json:26-28: safree = svf = lra = true; README.md:216-226), exactly as
+`run_nudity.py:439-460` calls the pipeline:
+    token ids -> CLIP text encoder (prompts, negative prompt, the 17 concept phrases, one masked copy per prompt token)
+    -> SAFREE projection + self-validation filter (per-prompt beta_adjusted) -> 50 denoising iterations, each = UNet forward
+    on [3P,4,64,64] ([uncond | projected-or-plain text | text], per-prompt text switching) + guidance combine + (t in
+    780..1000: x0 probe + repellency projection against proj_ref[515] + device-side re-noise select) + DDPM step
+    -> VAE decode -> uint8 [P,512,512,3] images (on the device; PIL wrapping is host-side file I/O).
+`value` = images/sec of that whole call.  Inputs are synthetic (no weights / datasets / vocabulary files on the box) and
+resident in HBM before the timed region: SD-v1.4-architecture UNet / CLIP / VAE with random weights generated on the GPU,
+synthetic prompt strings through a hash tokenizer (the real tokenizer is the caller's vocabulary lookup), proj_ref =
+channel-normalised randn([515,4,64,64], seed 0), repellency knobs of configs/nudity/safe_denoiser.yaml, beta_threshold
+calibrated by the engine's own row-R5 path.  Prompts shard across ranks (no collective in the loop); rank 0 broadcasts
+proj_ref + threshold once over RCCL.  Prints ONE JSON line on rank 0.  `--workload latent` times the round-1/2 headline
+instead (prompt embeddings in, latents out, 2 CFG branches); at N = 1 that figure is also reported as a secondary.
 """
 import argparse
 import json
@@ -30,18 +37,45 @@ PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip
 PEAK_HBM_GBS = 8000.0          # HBM3E peak, same table
 
 
+NEG_SPACE = ["Sexual Acts", "Content Meant to Arouse Sexual Excitement", "Nudity", "Pornography", "Erotic Art", "Lustful",
+             "Seductive", "Orgasmic", "Libido", "Kinky", "Sexual Orientation", "Sexual Attraction", "Sexual Intercourse",
+             "Sexual Pleasure", "Sexual Fantasy", "Carnal Desires", "Sexual Gratification"]        # run_nudity.py:353-358
+SAFREE = dict(safree=True, svf=True, lra=True, alpha=0.01, up_t=10, re_attn_t=[-1, 1001], category="nudity", logger=None)
+
+
+def synthetic_prompt(i: int) -> str:
+    """Prompt i of the synthetic 515-prompt job: 6..18 pseudo-words (i2p prompts are of that length), deterministic."""
+    n = 6 + (i * 7) % 13
+    return " ".join(f"w{(i * 131 + j * 17) % 997}" for j in range(n))
+
+
+def _dtype(args):
+    return torch.float16 if args.dtype == "f16" else torch.bfloat16
+
+
 def build_engine(args, rank, world, dev):
     from safe_denoiser_amd import dist as sdist
     from safe_denoiser_amd.pipeline import SafeDenoiserPipeline, make_scheduler
     from safe_denoiser_amd.repellency import repellency_methods_threshold as thr
     from safe_denoiser_amd.unet import UNet2DConditionModel
 
-    # latent_repeat = 2: the engine-side form of the reference's cat([latents] * 2) -- the two CFG branches share their
-    # latents, so the UNet computes the branch-independent prefix once (bit-identical, tests/test_gpu_unet.py)
-    unet = UNet2DConditionModel(dtype=torch.float16 if args.dtype == "f16" else torch.bfloat16,
-                                latent_repeat=1 if args.no_latent_repeat else 2)
+    e2e = args.workload == "e2e"
+    # latent_repeat = number of guidance branches: the engine-side form of the reference's cat([latents] * n) -- the branches
+    # share their latents, so the UNet computes the branch-independent prefix once (bit-identical, tests/test_gpu_unet.py)
+    nb = 3 if e2e else 2
+    unet = UNet2DConditionModel(dtype=_dtype(args), latent_repeat=1 if args.no_latent_repeat else nb)
     unet.load_synthetic_on_device(1234, device=dev)
     sched = make_scheduler(args.scheduler)
+    vae = enc = tok = None
+    if e2e:
+        from safe_denoiser_amd.clip import CLIPTextModel
+        from safe_denoiser_amd.vae import AutoencoderKL
+        from tests_support.fake_tokenizer import FakeCLIPTokenizer
+        enc = CLIPTextModel(dtype=_dtype(args))
+        enc.load_synthetic_on_device(4242, device=dev)
+        vae = AutoencoderKL(dtype=_dtype(args))
+        vae.load_synthetic_on_device(4321, device=dev)
+        tok = FakeCLIPTokenizer()
 
     refs = None
     if rank == 0:
@@ -70,7 +104,7 @@ def build_engine(args, rank, world, dev):
     beta = sdist.broadcast_scalar(beta, dev)
     proc = thr.get_repellency_method("kernel_fast", torch.zeros(1, device=dev), None, None, 50, 1000, 0.00085, 0.012,
                                      n_embed=16, beta_threshold=beta, **knobs)
-    pipe = SafeDenoiserPipeline(unet, sched, variant="threshold_time")
+    pipe = SafeDenoiserPipeline(unet, sched, variant="threshold_time", vae=vae, text_encoder=enc, tokenizer=tok)
     return unet, pipe, proc, beta, bcast_ms, comm_ms
 
 
@@ -83,26 +117,30 @@ def _attn_pad(label: str) -> float:
 
 
 def cpu_baseline(args):
-    """The CPU oracle (a port of the reference loop, fp32 torch ops) on the host cores: THREE of the 50 denoising iterations
-    of ONE prompt at the full SD-v1.4 size -- two inside the repellency window (t = 981, 961: UNet b=2 + CFG + x0 probe +
-    repellency M + re-noise + DDPM step) and one outside it (t = 761: UNet + CFG + DDPM step) -- timed separately and
-    extrapolated to the loop's 11 window + 39 plain iterations."""
+    """The CPU oracle (a port of the reference loop, fp32 torch ops) on the host cores, on a BOUNDED sample of the timed
+    workload: TWO of the 50 denoising iterations of ONE prompt at the full SD-v1.4 size -- t = 981 inside the repellency
+    window (UNet on the 3 guidance branches + CFG + x0 probe + repellency M + re-noise + DDPM step) and t = 761 outside it
+    (UNet + CFG + DDPM step) -- plus one VAE decode of that prompt's latent, timed separately and extrapolated to the loop's
+    11 window + 39 plain iterations + 1 decode.  (The CLIP / SAFREE front end is < 0.1 % of the work and is left out.)"""
     from oracle import repellency as orp
     from oracle import schedulers as osch
     from oracle.unet import OracleUNet
+    from oracle.vae import OracleVAEDecoder
     from safe_denoiser_amd.unet import UNet2DConditionModel
+    from safe_denoiser_amd.vae import AutoencoderKL
     cores = torch.get_num_threads()
+    nb = 3 if args.workload == "e2e" else 2
     sd = UNet2DConditionModel().synthetic_state_dict(1234)
     unet = OracleUNet(sd, None, act_dtype=None)
     g = torch.Generator().manual_seed(0)
     refs = orp.channel_normalise(torch.randn(args.refs, 4, 64, 64, generator=g))
     lat = torch.randn(1, 4, 64, 64, generator=g)
-    text = torch.randn(2, 77, 768, generator=g)
+    text = torch.randn(nb, 77, 768, generator=g)
     s = osch.DDPM(); s.set_timesteps(50)
     times = {}
-    for t in (981, 961, 761):
+    for t in (981, 761):
         t0 = time.perf_counter()
-        out = unet(torch.cat([lat] * 2), float(t), text)
+        out = unet(torch.cat([lat] * nb), float(t), text)
         eps = out[0:1] + 7.5 * (out[1:2] - out[0:1])
         if t >= 780:
             x0 = s.step(eps, t, lat, generator=g).pred_original_sample
@@ -111,39 +149,99 @@ def cpu_baseline(args):
             lat = s.add_noise(d["x_0_hat"], torch.randn(lat.shape, generator=g), t)
         lat = s.step(eps, t, lat, generator=g).prev_sample
         times[t] = time.perf_counter() - t0
-    win = 0.5 * (times[981] + times[961])
-    per_image = 11 * win + 39 * times[761]
+    t_dec = 0.0
+    if args.workload == "e2e":
+        del unet, sd
+        dec = OracleVAEDecoder(AutoencoderKL().synthetic_state_dict(4321), None, act_dtype=None)
+        t0 = time.perf_counter()
+        dec.decode_latents(lat * 0.18215)
+        t_dec = time.perf_counter() - t0
+    per_image = 11 * times[981] + 39 * times[761] + t_dec
     return {"value": 1.0 / per_image, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"1 prompt x 3 of 50 iterations at full size: t=981 {times[981]:.2f} s, t=961 {times[961]:.2f} s (window: UNet "
-                      f"b=2 fp32 + CFG + x0 probe + repellency M={args.refs} + re-noise + DDPM step), t=761 {times[761]:.2f} s "
-                      f"(UNet + CFG + DDPM step) = {sum(times.values()):.1f} s of CPU work; extrapolated 11 x window + 39 x plain"}
+            "sample": f"1 prompt x 2 of 50 iterations at full size: t=981 {times[981]:.2f} s (window: UNet b={nb} fp32 + CFG + x0 "
+                      f"probe + repellency M={args.refs} + re-noise + DDPM step), t=761 {times[761]:.2f} s (UNet + CFG + DDPM step)"
+                      + (f", VAE decode {t_dec:.2f} s" if t_dec else "") +
+                      f" = {times[981] + times[761] + t_dec:.1f} s of CPU work; extrapolated 11 x window + 39 x plain"
+                      + (" + 1 decode" if t_dec else "")}
 
 
-def measure_lra_b3(args, dev, proc, text_all, uncond, mine, P):
-    """The README default (configs/base/vanilla/safree_neg_prompt_config.json:26-28: lra = true): THREE guidance branches
-    per prompt ([uncond | text' | text], the third computed and discarded, ...threshold_time.py:518-548) -> 1.5x the UNet
-    work per image.  One warm-up batch + one timed batch, same gate as the headline run."""
+def measure_latent(args, dev, proc, P, precision=None, steps_timed=1, inference_steps=None):
+    """Secondary figures on the round-1/2 headline workload (prompt embeddings in, final latents out, 2 CFG branches,
+    80.3 TFLOP per image) with the same gate: the 16-bit engine (precision None) or a precision mode ("bf16x3" / "fp32":
+    fp32 storage; the modes that meet the north star's 1e-3).  One warm-up call of 3 iterations + `steps_timed` timed
+    batches of P prompts."""
     from safe_denoiser_amd.pipeline import SafeDenoiserPipeline, make_scheduler
     from safe_denoiser_amd.unet import UNet2DConditionModel
-    u3 = UNet2DConditionModel(dtype=torch.float16 if args.dtype == "f16" else torch.bfloat16, latent_repeat=3)
-    u3.load_synthetic_on_device(1234, device=dev)
-    pipe3 = SafeDenoiserPipeline(u3, make_scheduler(args.scheduler), variant="threshold_time")
-    out = {}
-    for k in range(2):
-        idx = [mine[(k * P + j) % len(mine)] for j in range(P)]
-        E = torch.cat([uncond.expand(P, -1, -1), text_all[idx]]).to(dev)
-        gens = [torch.Generator(device=dev).manual_seed(1000 + i) for i in idx]
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        pipe3(prompt_embeddings=E, num_inference_steps=args.inference_steps, guidance_scale=7.5, generator=gens,
-              repellency_processor=proc, safree_dict=dict(lra=True), return_latents=True)
-        torch.cuda.synchronize()
-        out = {"value": P / (time.perf_counter() - t0), "unit": "images/sec", "branches": 3, "prompts_per_batch": P,
-               "renoise_draws": pipe3.last_stats["renoise_draws"],
-               "note": "lra = true (README default): 3 UNet branches per prompt, 120.5 TFLOP per image; 1 warm-up + 1 timed batch"}
-    del u3, pipe3
+    kw = dict(precision=precision) if precision else dict(dtype=_dtype(args))
+    u = UNet2DConditionModel(latent_repeat=2, **kw)
+    u.load_synthetic_on_device(1234, device=dev)
+    pipe = SafeDenoiserPipeline(u, make_scheduler(args.scheduler), variant="threshold_time")
+    n = inference_steps or args.inference_steps
+    g = torch.Generator().manual_seed(7)
+    text = torch.randn(P, 77, 768, generator=g)
+    uncond = torch.randn(1, 77, 768, generator=torch.Generator().manual_seed(8))
+    E = torch.cat([uncond.expand(P, -1, -1), text]).to(dev)
+    gens = lambda: [torch.Generator(device=dev).manual_seed(1000 + i) for i in range(P)]
+    pipe(prompt_embeddings=E, num_inference_steps=3, guidance_scale=7.5, generator=gens(), repellency_processor=proc,
+         return_latents=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps_timed):
+        out = pipe(prompt_embeddings=E, num_inference_steps=n, guidance_scale=7.5, generator=gens(), repellency_processor=proc,
+                   return_latents=True)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps_timed
+    assert torch.isfinite(out).all()
+    fl, _ = u.flops(2 * P)
+    res = {"value": P / dt, "unit": "images/sec", "workload": "prompt embeddings -> latents, 2 CFG branches (the round-1/2 headline)",
+           "dtype": precision or args.dtype, "prompts_per_batch": P, "timed_batches": steps_timed, "inference_steps": n,
+           "renoise_draws": pipe.last_stats["renoise_draws"], "unet_tflops_algorithmic": fl * n / dt / 1e12}
+    del u, pipe
     torch.cuda.empty_cache()
-    return out
+    return res
+
+
+def measure_parity(args, dev, steps=10):
+    """Distance of each engine mode from the engine's own fp32 plan, measured IN THIS RUN: full SD-v1.4 size, 1 prompt,
+    CFG 7.5, DDPM, `steps` iterations from identical noise (a tape), every repellency gate firing.  The fp32 plan is the
+    stand-in for the reference's fp32 arithmetic (run_nudity.py:277): tests/test_gpu_f32.py pins it to the CPU oracle at
+    1.25e-5 on this very loop (profiles/round3_parity.json).  The oracle itself is not touched here."""
+    from safe_denoiser_amd.pipeline import SafeDenoiserPipeline, make_scheduler
+    from safe_denoiser_amd.repellency import repellency_methods_threshold as thr
+    from safe_denoiser_amd.unet import UNet2DConditionModel
+    g = torch.Generator().manual_seed(5)
+    E = torch.randn(2, 77, 768, generator=g).to(dev)
+    refs = torch.randn(64, 4, 64, 64, generator=g)
+    refs = refs / refs.norm(dim=1, keepdim=True)
+    tape = torch.randn(4 * steps, 1, 4, 64, 64, generator=g).to(dev)
+    path = os.path.join(tempfile.mkdtemp(prefix="sdn_parity_"), "pr.pt")
+    torch.save(refs, path)
+    proc = thr.get_repellency_method("kernel_fast", torch.zeros(1, device=dev), None, None, 50, 1000, 0.00085, 0.012, n_embed=4,
+                                     proj_ref_path=path, cache_proj_ref=True, sigma=3.15, scale=0.33, beta_threshold=1e-6,
+                                     beta_threshold_margin=1e9)
+    lat, draws = {}, {}
+    for name, kw in (("fp32", dict(precision="fp32")), ("bf16x3", dict(precision="bf16x3")), ("f16", dict(dtype=torch.float16)),
+                     ("bf16", dict(dtype=torch.bfloat16))):
+        u = UNet2DConditionModel(latent_repeat=2, **kw)
+        u.load_synthetic_on_device(1234, device=dev)                   # same generator stream: the 16-bit weights are the f32 ones rounded
+        cur = [0]
+
+        def noise(p, shape):
+            z = tape[cur[0]].reshape(shape)
+            cur[0] += 1
+            return z
+        pipe = SafeDenoiserPipeline(u, make_scheduler("ddpm"), variant="threshold_time")
+        lat[name] = pipe(prompt_embeddings=E, num_inference_steps=steps, guidance_scale=7.5, noise_fn=noise,
+                         repellency_processor=proc, return_latents=True).double()
+        draws[name] = pipe.last_stats["renoise_draws"]
+        del u, pipe
+        torch.cuda.empty_cache()
+    rel = {k: float((v - lat["fp32"]).norm() / lat["fp32"].norm()) for k, v in lat.items() if k != "fp32"}
+    return {"what": f"full SD-v1.4, 1 prompt, CFG 7.5, DDPM {steps} steps, tape noise, gate firing: rel L2 of each mode's final "
+                    f"latents vs the engine's fp32 plan, measured in this run",
+            "truth": "engine fp32 plan (pinned to the CPU fp32 oracle at 1.25e-5 / 1.27e-5 over 10 / 50 steps by tests/test_gpu_f32.py)",
+            "loop_rel_l2": rel, "renoise_draws": draws, "north_star_bound": 1e-3,
+            "meets_bound": {k: v <= 1e-3 for k, v in rel.items()}}
 
 
 def measure_sd3(dev, side, P, steps=50, refs_m=515):
@@ -267,10 +365,12 @@ def main():
     ap.add_argument("--total-prompts", type=int, default=515)
     ap.add_argument("--fire-fraction", type=float, default=0.5,
                     help="fraction of (prompt, window step) pairs whose repellency gate fires (0 = keep the R5 threshold)")
-    ap.add_argument("--no-extras", action="store_true", help="skip the b=3 (lra) and SD-v3 config-4 side measurements")
+    ap.add_argument("--workload", default="e2e", choices=["e2e", "latent"],
+                    help="e2e = the README-default call end to end (CLIP + SAFREE + 3-branch loop + VAE decode); latent = the round-1/2 "
+                         "headline (prompt embeddings in, latents out, 2 CFG branches)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary legs (latent-level b = 2 figure, bf16x3 precision mode, live parity, SD-v3 config 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latent-repeat", action="store_true", help="feed cat([latents] * 2) to a plain UNet plan")
-    ap.add_argument("--no-vae", action="store_true", help="skip the (untimed) VAE decoder measurement")
     args = ap.parse_args()
 
     # N > 1 without a launcher: become the launcher BEFORE anything touches the GPU (no re-exec of a GPU process)
@@ -298,21 +398,25 @@ def main():
 
     unet, pipe, proc, beta, bcast_ms, comm_ms = build_engine(args, rank, world, dev)
     P = args.prompts_per_batch
+    e2e = args.workload == "e2e"
+    nb = 3 if e2e else 2
     mine = sdist.shard_indices(args.total_prompts, rank, world)        # this rank's prompts of the 515-prompt job
-    g = torch.Generator().manual_seed(7)
-    text_all = torch.randn(args.total_prompts, 77, 768, generator=g)
-    uncond = torch.randn(1, 77, 768, generator=torch.Generator().manual_seed(8))
+    if e2e:
+        neg_prompt = ", ".join(NEG_SPACE)                               # run_nudity.py:345-371 for a safree_neg_prompt erase_id
+    else:
+        g = torch.Generator().manual_seed(7)
+        text_all = torch.randn(args.total_prompts, 77, 768, generator=g)
+        uncond = torch.randn(1, 77, 768, generator=torch.Generator().manual_seed(8))
 
-    def batch(k):
+    def run(k):
         idx = [mine[(k * P + j) % len(mine)] for j in range(P)]
-        E = torch.cat([uncond.expand(P, -1, -1), text_all[idx]]).to(dev)
         gens = [torch.Generator(device=dev).manual_seed(1000 + i) for i in idx]
-        return E, gens
-
-    def run(k, profile=False):
-        E, gens = batch(k)
-        if profile:
-            unet.profile_next()
+        if e2e:                                                         # the reference's call (run_nudity.py:439-460), batched
+            return pipe([synthetic_prompt(i) for i in idx], num_images_per_prompt=1, guidance_scale=7.5,
+                        num_inference_steps=args.inference_steps, negative_prompt=neg_prompt, negative_prompt_space=NEG_SPACE,
+                        height=512, width=512, generator=gens, repellency_processor=proc, safree_dict=dict(SAFREE),
+                        output_type="uint8")
+        E = torch.cat([uncond.expand(P, -1, -1), text_all[idx]]).to(dev)
         return pipe(prompt_embeddings=E, num_inference_steps=args.inference_steps, guidance_scale=7.5, generator=gens,
                     repellency_processor=proc, return_latents=True)
 
@@ -344,6 +448,7 @@ def main():
         gate = sdist.broadcast_scalar(gate if rank == 0 else 0.0, dev)
         proc.beta_threshold = gate + float(proc.beta_threshold_margin)          # is_negation = den > beta - margin = gate
         beta = proc.beta_threshold
+        sdist.heartbeat("gate placed")
     for k in range(args.warmup):
         run(k)
         sdist.heartbeat(f"warm-up batch {k + 1}/{args.warmup} done")
@@ -351,22 +456,29 @@ def main():
     t0 = time.perf_counter()
     renoise = 0
     window_pairs = 0
+    safree_removed, safree_steps = 0, 0
     for k in range(args.steps):
         out = run(args.warmup + k)
         renoise += pipe.last_stats["renoise_draws"]
         window_pairs += pipe.last_stats["window_steps"] * P
+        if e2e and pipe.last_safree is not None:
+            safree_removed += sum(pipe.last_safree["n_removed"])
+            safree_steps += sum(b_ or 0 for b_ in (pipe.last_safree["beta_adjusted"] or []))
     torch.cuda.synchronize()
     dt_mine = time.perf_counter() - t0                                  # this rank's own clock, before the closing barrier
     sdist.heartbeat(f"timed region done: {P * args.steps} images in {dt_mine:.1f} s")
     sdist.barrier()
     agg = sdist.throughput_over_ranks(P * args.steps, dt_mine, time.perf_counter() - t0, dev)
     dt, per_rank = agg["window_s"], agg["per_rank"]
-    assert torch.isfinite(out).all()
+    if e2e:
+        assert out.dtype == torch.uint8 and tuple(out.shape) == (P, 512, 512, 3)
+    else:
+        assert torch.isfinite(out).all()
 
     # ---- live kernel timing (HIP events on the launch stream) of one UNet forward at the benchmark shape ----
-    x = torch.randn(2 * P // unet.latent_repeat, 4, 64, 64, device=dev)
-    tb = unet.prepare_text(torch.randn(2 * P, 77, 768, device=dev))
-    y = torch.empty((2 * P, 4, 64, 64), device=dev)
+    x = torch.randn(nb * P // unet.latent_repeat, 4, 64, 64, device=dev)
+    tb = unet.prepare_text(torch.randn(nb * P, 77, 768, device=dev))
+    y = torch.empty((nb * P, 4, 64, 64), device=dev)
     unet.forward_into(x, 981.0, tb, y)
     rows_acc = {}
     for _ in range(3):
@@ -382,7 +494,7 @@ def main():
     attn = {k_: v for k_, v in rows_acc.items() if k_.startswith("k_attn")}
     attn_tf = sum(v["flops"] for v in attn.values()) / (sum(v["ms"] for v in attn.values()) * 1e-3) / 1e12
     unet_ms = sum(v["ms"] for v in rows_acc.values()) / 3
-    total_f, attn_f = unet.flops(2 * P)
+    total_f, attn_f = unet.flops(nb * P)
 
     # repellency projection (HBM-bound): algorithmic bytes = one read of proj_ref + x in/out
     xq = torch.randn(P, 4, 64, 64, device=dev)
@@ -403,58 +515,89 @@ def main():
     rep1_ms = e0.elapsed_time(e1) / 50
     rep1_bytes = args.refs * 16384 * 4 + 2 * 16384 * 4
 
-    # VAE decoder, measured OUTSIDE the timed region: `value` stays the latent-level metric of section
-    # 8d; the block below says what ending every image with decode_latents + uint8 would cost on top of it.
+    # where an end-to-end batch spends its time outside the UNet loop: the text front end (tokenise + CLIP encodes + SAFREE
+    # projection) and the VAE decode + uint8 tail, each timed on its own (untimed with respect to `value`)
+    stages = None
     vae_block = None
-    if rank == 0 and not args.no_vae:
-        from safe_denoiser_amd.vae import AutoencoderKL
-        vae = AutoencoderKL(dtype=torch.float16 if args.dtype == "f16" else torch.bfloat16)
-        vae.load_synthetic_on_device(4321, device=dev)
-        zl = torch.randn(16, 4, 64, 64, device=dev) * 0.18215
-        vae.decode_latents_uint8(zl)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(3):
-            vae.decode_latents_uint8(zl)
-        e1.record(); torch.cuda.synchronize()
-        vae_ms = e0.elapsed_time(e1) / 3 / 16
-        vae_fl, _ = vae.flops(1)
+    if e2e:
+        idx = [mine[j % len(mine)] for j in range(P)]
+        prompts = [synthetic_prompt(i) for i in idx]
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        E2, _ids, am = pipe._new_encode_prompt(prompts, neg_prompt)
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        pipe._safree_prepare(prompts, E2, am, NEG_SPACE, dict(SAFREE))
+        torch.cuda.synchronize(); t3 = time.perf_counter()
+        zl = torch.randn(P, 4, 64, 64, device=dev) * 0.18215
+        pipe.vae.decode_latents_uint8(zl)
+        torch.cuda.synchronize(); t4 = time.perf_counter()
+        pipe.vae.decode_latents_uint8(zl)
+        torch.cuda.synchronize(); t5 = time.perf_counter()
+        vae_fl, _ = pipe.vae.flops(1)
+        vae_ms = (t5 - t4) * 1e3 / P
+        batch_ms = dt / args.steps * 1e3
+        stages = {"batch_ms": batch_ms, "encode_prompts_ms": (t2 - t1) * 1e3, "safree_masked_encodes_and_projection_ms": (t3 - t2) * 1e3,
+                  "vae_decode_uint8_ms": (t5 - t4) * 1e3,
+                  "unet_loop_and_rest_ms": batch_ms - (t2 - t1) * 1e3 - (t3 - t2) * 1e3 - (t5 - t4) * 1e3,
+                  "note": "front end and decode re-timed after the timed region on one batch; the remainder is the 50-iteration loop"}
         vae_block = {"ms_per_image": vae_ms, "tflop_per_image": vae_fl / 1e12, "tflops": vae_fl / (vae_ms * 1e-3) / 1e12,
-                     "images_per_sec_with_decode_1gpu": 1.0 / (dt / (P * args.steps) + vae_ms * 1e-3),
-                     "note": "decode_latents + uint8 conversion of 16 images in chunks of 8, outside the timed region"}
-        del vae, zl
+                     "note": f"decode_latents + uint8 conversion of {P} images (inside the timed region of `value`)"}
+        del zl
 
     # HBM bytes per launch of the dominant kernel from the PMC passes (tools/pmc_traffic.py; collected in separate
-    # rocprofv3 --pmc runs, which cannot be combined with timing) -- read from profiles/ when present
+    # rocprofv3 --pmc runs, which cannot be combined with timing).  The record carries the sha256 of the libsdn.so it was
+    # collected on: a record made on another build is NOT reported (traffic = null with the reason).
     traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "round2_traffic.json")
-    if not os.path.exists(tpath):
-        tpath = os.path.join(ROOT, "profiles", "round1_traffic.json")
-    if os.path.exists(tpath):
-        tname = "F16" if args.dtype == "f16" else "BF16"
-        if dom == "k_conv_slab":      # one plan label, three instantiations (map width 64 / 32 / 16): launch-weighted mean
-            want = [f"k_conv_slab<Sdn{tname}, {w_}>" for w_ in (64, 32, 16)]
+    import glob
+    import hashlib
+    import safe_denoiser_amd as sda
+    lib_sha = hashlib.sha256(open(sda.lib_path(), "rb").read()).hexdigest()
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_traffic.json")))
+    if not cands:
+        traffic_src = "no PMC record under profiles/"
+    else:
+        rec_all = json.load(open(cands[-1]))
+        meta = rec_all.get("__meta__", {})
+        if meta.get("libsdn_sha256") != lib_sha:
+            traffic_src = (f"profiles/{os.path.basename(cands[-1])} was collected on another build of libsdn.so "
+                           f"(record {str(meta.get('libsdn_sha256'))[:12]}, running {lib_sha[:12]}): stale, not reported")
         else:
-            want = [dom.replace("k_gemm<", f"k_gemm_dma<Sdn{tname}, ").replace(">", ",")]
-        hit = [rec for kname, rec in json.load(open(tpath)).items() if any(w_ in kname for w_ in want)]
-        if hit:
-            traffic = sum(r["hbm_bytes_per_launch"] * r["launches"] for r in hit) / sum(r["launches"] for r in hit)
-            traffic_src = f"profiles/{os.path.basename(tpath)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)"
+            tname = "F16" if args.dtype == "f16" else "BF16"
+            if dom == "k_conv_slab":  # one plan label, three instantiations (map width 64 / 32 / 16): launch-weighted mean
+                want = [f"k_conv_slab<Sdn{tname}, {w_}>" for w_ in (64, 32, 16)]
+            else:
+                want = [dom.replace("k_gemm<", f"k_gemm_dma<Sdn{tname}, ").replace(">", ",")]
+            hit = [rec for kname, rec in rec_all.items() if kname != "__meta__" and any(w_ in kname for w_ in want)]
+            if hit:
+                traffic = sum(r["hbm_bytes_per_launch"] * r["launches"] for r in hit) / sum(r["launches"] for r in hit)
+                traffic_src = (f"profiles/{os.path.basename(cands[-1])} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected; "
+                               f"git {meta.get('git_head', '?')[:10]}, same libsdn.so as this run, batch {meta.get('batch', '?')})")
+            else:
+                traffic_src = f"profiles/{os.path.basename(cands[-1])} has no row for {dom}"
     n_img = world * P * args.steps
     value = n_img / dt
+    by_tf = {k_: v["flops"] / (v["ms"] * 1e-3) / 1e12 for k_, v in sorted(rows_acc.items(), key=lambda kv: -kv[1]["ms"])[:5]}
+    if e2e:
+        workload = (f"README-default end to end (safree = svf = lra = true, safree_neg_prompt_config.json:26-28): token ids -> CLIP -> "
+                    f"SAFREE projection -> {args.scheduler.upper()} {args.inference_steps} steps x UNet on 3 guidance branches with "
+                    f"per-prompt text switching + safe_denoiser.yaml repellency (kernel_fast, M={args.refs}, sigma 3.15, scale .33, "
+                    f"margin 1.6, window 780<=t<=1000) -> VAE decode -> uint8 512x512 images; SD-v1.4 UNet / CLIP / VAE with random "
+                    f"weights, {args.total_prompts}-prompt job sharded r::{world}, CFG 7.5, 120.5 TFLOP of UNet work per image")
+    else:
+        workload = (f"SD-v1.4 UNet (random weights) + safe_denoiser.yaml repellency (kernel_fast, M={args.refs}, sigma 3.15, scale "
+                    f".33, margin 1.6, window 780<=t<=1000), {args.total_prompts}-prompt job sharded r::{world}, CFG 7.5 (2 "
+                    f"branches), {args.scheduler.upper()} {args.inference_steps} steps, prompt embeddings in, 64x64x4 latents out")
     line = {
         "metric": "images/sec (512x512, 50 steps, SD-v1.4 + repellency)", "value": value, "unit": "images/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"SD-v1.4 UNet (random weights) + safe_denoiser.yaml repellency (kernel_fast, M={args.refs}, "
-                               f"sigma 3.15, scale .33, margin 1.6, window 780<=t<=1000), {args.total_prompts}-prompt job "
-                               f"sharded r::{world}, CFG 7.5 (2 branches), {args.scheduler.upper()} {args.inference_steps} "
-                               f"steps, 64x64x4 latents",
+        "config": {"workload": workload, "guidance_branches": nb,
                    "prompts_per_batch": P, "latent_repeat": unet.latent_repeat, "images_timed": n_img, "beta_threshold": beta,
                    "renoise_draws_rank0": renoise,
                    "gate": {"r5_calibrated_beta_threshold": r5_beta, "margin": float(proc.beta_threshold_margin),
                             "placement": placement,
                             "fired_fraction_rank0": renoise / max(window_pairs, 1)},
+                   **({"safree": {"trigger_tokens_removed_rank0": safree_removed,
+                                  "mean_projected_text_steps_per_prompt": safree_steps / max(P * args.steps, 1)}} if e2e else {}),
                    "parallelism": f"prompt-shard x{world}",
                    "per_rank_images_per_sec": per_rank, "proj_ref_broadcast_ms": bcast_ms, "communicator_setup_ms": comm_ms,
                    **({"rehearsal": "SDN_SHARE_GPU=1: ranks share the visible GPU(s) and talk over gloo -- a functional check of "
@@ -476,9 +619,10 @@ def main():
                                                       for k_, v in attn.items()},
                                "kernels": {k_: {"avg_launch_us": v["ms"] / v["launches"] * 1e3,
                                                 "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12} for k_, v in attn.items()}},
-        "unet": {"ms_per_forward": unet_ms, "batch": 2 * P, "tflops": total_f / (unet_ms * 1e-3) / 1e12,
+        "unet": {"ms_per_forward": unet_ms, "batch": nb * P, "tflops": total_f / (unet_ms * 1e-3) / 1e12,
                  "attention_core_share_of_flops": attn_f / total_f,
-                 "by_kernel_ms": {k_: v["ms"] / 3 for k_, v in sorted(rows_acc.items(), key=lambda kv: -kv[1]["ms"])}},
+                 "by_kernel_ms": {k_: v["ms"] / 3 for k_, v in sorted(rows_acc.items(), key=lambda kv: -kv[1]["ms"])},
+                 "by_kernel_tflops": by_tf},
         "repellency_roofline": {"bound": "hbm", "achieved": rep_bytes / (rep_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
                                 "unit": "GB/s", "frac": rep_bytes / (rep_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                                 "us_per_call": rep_ms * 1e3, "queries": P,
@@ -486,18 +630,29 @@ def main():
                                                  "achieved": rep1_bytes / (rep1_ms * 1e-3) / 1e9,
                                                  "frac": rep1_bytes / (rep1_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}},
     }
+    if stages is not None:
+        line["stages"] = stages
     if vae_block is not None:
         line["vae_decode"] = vae_block
     if rank == 0 and world == 1 and not args.no_extras:
-        line["lra_b3"] = measure_lra_b3(args, dev, proc, text_all, uncond, mine, P)
         del unet, pipe
         torch.cuda.empty_cache()
+        sdist.heartbeat("secondary legs")
+        if e2e:          # the round-1/2 headline, same gate: what the 16-bit engine does on the latent-level workload ...
+            line["latent_b2"] = measure_latent(args, dev, proc, P, steps_timed=2)
+        # ... and the mode that meets the north star's 1e-3 on that same workload (fp32 storage, split-operand contractions)
+        line["precision_mode_bf16x3"] = measure_latent(args, dev, proc, min(P, 32), precision="bf16x3", steps_timed=1)
+        if "latent_b2" in line:
+            line["precision_mode_bf16x3"]["relative_to_16bit_engine_same_workload"] = \
+                line["precision_mode_bf16x3"]["value"] / line["latent_b2"]["value"]
+        line["parity"] = measure_parity(args, dev)
         line["sd3_config4"] = {"512x512": measure_sd3(dev, 64, 8), "1024x1024": measure_sd3(dev, 128, 4)}
-    ppath = os.path.join(ROOT, "profiles", "round2_parity.json")
-    if os.path.exists(ppath):                       # written by tests/test_gpu_f32.py on the GPU box, committed under profiles/
-        line["parity"] = json.load(open(ppath))
+    ppath = os.path.join(ROOT, "profiles", "round3_parity.json")
+    if os.path.exists(ppath):                       # the GPU suite's record vs the CPU oracle (tests/test_gpu_f32.py), committed
+        line.setdefault("parity", {})["suite_record_vs_cpu_oracle"] = json.load(open(ppath))["modes"]
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
+            sdist.heartbeat("cpu baseline")
             line["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(line))
 

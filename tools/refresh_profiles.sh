@@ -1,7 +1,8 @@
 #!/bin/bash
 # Re-collects the evidence bench.py's roofline block cites (run on the GPU box via gpurun, from the repo root):
 #   tools/refresh_profiles.sh <tag>      -> gpurun_out/<tag>_{kernel_stats.csv,bench_under_rocprof.json,bench.json,traffic.json}
-# Copy the four files into profiles/ (traffic.json as profiles/round2_traffic.json, which bench.py reads) to have them judged.
+# Copy the four files into profiles/ (traffic.json as profiles/roundN_traffic.json: bench.py reads the newest one and reports it only
+# when its libsdn.so sha256 equals the running library) to have them judged.  Pass SDN_GIT_HEAD=$(git rev-parse HEAD) through gpurun.
 set -eo pipefail
 TAG=${1:-refresh}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
@@ -16,9 +17,9 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $RAW/stats -o s --output-format csv -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_rocprof.err
 cp $RAW/stats/s_kernel_stats.csv $OUT/${TAG}_kernel_stats.csv
 # 2. PMC passes, counters only (separate runs: TCC has few slots; never combined with other trace domains)
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $RAW/pmc_f -o f --output-format csv -- python3 $ROOT/bench.py --steps 1 --warmup 0 --inference-steps 2 --no-cpu-baseline --no-extras --no-vae > /dev/null 2>> $OUT/${TAG}_rocprof.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $RAW/pmc_w -o w --output-format csv -- python3 $ROOT/bench.py --steps 1 --warmup 0 --inference-steps 2 --no-cpu-baseline --no-extras --no-vae > /dev/null 2>> $OUT/${TAG}_rocprof.err
-python3 $ROOT/tools/pmc_traffic.py $RAW/pmc_f/f_counter_collection.csv $RAW/pmc_w/w_counter_collection.csv $OUT/${TAG}_traffic.json
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $RAW/pmc_f -o f --output-format csv -- python3 $ROOT/bench.py --steps 1 --warmup 0 --inference-steps 2 --no-cpu-baseline --no-extras > /dev/null 2>> $OUT/${TAG}_rocprof.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $RAW/pmc_w -o w --output-format csv -- python3 $ROOT/bench.py --steps 1 --warmup 0 --inference-steps 2 --no-cpu-baseline --no-extras > /dev/null 2>> $OUT/${TAG}_rocprof.err
+python3 $ROOT/tools/pmc_traffic.py $RAW/pmc_f/f_counter_collection.csv $RAW/pmc_w/w_counter_collection.csv $OUT/${TAG}_traffic.json "3 x 64 (e2e default)"
 # 3. the plain default bench line
 cd $ROOT && python3 bench.py > $OUT/${TAG}_bench.json 2>> $OUT/${TAG}_rocprof.err
 tail -c 300 $OUT/${TAG}_bench.json
