@@ -201,6 +201,38 @@ def measure_latent(args, dev, proc, P, precision=None, steps_timed=1, inference_
     return res
 
 
+def measure_e2e_elided(args, dev, proc, P, mine):
+    """The headline call with `elide_dead_branch=True`: `lra`'s third guidance branch, whose output the reference discards
+    (...threshold_time.py:542-544), is not computed -- bit-identical images (tests/test_gpu_pipeline.py), 2/3 of the UNet work.
+    NOT the headline: `value` keeps the reference's three branches.  One warm-up (3 iterations) + one timed batch."""
+    from safe_denoiser_amd.clip import CLIPTextModel
+    from safe_denoiser_amd.pipeline import SafeDenoiserPipeline, make_scheduler
+    from safe_denoiser_amd.unet import UNet2DConditionModel
+    from safe_denoiser_amd.vae import AutoencoderKL
+    from tests_support.fake_tokenizer import FakeCLIPTokenizer
+    u = UNet2DConditionModel(dtype=_dtype(args), latent_repeat=2); u.load_synthetic_on_device(1234, device=dev)
+    enc = CLIPTextModel(dtype=_dtype(args)); enc.load_synthetic_on_device(4242, device=dev)
+    vae = AutoencoderKL(dtype=_dtype(args)); vae.load_synthetic_on_device(4321, device=dev)
+    pipe = SafeDenoiserPipeline(u, make_scheduler(args.scheduler), variant="threshold_time", vae=vae, text_encoder=enc,
+                                tokenizer=FakeCLIPTokenizer(), elide_dead_branch=True)
+    idx = [mine[j % len(mine)] for j in range(P)]
+    call = lambda n: pipe([synthetic_prompt(i) for i in idx], guidance_scale=7.5, num_inference_steps=n,
+                          negative_prompt=", ".join(NEG_SPACE), negative_prompt_space=NEG_SPACE,
+                          generator=[torch.Generator(device=dev).manual_seed(1000 + i) for i in idx], repellency_processor=proc,
+                          safree_dict=dict(SAFREE), output_type="uint8")
+    call(3)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    out = call(args.inference_steps)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    res = {"value": P / dt, "unit": "images/sec", "guidance_branches_computed": pipe.last_stats["branches"], "prompts_per_batch": P,
+           "note": "the headline call with lra's dead third branch not computed: bit-identical images, 80.3 TFLOP of UNet work per "
+                   "image instead of 120.5; a labelled secondary, not `value`"}
+    assert out.dtype == torch.uint8
+    del u, enc, vae, pipe
+    torch.cuda.empty_cache()
+    return res
+
+
 def measure_parity(args, dev, steps=10):
     """Distance of each engine mode from the engine's own fp32 plan, measured IN THIS RUN: full SD-v1.4 size, 1 prompt,
     CFG 7.5, DDPM, `steps` iterations from identical noise (a tape), every repellency gate firing.  The fp32 plan is the
@@ -640,6 +672,7 @@ def main():
         sdist.heartbeat("secondary legs")
         if e2e:          # the round-1/2 headline, same gate: what the 16-bit engine does on the latent-level workload ...
             line["latent_b2"] = measure_latent(args, dev, proc, P, steps_timed=2)
+            line["e2e_dead_branch_elided"] = measure_e2e_elided(args, dev, proc, P, mine)
         # ... and the mode that meets the north star's 1e-3 on that same workload (fp32 storage, split-operand contractions)
         line["precision_mode_bf16x3"] = measure_latent(args, dev, proc, min(P, 32), precision="bf16x3", steps_timed=1)
         if "latent_b2" in line:

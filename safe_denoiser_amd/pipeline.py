@@ -47,7 +47,7 @@ class SafeDenoiserPipeline:
     GRAPH_MAX_BATCH = 16      # UNet rows (branches x prompts) up to which a forward is launch-bound and replayed as a hipGraph
 
     def __init__(self, unet, scheduler, variant: str = "threshold_time", vae=None, use_graphs: Optional[bool] = None,
-                 text_encoder=None, tokenizer=None, split_k: bool = False):
+                 text_encoder=None, tokenizer=None, split_k: bool = False, elide_dead_branch: bool = False):
         if variant not in VARIANTS:
             raise KeyError(f"unknown variant {variant}; have {sorted(VARIANTS)}")
         self.unet, self.scheduler, self.variant, self.vae = unet, scheduler, variant, vae
@@ -57,6 +57,11 @@ class SafeDenoiserPipeline:
         # split_k=True: small batches additionally run their long, thin GEMMs in split-K form (lower single-prompt latency;
         # a prompt's result then depends, in the last fp32 bits, on how many prompts share its batch)
         self.split_k = split_k
+        # `lra` makes the reference run a THIRD guidance branch ([uncond | text' | text]) whose output it then discards
+        # (`noise_pred_uncond, noise_pred_text, _ = noise_pred.chunk(3)`, ...threshold_time.py:542-544); samples do not interact
+        # inside the UNet, so the two live branches give the same bits without it.  Off by default: the engine then does the
+        # reference's work, branch for branch.  True = skip the dead branch (same images, 2/3 of the UNet work).
+        self.elide_dead_branch = elide_dead_branch
         self.vae_scale_factor = 8
         self.last_stats = {}
         self.last_safree = None
@@ -194,7 +199,7 @@ class SafeDenoiserPipeline:
         else:                                                         # reference: t <= start and t >= end
             hi = kwargs.get("negation_warmup_start", hi_default)
             lo = kwargs.get("negation_warmup_end", 780 if (sld and self.variant == "time") else lo_default)
-        nb = 3 if (sf["lra"] or sld) else 2
+        nb = 3 if ((sf["lra"] and not self.elide_dead_branch) or sld) else 2
         if guidance_scale <= 1.0:
             raise NotImplementedError("guidance_scale <= 1 (no CFG) is not on the reference's benchmarked path")
         dev = torch.device("cuda", torch.cuda.current_device())

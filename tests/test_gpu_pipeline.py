@@ -293,3 +293,22 @@ def test_window_kwargs_follow_each_variant(world, tmp_path):
     assert windows("sd_threshold_time", negation_warmup_start=2, negation_warmup_end=4) == 3   # i in {2, 3, 4}
     assert windows("threshold_time") == 2                                                      # t = 901, 801 are >= 780
     assert windows("threshold_time", negation_warmup_start=700, negation_warmup_end=400) == 3  # t = 601, 501, 401
+
+
+def test_eliding_the_dead_lra_branch_gives_the_same_bits(world, tmp_path):
+    """`lra`: the reference computes a third guidance branch and discards its output (...threshold_time.py:542-544).  With
+    elide_dead_branch=True the engine runs the two live branches only: identical latents, identical draw counts."""
+    u, sd, E, refs, P = world
+    Es = _safe_text(E, P, 77)
+    sf = dict(safree=True, svf=True, lra=True, re_attn_t=(-1, -1))
+    params = dict(sigma=3.15, scale=0.33, beta_threshold=1e-6, beta_threshold_margin=1e9)
+    outs, draws = [], []
+    for elide in (False, True):
+        pipe = SafeDenoiserPipeline(u, DDPMScheduler(), variant="threshold_time", elide_dead_branch=elide)
+        outs.append(pipe(prompt_embeddings=E.cuda(), num_inference_steps=STEPS, repellency_processor=make_proc(thr, refs, tmp_path, **params),
+                         noise_fn=Tapes(P, (1, 4, 16, 16), 3 * STEPS + 4, seed=21), safree_dict=sf, rescaled_text_embeddings=Es.cuda(),
+                         beta_adjusted=[3, 0, 7][:P], return_latents=True))
+        draws.append(pipe.last_stats["renoise_draws"])
+        assert pipe.last_stats["branches"] == (2 if elide else 3)
+    assert draws[0] == draws[1] > 0
+    torch.testing.assert_close(outs[1], outs[0], rtol=0, atol=0)

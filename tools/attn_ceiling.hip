@@ -1,0 +1,140 @@
+// No-memory ceiling of the d = 40 flash-attention inner loop on gfx950 ("... or a committed no-memory
+// microbenchmark of the exact instruction mix proving the ceiling is below it").
+//
+// k_attn<bf16, 40, QS = 2> (csrc/sdn_attn.hip) executes, per wave and per 64-key tile, for each of its QS = 2 sets of 32 queries:
+//   QK^T : 2 key blocks x 3 k-steps (d = 40 padded to 48)            =  6 v_mfma_f32_32x32x16_bf16
+//   softmax: running max over 32 scores (v_max3), one v_permlane32_swap, 32 v_exp_f32 (offset-free form: no subtraction)
+//   PV   : 4 key quarters x 2 row blocks (d = 40 + ones column -> 64) =  8 v_mfma_f32_32x32x16_bf16, each fed by 4 v_cvt_pk_bf16_f32
+// i.e. 28 MFMAs (896 matrix-pipe cycles) and ~2 x (32 exp + 16 cvt_pk + 16 max3 + 2) vector instructions per wave-tile, for
+// 2 * 4 * 32 * 64 * 40 = 655,360 algorithmic FLOP.  This program runs exactly that mix with EVERY operand already in
+// registers -- no LDS reads, no LDS-DMA, no barriers, no global memory in the loop -- at the kernel's occupancy (2 waves per
+// SIMD, all 256 CUs), and reports the attention TFLOP/s it corresponds to:
+//   mix   : the full mix                          -> the ceiling of ANY schedule of this instruction mix
+//   mfma  : the 28 MFMAs alone                    -> the matrix-pipe bound at the clock the chip holds
+//   valu  : the softmax / pack vector work alone  -> the vector-issue bound
+// Build + run on the GPU box:  hipcc -O3 --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form tools/attn_ceiling.hip -o /tmp/attn_ceiling && /tmp/attn_ceiling
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+__device__ __forceinline__ unsigned pk(float a, float b) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 v2;
+  v2 p = {(__bf16)a, (__bf16)b};
+  return *reinterpret_cast<unsigned*>(&p);
+}
+
+// MODE 0 = full mix, 1 = MFMAs only, 2 = vector work only
+template <int MODE, int QS>
+__global__ void __launch_bounds__(256) k_mix(float* out, int tiles) {
+  const int lane = threadIdx.x & 63;
+  bf16x8 kf[2][3], qf[QS][3], vf[8];
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 3; ++j) _Pragma("unroll") for (int e = 0; e < 8; ++e) kf[i][j][e] = (__bf16)(0.01f * ((lane * 7 + i * 3 + j * 5 + e) % 13 - 6));
+  _Pragma("unroll") for (int s = 0; s < QS; ++s) _Pragma("unroll") for (int j = 0; j < 3; ++j) _Pragma("unroll") for (int e = 0; e < 8; ++e) qf[s][j][e] = (__bf16)(0.02f * ((lane * 5 + s * 3 + j * 7 + e) % 11 - 5));
+  _Pragma("unroll") for (int i = 0; i < 8; ++i) _Pragma("unroll") for (int e = 0; e < 8; ++e) vf[i][e] = (__bf16)(0.03f * ((lane * 3 + i * 5 + e) % 9 - 4));
+  f32x16 o[QS][2];
+  float m_hi[QS];
+  _Pragma("unroll") for (int s = 0; s < QS; ++s) { m_hi[s] = -1e30f; _Pragma("unroll") for (int d = 0; d < 2; ++d) _Pragma("unroll") for (int i = 0; i < 16; ++i) o[s][d][i] = 0.f; }
+  f32x16 st[QS][2];
+  _Pragma("unroll") for (int s = 0; s < QS; ++s) _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) _Pragma("unroll") for (int i = 0; i < 16; ++i) st[s][kb][i] = 0.001f * (lane + i + kb);
+  for (int t = 0; t < tiles; ++t) {
+    // the fragments of the next tile: opaque to the compiler (in the kernel they arrive from LDS), no instruction emitted
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(kf[i][j]));
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(vf[i]));
+    if (MODE != 2) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s = 0; s < QS; ++s) {
+          f32x16 z;
+          _Pragma("unroll") for (int i = 0; i < 16; ++i) z[i] = 0.f;
+#pragma unroll
+          for (int j = 0; j < 3; ++j) z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kb][j], qf[s][j], z, 0, 0, 0);
+          st[s][kb] = z;
+        }
+    }
+    if (MODE != 1) {
+#pragma unroll
+      for (int s = 0; s < QS; ++s) {
+        float mx = fmaxf(st[s][0][0], st[s][1][0]);
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mx = fmaxf(fmaxf(mx, st[s][0][i]), st[s][1][i]);
+        const unsigned u = __float_as_uint(mx);
+        const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        m_hi[s] = fmaxf(m_hi[s], mx);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) st[s][kb][i] = __builtin_amdgcn_exp2f(st[s][kb][i]);
+      }
+    }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int item = 0; item < 8; ++item) {
+      const int kb = item >> 2, s2 = (item >> 1) & 1, d = item & 1;
+#pragma unroll
+      for (int s = 0; s < QS; ++s) {
+        u32x4 pw;
+        if (MODE != 1) {
+          pw.x = pk(st[s][kb][8 * s2 + 0], st[s][kb][8 * s2 + 1]); pw.y = pk(st[s][kb][8 * s2 + 2], st[s][kb][8 * s2 + 3]);
+          pw.z = pk(st[s][kb][8 * s2 + 4], st[s][kb][8 * s2 + 5]); pw.w = pk(st[s][kb][8 * s2 + 6], st[s][kb][8 * s2 + 7]);
+        } else {
+          pw.x = __float_as_uint(st[s][kb][8 * s2]); pw.y = __float_as_uint(st[s][kb][8 * s2 + 2]);
+          pw.z = __float_as_uint(st[s][kb][8 * s2 + 4]); pw.w = __float_as_uint(st[s][kb][8 * s2 + 6]);
+        }
+        if (MODE != 2) o[s][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[item], *reinterpret_cast<bf16x8*>(&pw), o[s][d], 0, 0, 0);
+        else { o[s][d][0] += __uint_as_float(pw.x ^ pw.y ^ pw.z ^ pw.w); }
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+  }
+  float acc = 0.f;
+  _Pragma("unroll") for (int s = 0; s < QS; ++s) { acc += m_hi[s]; _Pragma("unroll") for (int d = 0; d < 2; ++d) _Pragma("unroll") for (int i = 0; i < 16; ++i) acc += o[s][d][i]; }
+  out[(size_t)blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
+template <int MODE, int QS>
+static double run(int blocks, int tiles, float* out) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL((k_mix<MODE, QS>), dim3(blocks), dim3(256), 0, 0, out, tiles);   // warm-up (clock ramp)
+  hipLaunchKernelGGL((k_mix<MODE, QS>), dim3(blocks), dim3(256), 0, 0, out, tiles);
+  hipDeviceSynchronize();
+  hipEventRecord(e0, 0);
+  for (int r = 0; r < 5; ++r) hipLaunchKernelGGL((k_mix<MODE, QS>), dim3(blocks), dim3(256), 0, 0, out, tiles);
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, e0, e1);
+  ms /= 5;
+  const double flop = (double)blocks * 4 /*waves*/ * tiles * (4.0 * 32 * QS * 64 * 40);
+  return flop / (ms * 1e-3) / 1e12;
+}
+
+int main() {
+  hipDeviceProp_t p;
+  hipGetDeviceProperties(&p, 0);
+  const int cus = p.multiProcessorCount;
+  float* out;
+  hipMalloc(&out, (size_t)cus * 8 * 256 * sizeof(float));
+  const int tiles = 4096;
+  printf("{\"device\": \"%s\", \"cus\": %d, \"tiles_per_wave\": %d, \"what\": \"d = 40 flash-attention inner-loop instruction mix, operands in registers, no LDS / global memory / barriers; attention TFLOP/s equivalent (4*Nq*Nk*d)\",\n", p.gcnArchName, cus, tiles);
+  // QS = 2 at 2 waves per SIMD (the kernel's occupancy: 207 VGPRs) = 2 blocks of 4 waves per CU; also 1 and 4 per CU for reference
+  for (int per_cu = 1; per_cu <= 4; per_cu *= 2) {
+    const int blocks = cus * per_cu;
+    printf(" \"qs2_blocks_per_cu_%d\": {\"mix\": %.1f, \"mfma_only\": %.1f, \"valu_only\": %.1f},\n", per_cu,
+           run<0, 2>(blocks, tiles, out), run<1, 2>(blocks, tiles, out), run<2, 2>(blocks, tiles, out));
+  }
+  for (int per_cu = 2; per_cu <= 4; per_cu *= 2) {
+    const int blocks = cus * per_cu;
+    printf(" \"qs1_blocks_per_cu_%d\": {\"mix\": %.1f, \"mfma_only\": %.1f, \"valu_only\": %.1f},\n", per_cu,
+           run<0, 1>(blocks, tiles, out), run<1, 1>(blocks, tiles, out), run<2, 1>(blocks, tiles, out));
+  }
+  printf(" \"peak_bf16_tflops\": 2500.0, \"target_40pct\": 1000.0}\n");
+  hipFree(out);
+  return 0;
+}
