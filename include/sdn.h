@@ -316,6 +316,16 @@ int sdn_attention_x3(const void* q, const void* k, const void* v, void* out, int
                      int32_t nq, int32_t nk, int32_t head_dim, int32_t ldq, int32_t ldk, int32_t ldv,
                      int32_t ldo, float scale, void* stream);
 
+/* ---- random draws (row S2): P per-prompt generators in one launch ------------------------------------------------
+ * Replaces the per-prompt `torch.randn(latents_shape, generator=gen)` calls behind prepare_latents / scheduler.step /
+ * add_noise (...threshold_time.py:494-503,554,565-567,576; run_nudity.py:142,448) bit for bit: Philox4x32-10 seeded
+ * (seed, subsequence = thread index, offset = the generator's philox offset), Box-Muller normal4, torch's launch geometry.
+ * out[rows[p] or p, 0..numel) is what `torch.randn(numel, generator=g_p)` would return; afterwards advance generator p by
+ * the increment sdn_randn_philox_plan reports (torch.Generator.set_offset).  seeds / offsets / rows: device arrays. */
+int sdn_randn_philox_plan(int64_t numel, int32_t* grid_out, int64_t* offset_increment_out);
+int sdn_randn_philox(const uint64_t* seeds, const uint64_t* offsets, const int32_t* rows, int32_t n_gen, int64_t numel,
+                     float* out, void* stream);
+
 /* ---- whole-network entry: SD-v1.4-family UNet2DConditionModel forward -------------------------- */
 typedef struct sdn_unet_config {
   int32_t in_channels, out_channels, sample_size;      /* 4, 4, 64                                  */

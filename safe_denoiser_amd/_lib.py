@@ -125,6 +125,8 @@ SIGNATURES = {
     "sdn_groupnorm_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "sdn_layernorm_f32": (C.c_int, [_vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp]),
     "sdn_attention_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "sdn_randn_philox_plan": (C.c_int, [C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    "sdn_randn_philox": (C.c_int, [_vp, _vp, _vp, _i32, C.c_int64, _vp, _vp]),
     "sdn_gemm_x3": (C.c_int, [C.POINTER(GemmDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sdn_attention_x3": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "sdn_conv_in_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),

@@ -66,6 +66,8 @@ class SafeDenoiserPipeline:
         self.last_stats = {}
         self.last_safree = None
         self._bufs = {}
+        self._rngs = {}
+        self.batched_rng = True    # False: per-prompt torch.randn calls (the draws are the same bits either way)
         self.record_den = False    # diagnostics: keep each window step's denominators (device tensors, no sync) in last_stats
         # SLDPipeline._safety_text_concept: the default of the third-party base class the reference's SLD pipelines inherit
         # (python_sld == 1.0.10, requirements.txt:16; not in /root/reference -- restated from the published package)
@@ -112,6 +114,14 @@ class SafeDenoiserPipeline:
     def to(self, *args, **kwargs):
         """`pipe.to(device)` of the reference's load_sd (run_nudity.py:131): the engine's weights already live on the GPU."""
         return self
+
+    def _rng_for(self, dev, numel: int):
+        from .rng import BatchedNormal
+        key = (str(dev), int(numel))
+        r = self._rngs.get(key)
+        if r is None:
+            r = self._rngs[key] = BatchedNormal(dev, numel)
+        return r if self.batched_rng else None
 
     def _noise(self, noise_fn, generators, p: int, shape, device):
         if noise_fn is not None:
@@ -242,10 +252,27 @@ class SafeDenoiserPipeline:
             if len(beta_list) != P:
                 raise _lib.SdnError(f"beta_adjusted: need one value per prompt ({P}), got {len(beta_list)}")
         gens = self._generators(generator, P, dev) if noise_fn is None else None
+        # one launch per draw kind for the whole batch, bit-identical to the per-prompt torch.randn calls (rng.py); a noise
+        # tape (tests) and exotic generators keep the per-prompt path
+        rng = self._rng_for(dev, D) if (gens is not None and all(g_.device.type == "cuda" for g_ in gens)) else None
+
+        def draw_into(dst, which=None):
+            if rng is not None:
+                rng.draw(gens, dst, which, shape1)
+            else:
+                for p in (range(P) if which is None else which):
+                    dst[p:p + 1] = self._noise(noise_fn, gens, p, shape1, dev)
+
+        def draw_discard():
+            if rng is not None:
+                rng.skip(gens)
+            else:
+                for p in range(P):
+                    self._noise(noise_fn, gens, p, shape1, dev)
+
         if latents is None:
             lat = torch.empty((P, C_, s, s), dtype=torch.float32, device=dev)
-            for p in range(P):
-                lat[p:p + 1] = self._noise(noise_fn, gens, p, shape1, dev)
+            draw_into(lat)
             lat = lat * sch.init_noise_sigma if sch.init_noise_sigma != 1.0 else lat
         else:
             lat = latents.to(device=dev, dtype=torch.float32).clone()
@@ -322,8 +349,7 @@ class SafeDenoiserPipeline:
                 _lib.check(L.sdn_pred_x0(lat.data_ptr(), eps.data_ptr(), lat.numel(), sa, s1, clip, x0.data_ptr(), st),
                            "sdn_pred_x0")
                 if is_ddpm and t > 0:                       # scheduler.step() draws (and the caller discards) a randn
-                    for p in range(P):
-                        self._noise(noise_fn, gens, p, shape1, dev)
+                    draw_discard()
                 src, isneg = self._condition(repellency_processor, x0, use_beta)
                 if self.record_den and self._last_den is not None:
                     den_log.append(self._last_den.clone())
@@ -333,18 +359,16 @@ class SafeDenoiserPipeline:
                     flags = [1] * P
                     isneg = torch.ones(P, dtype=torch.int32, device=dev)
                 if any(flags):
-                    for p in range(P):
-                        if flags[p]:
-                            noise[p:p + 1] = self._noise(noise_fn, gens, p, shape1, dev)
-                            n_renoise += 1
+                    fired = [p for p in range(P) if flags[p]]
+                    draw_into(noise, fired if len(fired) < P else None)
+                    n_renoise += len(fired)
                     _lib.check(L.sdn_renoise_select(lat.data_ptr(), src.data_ptr(), noise.data_ptr(), isneg.data_ptr(),
                                                     P, D, sa, s1, st), "sdn_renoise_select")
 
             co = sch.step_coefficients(t)
             z = None
             if is_ddpm and t > 0:
-                for p in range(P):
-                    noise[p:p + 1] = self._noise(noise_fn, gens, p, shape1, dev)
+                draw_into(noise)
                 z = noise
             clip = sch.config.clip_sample_range if sch.config.clip_sample else 0.0
             _lib.check(L.sdn_sched_step(lat.data_ptr(), eps.data_ptr(), None if z is None else z.data_ptr(),

@@ -1,0 +1,67 @@
+"""Batched per-prompt random streams: sdn_randn_philox must reproduce `torch.randn(shape, generator=g,
+device="cuda")` BIT FOR BIT -- values and the generator's offset bookkeeping -- for every draw shape of the loops, including
+tensors large enough for torch's grid cap (several passes / unroll slots per thread), and the pipeline must give the same
+latents with the batched path on and off."""
+import pytest
+import torch
+
+from safe_denoiser_amd.pipeline import SafeDenoiserPipeline
+from safe_denoiser_amd.rng import BatchedNormal
+from safe_denoiser_amd.schedulers import DDPMScheduler
+from safe_denoiser_amd.unet import UNet2DConditionModel
+from tests.test_gpu_pipeline import SMALL
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("shape", [(1, 4, 64, 64), (1, 16, 64, 64), (1, 4, 16, 16), (1, 16, 128, 128), (1, 3, 333, 777), (5,)])
+def test_kernel_reproduces_torch_randn_bit_for_bit(shape):
+    numel = 1
+    for d in shape:
+        numel *= d
+    rng = BatchedNormal(torch.device(DEV, 0), numel)
+    assert rng.ok, "the library's Philox / Box-Muller does not reproduce this torch build's randn"
+    seeds = [0, 42, 2868251644, 2 ** 63 + 12345, 1000, 1001, 1002]
+    mine = [torch.Generator(device=DEV).manual_seed(s) for s in seeds]
+    ref = [torch.Generator(device=DEV).manual_seed(s) for s in seeds]
+    for k, (a, b) in enumerate(zip(mine, ref)):                           # different starting offsets per generator
+        for _ in range(k % 3):
+            torch.randn(11, generator=a, device=DEV); torch.randn(11, generator=b, device=DEV)
+    out = torch.full((len(seeds),) + shape[1:] if len(shape) > 1 else (len(seeds), numel), float("nan"), device=DEV)
+    for rep in range(3):                                                  # three consecutive draws: the offsets must chain
+        rng.draw(mine, out, None, shape)
+        for p, g in enumerate(ref):
+            want = torch.randn(shape, generator=g, device=DEV)
+            assert torch.equal(out[p].reshape(-1), want.reshape(-1)), (shape, p, rep)
+            assert mine[p].get_offset() == g.get_offset()
+    # a subset: only rows 1 and 4 are written and only those generators advance
+    before = out.clone()
+    rng.draw(mine, out, [1, 4], shape)
+    for p, g in enumerate(ref):
+        if p in (1, 4):
+            assert torch.equal(out[p].reshape(-1), torch.randn(shape, generator=g, device=DEV).reshape(-1))
+        else:
+            assert torch.equal(out[p], before[p])
+        assert mine[p].get_offset() == g.get_offset()
+    rng.skip(mine)                                                        # a draw nobody reads: streams advance, no values
+    for p, g in enumerate(ref):
+        torch.randn(shape, generator=g, device=DEV)
+        assert mine[p].get_offset() == g.get_offset()
+    # and the streams continue identically in plain torch afterwards
+    assert torch.equal(torch.randn(9, generator=mine[2], device=DEV), torch.randn(9, generator=ref[2], device=DEV))
+
+
+def test_pipeline_latents_do_not_depend_on_the_batched_path():
+    u = UNet2DConditionModel(text_len=77, **SMALL)
+    u.load_state_dict(u.synthetic_state_dict(11))
+    P = 3
+    E = torch.randn(2 * P, 77, 768, generator=torch.Generator().manual_seed(2)).cuda()
+    outs = []
+    for batched in (True, False):
+        pipe = SafeDenoiserPipeline(u, DDPMScheduler(), variant="plain")
+        pipe.batched_rng = batched
+        gens = [torch.Generator(device=DEV).manual_seed(1000 + p) for p in range(P)]
+        outs.append(pipe(prompt_embeddings=E, num_inference_steps=6, generator=gens, return_latents=True))
+        outs.append(torch.stack([torch.randn(4, generator=g, device=DEV) for g in gens]))      # where every stream stands afterwards
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[3])
