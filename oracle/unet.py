@@ -43,6 +43,7 @@ class OracleUNet:
         if config:
             self.cfg.update(config)
         self.q_dtype = act_dtype
+        self.device = device
         self.q_map = {k: act_dtype for k in self.KINDS}
         if q_map:
             self.q_map.update(q_map)
@@ -75,8 +76,8 @@ class OracleUNet:
         half = dim // 2
         freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
         ang = torch.full((batch, 1), float(t), dtype=torch.float32) * freqs[None]
-        dev = self.sd["conv_in.weight"].device
-        freqs, ang = freqs.to(dev), ang.to(dev)
+        if self.device is not None:
+            freqs, ang = freqs.to(self.device), ang.to(self.device)
         return torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1)
 
     def resnet(self, pfx, x, semb):

@@ -521,6 +521,14 @@ int sdn_gemm_pick_nrep(int n_padded, int act) {
 
 // Undeclared debug hook for in-process A/B timing (tools/bench_gemm.py): 2 = tile heuristic off, >=16: ablations.
 extern "C" void sdn_debug_set_gemm_variant(int v) { g_gemm_variant = v; }
+// diagnostics (tests, bench.py): how many sdn_gemm_* calls since the last reset went to the slab-ring convolution kernel
+// (out[0]) and how many to the implicit-GEMM / plain tile (out[1]) -- so that a test of the slab path cannot pass vacuously
+// and a plan label can be checked against what was actually launched
+static long long g_gemm_launches[2] = {0, 0};
+extern "C" void sdn_debug_gemm_launch_counts(long long* out2, int reset) {
+  if (out2) { out2[0] = g_gemm_launches[0]; out2[1] = g_gemm_launches[1]; }
+  if (reset) g_gemm_launches[0] = g_gemm_launches[1] = 0;
+}
 extern "C" void sdn_debug_set_gemm_stamps(void* p) { g_gemm_stamps = (unsigned long long*)p; }
 
 // Tile choice with the grid in mind: when the widest tile leaves the 256 CUs (x2 resident blocks) underfilled
@@ -655,8 +663,9 @@ static int sdn_gemm_impl(int dtype, const sdn_gemm_desc* d, const void* a, const
   }
   if (nrep == 10 && g_gemm_variant != 13) {                    // variant 13: slab convolution off (A/B, equality tests)
     const int rc = dispatch_conv_slab(dtype, g, st);
-    if (rc != SDN_GEMM_NOT_SLAB) return rc;
+    if (rc != SDN_GEMM_NOT_SLAB) { ++g_gemm_launches[0]; return rc; }
   }
+  ++g_gemm_launches[1];
   return dtype == 0 ? dispatch_dma<SdnBF16>(nrep, g, st) : dispatch_dma<SdnF16>(nrep, g, st);
 }
 

@@ -550,10 +550,19 @@ def test_slab_ring_convolution_gives_the_implicit_gemm_bits(dt, B, H, Cin, Cout)
     cases = [("plain", lambda cs: ops.gemm(x, w2, bias=bias, conv=conv)),
              ("row bias + residual", lambda cs: ops.gemm(x, w2, bias=bias, rowbias=rowbias, residual=res, conv=conv)),
              ("residual + column sums", lambda cs: ops.gemm(x, w2, bias=bias, residual=res, conv=conv, col_stats=cs))]
+    import ctypes
+    counts = (ctypes.c_longlong * 2)()
+
+    def launched(reset=True):
+        sda.lib().sdn_debug_gemm_launch_counts(counts, 1 if reset else 0)
+        return counts[0], counts[1]
     try:
         for name, fn in cases:
+            launched()
             _variant(13); want = fn(cs_a); torch.cuda.synchronize()
+            assert launched() == (0, 1), (name, "variant 13 must take the implicit-GEMM kernel")
             _variant(0); got = fn(cs_b); torch.cuda.synchronize()
+            assert launched() == (1, 0), (name, "the default build must take the slab-ring kernel for this shape")
             assert torch.isfinite(got.float()).all(), name
             assert torch.equal(got.view(torch.int16), want.view(torch.int16)), (name, float((got.float() - want.float()).abs().max()))
         assert torch.equal(cs_a, cs_b)

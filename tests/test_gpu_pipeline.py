@@ -1,6 +1,7 @@
 """The batched HIP loop vs the per-prompt CPU oracle loop on the SAME per-prompt noise tapes (seed-for-seed).
 
-Tolerance: final latents, relative L2 <= 8e-2 per prompt vs the oracle run with bf16 storage emulation (measured
+Tolerance: final latents, relative L2 per prompt vs the oracle run with bf16 storage emulation <= LOOP_BOUND[mode] = the
+measured distance + 25 % (2.2e-2 ... 3.9e-2 measured; rounds 1-2 used a blanket 8e-2) (measured
 3.5e-2 .. 4.1e-2 after 20 steps; the tests run 12).  The loop arithmetic is fp32 on both sides; the residue is the UNet's bf16 storage
 noise (1.1e-2 per forward, see test_gpu_unet.py) amplified by classifier-free guidance (eps = u + 7.5 (t - u)
 multiplies uncorrelated errors of the two branches by ~10) and integrated over the trajectory.  The is_negation
@@ -77,6 +78,14 @@ def run_oracle(sd, E, refs, P, tapes, sched, variant, repel):
     return torch.cat(outs), draws
 
 
+# Loop bounds = the distance measured on MI355X (round 3, gpurun_out/t_all.log: max over the prompts of each mode) + 25 %
+# (VERDICT r2 #1d; the blanket 8e-2 / 1.5e-2 of rounds 1-2 left a 2-4x slack).  16-bit storage vs the storage-emulating
+# oracle at the small configuration; CFG 7.5 amplifies the two branches' uncorrelated rounding ~3x over one forward.
+LOOP_BOUND = {"ddpm_threshold_time": 4.6e-2, "ddim_threshold_time": 4.5e-2, "ddpm_time_fast": 4.8e-2, "ddpm_norepel": 3.5e-2,
+              "ddim_norepel": 2.8e-2, "ddpm_sparse": 4.6e-2, "fp16": 4.2e-3, "sld": 5.0e-2, "lra_svf": 3.1e-2, "lra_re_attn": 4.5e-2,
+              "svf_2branch": 3.2e-2, "safree_call": 3.1e-2}
+
+
 @pytest.mark.parametrize("mode", ["ddpm_threshold_time", "ddim_threshold_time", "ddpm_time_fast", "ddpm_norepel",
                                   "ddim_norepel",          # BASELINE config 1: DDIM 50-step plumbing with repellency OFF
                                   "ddpm_sparse"])          # row R4 (SPELL) inside the loop
@@ -143,7 +152,7 @@ def test_loop_matches_oracle(world, tmp_path, mode):
     assert pipe.last_stats["renoise_draws"] == draws_o
     errs = [rel_l2(lat[p:p + 1], ref[p:p + 1]) for p in range(P)]
     print(f"{mode}: renoise draws {draws_o}, per-prompt rel L2 {['%.2e' % e for e in errs]}")
-    assert max(errs) <= 8e-2, errs
+    assert max(errs) <= LOOP_BOUND[mode], errs
     if mode.endswith("threshold_time") or mode == "ddpm_sparse":
         assert draws_o > 0                                             # the gate fired at least once
 
@@ -197,7 +206,7 @@ def test_fp16_storage_loop_parity(tmp_path):
     lat = SafeDenoiserPipeline(u, DDPMScheduler())(prompt_embeddings=E.cuda(), num_inference_steps=STEPS, noise_fn=t_p, return_latents=True)
     errs = [rel_l2(lat[p:p + 1], ref[p:p + 1]) for p in range(P)]
     print(f"fp16 loop: per-prompt rel L2 {['%.2e' % e for e in errs]}")
-    assert t_p.cur == t_o.cur and max(errs) <= 1.5e-2
+    assert t_p.cur == t_o.cur and max(errs) <= LOOP_BOUND["fp16"]
 
 
 def test_sld_family_loop_matches_oracle(world, tmp_path):
@@ -222,7 +231,7 @@ def test_sld_family_loop_matches_oracle(world, tmp_path):
                sld_momentum_scale=sld["ms"], sld_mom_beta=sld["mb"], return_latents=True)
     errs = [rel_l2(lat[p:p + 1], ref[p:p + 1]) for p in range(P)]
     print(f"sld loop: per-prompt rel L2 {['%.2e' % e for e in errs]}")
-    assert t_p.cur == t_o.cur and max(errs) <= 8e-2
+    assert t_p.cur == t_o.cur and max(errs) <= LOOP_BOUND["sld"]
 
 
 # ---- SAFREE text switching inside the loop, 3-branch `lra` batches (...threshold_time.py:518-548) -------------------
@@ -274,7 +283,7 @@ def test_lra_and_safree_text_switch_match_oracle(world, tmp_path, mode):
     errs = [rel_l2(lat[p:p + 1], ref[p:p + 1]) for p in range(P)]
     sep = rel_l2(ctl, ref[0:1])
     print(f"{mode}: per-prompt rel L2 {['%.2e' % e for e in errs]}; without the text switch prompt 0 is {sep:.2e} away")
-    assert max(errs) <= 8e-2 and sep > 1.5 * max(errs)
+    assert max(errs) <= LOOP_BOUND[mode] and sep > 1.5 * max(errs)
 
 
 def test_window_kwargs_follow_each_variant(world, tmp_path):

@@ -24,7 +24,7 @@ from safe_denoiser_amd.pipeline import SafeDenoiserPipeline
 from safe_denoiser_amd.repellency import repellency_methods_threshold as thr
 from safe_denoiser_amd.schedulers import DDPMScheduler
 from safe_denoiser_amd.unet import UNet2DConditionModel
-from tests.test_gpu_pipeline import SMALL, SMALL_O, Tapes, make_proc, rel_l2
+from tests.test_gpu_pipeline import LOOP_BOUND, SMALL, SMALL_O, Tapes, make_proc, rel_l2
 from tests_support.fake_tokenizer import FakeCLIPTokenizer
 
 pytestmark = pytest.mark.gpu
@@ -129,7 +129,7 @@ def test_prompt_call_with_safree_matches_oracle_stage_by_stage(stack, tmp_path):
     print(f"safree prompt call: beta_adjusted {prep['beta_adjusted']}, removed tokens {prep['n_removed']}, "
           f"loop rel L2 {['%.2e' % e for e in errs]}")
     assert t_p.cur == t_o.cur and pipe.last_stats["renoise_draws"] == draws > 0
-    assert max(errs) <= 8e-2
+    assert max(errs) <= LOOP_BOUND["safree_call"]              # measured 2.4e-2 + 25 %
 
 
 def test_prompt_call_requires_concept_space_and_keeps_plain_path(stack):
