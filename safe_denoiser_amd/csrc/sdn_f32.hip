@@ -178,6 +178,55 @@ k_groupnorm_f32(const float* __restrict__ x, const float* __restrict__ x2, int h
   const int C = c1 + c2, cpg = C / groups;
   const int b = blockIdx.x / groups, gi = blockIdx.x - b * groups;
   const int ch0 = gi * cpg;
+  // thread -> (channel pair tx of the group, pixel ty + k * ppp): float2 accesses, no per-element index arithmetic
+  // (cpg and c1 are even for every layer of the plan: 10 ... 80 channels per group)
+  const int hp = cpg >> 1, ppp = 256 / hp;
+  const int tx = threadIdx.x % hp, ty = threadIdx.x / hp;
+  const bool live = ty < ppp;
+  const int c = ch0 + 2 * tx;
+  const float* src = c < c1 ? x + (long)b * hw * c1 + c : x2 + (long)b * hw * c2 + (c - c1);
+  const int ld = c < c1 ? c1 : c2;
+  double s = 0.0, q = 0.0;
+  if (live)
+    for (int p = ty; p < hw; p += ppp) {
+      const float2 v = *reinterpret_cast<const float2*>(src + (long)p * ld);
+      const double a0 = v.x, a1 = v.y;
+      s += a0 + a1; q += a0 * a0 + a1 * a1;
+    }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off, 64); q += __shfl_xor(q, off, 64); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = q; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double n = (double)hw * cpg;
+    const double ts = red[0][0] + red[0][1] + red[0][2] + red[0][3], tq = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    const double mean = ts / n;
+    double var = tq / n - mean * mean;                                       // biased variance, as torch's group_norm
+    if (var < 0.0) var = 0.0;
+    stat[0] = (float)mean; stat[1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  if (!live) return;
+  const float mean = stat[0], rstd = stat[1];
+  const float ga0 = gamma[c], ga1 = gamma[c + 1], be0 = beta[c], be1 = beta[c + 1];
+  float* dst = out + (long)b * hw * C + c;
+  for (int p = ty; p < hw; p += ppp) {
+    const float2 v = *reinterpret_cast<const float2*>(src + (long)p * ld);
+    float o0 = (v.x - mean) * rstd * ga0 + be0, o1 = (v.y - mean) * rstd * ga1 + be1;      // centred first: |mean| >> std must not cancel
+    if (silu) { o0 = silu_f(o0); o1 = silu_f(o1); }
+    *reinterpret_cast<float2*>(dst + (long)p * C) = make_float2(o0, o1);
+  }
+}
+
+// general form (odd channels per group, or an odd split of a concatenated input): one element per access
+__global__ void __launch_bounds__(256)
+k_groupnorm_f32_any(const float* __restrict__ x, const float* __restrict__ x2, int hw, int c1, int c2, int groups, float eps,
+                    int silu, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ out) {
+  __shared__ double red[2][4];
+  __shared__ float stat[2];
+  const int C = c1 + c2, cpg = C / groups;
+  const int b = blockIdx.x / groups, gi = blockIdx.x - b * groups;
+  const int ch0 = gi * cpg;
   const long n = (long)hw * cpg;
   auto at = [&](long e) -> float {
     const int p = (int)(e / cpg), c = ch0 + (int)(e - (long)p * cpg);
@@ -192,7 +241,7 @@ k_groupnorm_f32(const float* __restrict__ x, const float* __restrict__ x2, int h
   if (threadIdx.x == 0) {
     const double ts = red[0][0] + red[0][1] + red[0][2] + red[0][3], tq = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     const double mean = ts / (double)n;
-    double var = tq / (double)n - mean * mean;                               // biased variance, as torch's group_norm
+    double var = tq / (double)n - mean * mean;
     if (var < 0.0) var = 0.0;
     stat[0] = (float)mean; stat[1] = (float)(1.0 / sqrt(var + (double)eps));
   }
@@ -206,6 +255,7 @@ k_groupnorm_f32(const float* __restrict__ x, const float* __restrict__ x2, int h
   }
 }
 
+// ================================================================================================
 // LayerNorm over the last axis: one wave per row, two passes over registers / L1 (mean, then centred sum of squares).
 __global__ void __launch_bounds__(256)
 k_layernorm_f32(const float* __restrict__ x, long rows, int c, float eps, const float* __restrict__ gamma,
@@ -766,8 +816,15 @@ extern "C" int sdn_groupnorm_f32(const void* x, const void* x2, int32_t batch, i
       (c1 + c2) % groups != 0)
     return SDN_E_INVALID;
   if (batch == 0) return SDN_OK;
-  hipLaunchKernelGGL(k_groupnorm_f32, dim3((unsigned)(batch * groups)), dim3(256), 0, (hipStream_t)stream, (const float*)x,
-                     (const float*)x2, hw, c1, c2, groups, eps, silu, gamma, beta, (float*)out);
+  const int cpg = (c1 + c2) / groups;
+  const bool pairs = (cpg & 1) == 0 && (c1 & 1) == 0 && cpg <= 512 && (reinterpret_cast<uintptr_t>(x) & 7) == 0 &&
+                     (reinterpret_cast<uintptr_t>(out) & 7) == 0 && (!x2 || (reinterpret_cast<uintptr_t>(x2) & 7) == 0);
+  if (pairs)
+    hipLaunchKernelGGL(k_groupnorm_f32, dim3((unsigned)(batch * groups)), dim3(256), 0, (hipStream_t)stream, (const float*)x,
+                       (const float*)x2, hw, c1, c2, groups, eps, silu, gamma, beta, (float*)out);
+  else
+    hipLaunchKernelGGL(k_groupnorm_f32_any, dim3((unsigned)(batch * groups)), dim3(256), 0, (hipStream_t)stream, (const float*)x,
+                       (const float*)x2, hw, c1, c2, groups, eps, silu, gamma, beta, (float*)out);
   return sdn_launch_status();
 }
 
