@@ -44,6 +44,7 @@ struct GemmArgsF {
   int a_mode, Hs, Ws, Cin, Ho, Wo, stride, upsample, conv_off;
   int act, out_kind, rows_per_batch, ld_rowbias, ld_rowgate, residual_bcast, n_valid, ldc;
   int tiles_n;
+  int dbg;                    // timing-only ablations of k_gemm_x3 (SDN_X3_DBG; tools/bench_x3_gemm.py): 1 no split arithmetic, 2 no global loads after the prologue, 4 no LDS writes, 8 one MFMA per product
 };
 
 // One output row's share of a wave's 16 x 64 accumulator block: acc[j][e] <-> row m, column n0 + 16 j + 4 fq + e.  Bias,
@@ -515,9 +516,12 @@ k_gemm_x3(const GemmArgsF g) {
   // LDS element offset of (row r, k chunk of 8 elements q) under the swizzle
   auto at = [](int r, int q) { return r * XK + ((q ^ (3 * ((r >> 2) & 1))) << 3); };
   // one instalment of the split: one float4 (4 consecutive k of row sr + 32 i) -> the hi and lo images of `stage`
+  const int dbg = g.dbg;
   auto put = [&](int stage, int img_hi, int img_lo, const f32x4& v, int i) {
     unsigned h0, l0, h1, l1;
-    split2(v[0], v[1], h0, l0); split2(v[2], v[3], h1, l1);
+    if (dbg & 4) return;
+    if (dbg & 1) { h0 = __float_as_uint(v[0]); l0 = __float_as_uint(v[1]); h1 = __float_as_uint(v[2]); l1 = __float_as_uint(v[3]); }
+    else { split2(v[0], v[1], h0, l0); split2(v[2], v[3], h1, l1); }
     const int o = at(sr + 32 * i, sc >> 1) + 4 * (sc & 1);
     *reinterpret_cast<uint2*>(&smem[stage][img_hi + o]) = make_uint2(h0, h1);
     *reinterpret_cast<uint2*>(&smem[stage][img_lo + o]) = make_uint2(l0, l1);
@@ -543,7 +547,7 @@ k_gemm_x3(const GemmArgsF g) {
   // tile both are harmless repeats of the last tile into a stage nobody reads)
   auto step = [&](auto CURc, int kt, f32x4 (&rac)[4], f32x4 (&rwc)[XNJ], f32x4 (&ran)[4], f32x4 (&rwn)[XNJ]) {
     constexpr int CUR = decltype(CURc)::value, NXT = CUR ^ 1;
-    load_a(kt + 2, rac); load_w(kt + 2, rwc);
+    if (!(dbg & 2)) { load_a(kt + 2, rac); load_w(kt + 2, rwc); }
     u32x4 ah[4], al[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -554,11 +558,15 @@ k_gemm_x3(const GemmArgsF g) {
     for (int j = 0; j < XNJ; ++j) {
       const int o = at(wn * (XN / 2) + j * 16 + fr, fq);
       const u32x4 wh = *reinterpret_cast<const u32x4*>(&smem[CUR][IMG_WH + o]), wl = *reinterpret_cast<const u32x4*>(&smem[CUR][IMG_WL + o]);
+      if (!(dbg & 8)) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i][j] = mfma_bf16(wl, ah[i], acc[i][j]);
+        for (int i = 0; i < 4; ++i) acc[i][j] = mfma_bf16(wl, ah[i], acc[i][j]);
+      }
       if (j < 4) put(NXT, 0, IMG_AL, ran[j], j);
+      if (!(dbg & 8)) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i][j] = mfma_bf16(wh, al[i], acc[i][j]);
+        for (int i = 0; i < 4; ++i) acc[i][j] = mfma_bf16(wh, al[i], acc[i][j]);
+      }
       put(NXT, IMG_WH, IMG_WL, rwn[j], j);
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[i][j] = mfma_bf16(wh, ah[i], acc[i][j]);
@@ -779,6 +787,8 @@ static int gemm_f32_storage(int x3, const sdn_gemm_desc* d, const void* a, const
   if (x3 && d->M >= 64) {                                                    // (a handful of rows: the small f32 tile is as fast and exact)
     const bool wide = d->act != SDN_ACT_GEGLU && (d->N % 160 == 0 || d->N % 128 != 0);
     const int xn = wide ? 160 : 128;
+    static const int x3_dbg = getenv("SDN_X3_DBG") ? atoi(getenv("SDN_X3_DBG")) : 0;
+    g.dbg = x3_dbg;
     g.tiles_n = (d->N + xn - 1) / xn;
     const long tiles = (long)((d->M + XM - 1) / XM) * g.tiles_n;
     if (tiles > 0x7fffffffL) return SDN_E_INVALID;
