@@ -20,8 +20,6 @@
 // The Gram form's cancellation is harmless here: a query is never close to a reference in units of |x|^2 + |r|^2 (the
 // reference's own torch.cdist takes the same form above 25 rows); fp32 error in d is ~1e-7 * (|x|^2 + |r|^2) / (2 d).
 // Results are deterministic (no float atomics; every sum has a fixed order).
-#include <hip/hip_cooperative_groups.h>
-
 #include "sdn_common.h"
 
 namespace {
@@ -65,11 +63,6 @@ inline Plan make_plan(int N, int M, int64_t D) {
   p.off_w = o;   o += align256((size_t)p.np * p.mp * 4);
   p.off_den = o; o += align256((size_t)p.np * p.mquads * 4);
   p.off_d2 = o;  o += align256((size_t)N * M * 4);
-  // the fused single-launch form (k_repel_fused) keeps its per-slice partials and the weights at the start of the workspace
-  if (N <= 4 && M > 0 && D % 64 == 0 && D / 64 <= 256) {
-    const size_t fused = align256(((size_t)(D / 64) * (M + 1) * 5 + (size_t)M * 4) * 4);
-    if (fused > o) o = fused;
-  }
   p.total = o;
   return p;
 }
@@ -403,220 +396,6 @@ k_wsum(const WsumArgs a) {
   }
 }
 
-// ================================================================================================
-// Fused single-launch projection for the reference's own call shape (N <= 4 queries, RBF, no query normalisation, SD-v1.4's
-// D = 16384): proj_ref is read from HBM exactly ONCE and stays in LDS between the two sweeps.
-//   Workgroup w (one per CU, cooperative launch: D / 64 = 256 of them) owns columns [64 w, 64 w + 64) of ALL M references:
-//   its [M][64] slice (132 KB for M = 515) is streamed into LDS once (rows padded to 65 floats: a thread per ROW then reads
-//   conflict-free).
-//   sweep 1: per-row partial dot products x_n . r_m and |r_m|^2 over the slice -> part[w][m][N + 1]      | grid barrier
-//   reduce : workgroup w sums the G partials of rows w, w + G, w + 2G in a fixed order, forms the distances and the
-//            weights of those rows -> wts[m][n]                                                            | grid barrier
-//   sweep 2: every workgroup reads the M x N weights (8 KB), den[n] = sum_m w + eps in a fixed order, and the weighted sum of
-//            ITS columns from the LDS-resident slice; fused epilogue (neg / den, in-place update, gate) as k_wsum.
-// Three launches and a second pass over proj_ref (through the Infinity Cache) become one launch and one pass; deterministic
-// (no float atomics).  Everything else (N > 4, SPARSE, channel-normalised queries, other D, slices that do not fit 160 KB)
-// keeps the three-launch path.
-// ================================================================================================
-constexpr int kFusedSW = 64, kFusedLD = kFusedSW + 1, kFusedMaxQ = 4;
-
-struct FusedArgs {
-  float* x; const float* R; float* out_neg; float* out_den; int32_t* out_isneg;
-  float* part;            // [G][M + 1][kFusedMaxQ + 1]: per-slice partial dots (row M = |x_n|^2 partials)
-  float* wts;             // [M][kFusedMaxQ]
-  int N, M; int64_t D; int G;
-  float i2s, scale, eps, gate;
-};
-
-__global__ void __launch_bounds__(256)
-k_repel_fused(const FusedArgs a) {
-  extern __shared__ float lds[];                                            // [M][65] slice | xs [4][64] | wl [M][4] | red
-  namespace cg = cooperative_groups;
-  cg::grid_group grid = cg::this_grid();
-  const int tid = threadIdx.x, w = blockIdx.x;
-  const int M = a.M, N = a.N;
-  const int64_t c0 = (int64_t)w * kFusedSW;
-  float* slice = lds;
-  float* xs = lds + (size_t)M * kFusedLD;                                    // [4][64]
-  float* wl = xs + kFusedMaxQ * kFusedSW;                                    // [M][4]
-  float* red = wl + (size_t)M * kFusedMaxQ;                                  // [4 waves][20]
-  // ---- the slice: M rows x 256 B, 16 lanes per row segment, eight float4 in flight per thread ----
-  const int per_row = kFusedSW / 4;
-  const int total4 = M * per_row;
-  for (int base = 0; base < total4; base += 256 * 8) {
-    f32x4 v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = base + u * 256 + tid;
-      v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (i < total4) {
-        const int row = i / per_row, c4 = (i - row * per_row) * 4;
-        v[u] = *reinterpret_cast<const f32x4*>(a.R + (int64_t)row * a.D + c0 + c4);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = base + u * 256 + tid;
-      if (i < total4) {
-        const int row = i / per_row, c4 = (i - row * per_row) * 4;
-        float* d = slice + (size_t)row * kFusedLD + c4;
-        d[0] = v[u][0]; d[1] = v[u][1]; d[2] = v[u][2]; d[3] = v[u][3];
-      }
-    }
-  }
-  if (tid < kFusedMaxQ * kFusedSW) {
-    const int n = tid >> 6, j = tid & 63;
-    xs[tid] = n < N ? a.x[(int64_t)n * a.D + c0 + j] : 0.f;
-  }
-  __syncthreads();
-  // ---- sweep 1: one thread per row ----
-  float* mypart = a.part + (size_t)w * (M + 1) * (kFusedMaxQ + 1);
-  for (int row = tid; row < M; row += 256) {
-    const float* r = slice + (size_t)row * kFusedLD;
-    float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f, rr = 0.f;
-#pragma unroll 8
-    for (int j = 0; j < kFusedSW; ++j) {
-      const float rv = r[j];
-      rr = fmaf(rv, rv, rr);
-      g0 = fmaf(rv, xs[j], g0); g1 = fmaf(rv, xs[64 + j], g1); g2 = fmaf(rv, xs[128 + j], g2); g3 = fmaf(rv, xs[192 + j], g3);
-    }
-    float* o = mypart + (size_t)row * (kFusedMaxQ + 1);
-    o[0] = g0; o[1] = g1; o[2] = g2; o[3] = g3; o[4] = rr;
-  }
-  if (tid < kFusedMaxQ) {                                                   // |x_n|^2 over the slice
-    float q = 0.f;
-    for (int j = 0; j < kFusedSW; ++j) q = fmaf(xs[tid * 64 + j], xs[tid * 64 + j], q);
-    mypart[(size_t)M * (kFusedMaxQ + 1) + tid] = q;
-  }
-  __threadfence();
-  grid.sync();
-  // ---- reduce: rows w, w + G, ...; thread t holds slice t's partial (G <= 256), fixed-order block sums ----
-  const int G = a.G;
-  auto bsum = [&](float v, int slot) -> float {                              // deterministic: butterfly inside a wave, waves in order
-    v = wave_sum(v);
-    if ((tid & 63) == 0) red[(tid >> 6) * 20 + slot] = v;
-    return v;
-  };
-  float xx[kFusedMaxQ];
-  {
-    float p[kFusedMaxQ];
-#pragma unroll
-    for (int n = 0; n < kFusedMaxQ; ++n)
-      p[n] = tid < G ? a.part[((size_t)tid * (M + 1) + M) * (kFusedMaxQ + 1) + n] : 0.f;
-#pragma unroll
-    for (int n = 0; n < kFusedMaxQ; ++n) bsum(p[n], n);
-    __syncthreads();
-#pragma unroll
-    for (int n = 0; n < kFusedMaxQ; ++n) xx[n] = ((red[n] + red[20 + n]) + red[40 + n]) + red[60 + n];
-    __syncthreads();
-  }
-  for (int row = w; row < M; row += G) {
-    float p[kFusedMaxQ + 1];
-#pragma unroll
-    for (int k = 0; k <= kFusedMaxQ; ++k)
-      p[k] = tid < G ? a.part[((size_t)tid * (M + 1) + row) * (kFusedMaxQ + 1) + k] : 0.f;
-#pragma unroll
-    for (int k = 0; k <= kFusedMaxQ; ++k) bsum(p[k], k);
-    __syncthreads();
-    if (tid < N) {
-      const float Gs = ((red[tid] + red[20 + tid]) + red[40 + tid]) + red[60 + tid];
-      const float rs = ((red[kFusedMaxQ] + red[20 + kFusedMaxQ]) + red[40 + kFusedMaxQ]) + red[60 + kFusedMaxQ];
-      float dd = (xx[tid] + rs) - 2.f * Gs;
-      dd = dd < 0.f ? 0.f : dd;                                              // rounding below zero; a NaN stays a NaN
-      a.wts[(size_t)row * kFusedMaxQ + tid] = expf(-sqrtf(dd) * a.i2s);
-    }
-    __syncthreads();
-  }
-  __threadfence();
-  grid.sync();
-  // ---- sweep 2: weights -> LDS, den, weighted sum of this workgroup's 64 columns from the resident slice ----
-  for (int i = tid; i < M * kFusedMaxQ; i += 256) wl[i] = a.wts[i];
-  __syncthreads();
-  float den[kFusedMaxQ];
-  {
-    float p[kFusedMaxQ] = {0.f, 0.f, 0.f, 0.f};
-    for (int m = tid; m < M; m += 256) {
-#pragma unroll
-      for (int n = 0; n < kFusedMaxQ; ++n) p[n] += wl[m * kFusedMaxQ + n];
-    }
-#pragma unroll
-    for (int n = 0; n < kFusedMaxQ; ++n) bsum(p[n], n);
-    __syncthreads();
-#pragma unroll
-    for (int n = 0; n < kFusedMaxQ; ++n) den[n] = (((red[n] + red[20 + n]) + red[40 + n]) + red[60 + n]) + a.eps;
-    __syncthreads();
-  }
-  const int j = tid & 63, gq = tid >> 6;                                    // column, row quarter (rows gq, gq + 4, ...)
-  float acc[kFusedMaxQ] = {0.f, 0.f, 0.f, 0.f};
-  for (int m = gq; m < M; m += 4) {
-    const float rv = slice[(size_t)m * kFusedLD + j];
-    const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + m * kFusedMaxQ);
-#pragma unroll
-    for (int n = 0; n < kFusedMaxQ; ++n) acc[n] = fmaf(wv[n], rv, acc[n]);
-  }
-  // combine the four row quarters in a fixed order through LDS (xs is free now: [4 quarters][4 queries][64] needs 1024 floats -> use the slice head)
-  __syncthreads();
-  float* comb = slice;                                                      // the slice is dead after the loop above
-#pragma unroll
-  for (int n = 0; n < kFusedMaxQ; ++n) comb[(gq * kFusedMaxQ + n) * 64 + j] = acc[n];
-  __syncthreads();
-  if (tid < N * 64) {
-    const int n = tid >> 6, jj = tid & 63;
-    const float s = ((comb[(0 * kFusedMaxQ + n) * 64 + jj] + comb[(1 * kFusedMaxQ + n) * 64 + jj]) + comb[(2 * kFusedMaxQ + n) * 64 + jj]) +
-                    comb[(3 * kFusedMaxQ + n) * 64 + jj];
-    const float g = s / den[n];
-    float* xp = a.x + (int64_t)n * a.D + c0 + jj;
-    *xp = *xp - a.scale * g;
-    if (a.out_neg) a.out_neg[(int64_t)n * a.D + c0 + jj] = g;
-    if (w == 0 && jj == 0) {
-      if (a.out_den) a.out_den[n] = den[n];
-      if (a.out_isneg) a.out_isneg[n] = den[n] > a.gate ? 1 : 0;
-    }
-  }
-}
-
-static int g_repel_fused = 1;        // debug A/B switch (sdn_debug_set_repel_fused)
-
-// Launches the fused form when the problem suits it; returns 1 if it did, 0 to keep the three-launch path, < 0 on error.
-inline int try_fused(const sdn_repel_params* p, float* x, const float* R, float* out_neg, float* out_den, int32_t* out_isneg,
-                     char* ws, size_t ws_bytes, hipStream_t st) {
-  const int N = p->n_query, M = p->n_ref;
-  const int64_t D = (int64_t)p->channels * p->hw;
-  if (!g_repel_fused || N > kFusedMaxQ || M <= 0 || p->weight_fn != SDN_REPEL_RBF || p->qnorm != SDN_QNORM_NONE || (D % kFusedSW) != 0)
-    return 0;
-  const int64_t G = D / kFusedSW;
-  if (G > 256) return 0;                                                     // one slice per thread in the reduce
-  const size_t lds_bytes = ((size_t)M * kFusedLD + kFusedMaxQ * kFusedSW + (size_t)M * kFusedMaxQ + 80) * sizeof(float);
-  if (lds_bytes > 160 * 1024 || (size_t)M * kFusedLD < 4 * kFusedMaxQ * 64) return 0;
-  const size_t need = ((size_t)G * (M + 1) * (kFusedMaxQ + 1) + (size_t)M * kFusedMaxQ) * sizeof(float);
-  if (ws_bytes < need) return 0;
-  static int coresident = -1;                                                // co-resident workgroups of this kernel on the device
-  static size_t attr_for = 0;
-  if (attr_for < lds_bytes) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_repel_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return 0;
-    attr_for = 160 * 1024;
-  }
-  if (coresident < 0) {
-    int dev = 0, per_cu = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k_repel_fused), 256, lds_bytes) != hipSuccess)
-      return 0;
-    coresident = prop.cooperativeLaunch ? per_cu * prop.multiProcessorCount : 0;
-  }
-  if (G > coresident) return 0;                                              // the grid barrier needs every workgroup resident
-  FusedArgs a{x, R, out_neg, out_den, out_isneg, reinterpret_cast<float*>(ws),
-              reinterpret_cast<float*>(ws) + (size_t)G * (M + 1) * (kFusedMaxQ + 1), N, M, D, (int)G,
-              1.f / (2.f * p->sigma * p->sigma), p->scale, p->epsilon, p->gate};
-  void* args[] = {&a};
-  if (hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_repel_fused), dim3((unsigned)G), dim3(256), args, lds_bytes, st) != hipSuccess) {
-    (void)hipGetLastError();
-    return 0;                                                                // fall back to the three-launch path
-  }
-  return 1;
-}
-
 // ---- calibration tail: beta[n] = sum_m exp(-dist / 2 sigma^2) + eps comes out of k_weights (den) -----------------
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -661,8 +440,6 @@ inline const float* run_gram(const sdn_repel_params* p, const Plan& pl, const fl
 
 }  // namespace
 
-extern "C" void sdn_debug_set_repel_fused(int on) { g_repel_fused = on; }
-
 extern "C" {
 
 size_t sdn_repel_workspace_bytes(int32_t n_query, int32_t n_ref, int32_t channels, int32_t hw) {
@@ -684,10 +461,6 @@ int sdn_repel_apply(const sdn_repel_params* p, float* x, const float* R, float* 
   if (workspace_bytes < pl.total) return SDN_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   char* ws = static_cast<char*>(workspace);
-  {
-    const int fused = try_fused(p, x, R, out_neg, out_den, out_isneg, ws, workspace_bytes, st);
-    if (fused != 0) return fused > 0 ? sdn_launch_status() : fused;
-  }
   float* w = reinterpret_cast<float*>(ws + pl.off_w);
   float* den = reinterpret_cast<float*>(ws + pl.off_den);
   const float* gp = reinterpret_cast<const float*>(ws + pl.off_g);

@@ -246,35 +246,3 @@ def test_g7_goldens_against_product_project(golden, tmp_path):
         assert calls == ([k] if k <= ne else [min(ne, k - i) for i in range(0, k, ne)]), (name, calls)
         n += 1
     assert n == 6
-
-
-@pytest.mark.parametrize("n", [1, 2, 4])
-def test_fused_single_launch_form_matches_the_three_launch_form(tmp_path, n):
-    """Round 3: for N <= 4 RBF queries at SD-v1.4's D = 16384 the projection runs as ONE cooperative launch with proj_ref
-    LDS-resident between the two sweeps (k_repel_fused).  Same arithmetic form (Gram distances, fixed-order sums), different
-    summation order than the three-launch path: latents within 2e-6 rel, denominators 1e-6, gates identical -- and both
-    within the usual tolerance of the oracle."""
-    import safe_denoiser_amd as sda
-    from safe_denoiser_amd.repellency import repellency_methods_threshold as thr
-    g = torch.Generator().manual_seed(3)
-    refs = orp.channel_normalise(torch.randn(515, 4, 64, 64, generator=g))
-    x = 0.9 * refs[torch.tensor([7, 100, 300, 514])[:n]] + 0.15 * torch.randn(n, 4, 64, 64, generator=g)      # near references: weights far from underflow
-    proc = make_proc(thr, "kernel_fast", refs, tmp_path, sigma=3.15, scale=0.33, beta_threshold=1.0, beta_threshold_margin=0.4)
-    outs = {}
-    try:
-        for fused in (1, 0):
-            sda.lib().sdn_debug_set_repel_fused(fused)
-            xq = x.clone().cuda()
-            neg, den, isneg = proc.conditioning_device(xq, beta_threshold=True, want_neg=True)
-            outs[fused] = (xq.cpu(), neg.cpu(), den.cpu(), isneg.cpu())
-    finally:
-        sda.lib().sdn_debug_set_repel_fused(1)
-    for a, b in zip(outs[1][:3], outs[0][:3]):
-        assert float((a.double() - b.double()).norm() / b.double().norm()) <= 2e-6
-    assert torch.equal(outs[1][3], outs[0][3])
-    for i in range(n):
-        ref = orp.kernel_fast_conditioning(x[i:i + 1].clone(), refs, flavour="threshold", scale=0.33, sigma=3.15, beta_threshold=1.0,
-                                           beta_threshold_margin=0.4, use_beta_threshold=True)
-        close(outs[1][0][i:i + 1], ref["x_0_hat"])
-        close(outs[1][2][i], ref["mean_x_0_hat"]["denominator"], rt=1e-5)
-        assert int(outs[1][3][i]) == int(ref["is_negation"])
