@@ -516,7 +516,11 @@ k_gemm_x3(const GemmArgsF g) {
   // LDS element offset of (row r, k chunk of 8 elements q) under the swizzle
   auto at = [](int r, int q) { return r * XK + ((q ^ (3 * ((r >> 2) & 1))) << 3); };
   // one instalment of the split: one float4 (4 consecutive k of row sr + 32 i) -> the hi and lo images of `stage`
-  const int dbg = g.dbg;
+#ifdef SDN_X3_ABLATE                       // timing-only ablations (tools/bench_x3_gemm.py): compiled in only on request, the runtime
+  const int dbg = g.dbg;                   // branches cost the production kernel 13 % (measured: 2.78 -> 2.41 images/sec in the loop)
+#else
+  constexpr int dbg = 0;
+#endif
   auto put = [&](int stage, int img_hi, int img_lo, const f32x4& v, int i) {
     unsigned h0, l0, h1, l1;
     if (dbg & 4) return;

@@ -1,5 +1,7 @@
 """Per-shape timing of sdn_gemm_x3 (fp32 storage, bf16x3 products) with the timing-only ablations of SDN_X3_DBG.
-    SDN_X3_DBG=<bits> python tools/bench_x3_gemm.py        (1 no split arithmetic, 2 no loads in the loop, 4 no LDS writes, 8 one MFMA per product)"""
+    SDN_X3_DBG=<bits> python tools/bench_x3_gemm.py        (1 no split arithmetic, 2 no loads in the loop, 4 no LDS writes, 8 one MFMA per product)
+The ablation branches are compiled in only with -DSDN_X3_ABLATE (make -C safe_denoiser_amd/csrc CXXFLAGS+=-DSDN_X3_ABLATE after touching
+sdn_f32.hip): as runtime branches they cost the production kernel 13 %."""
 import os
 import sys
 
