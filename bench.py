@@ -596,8 +596,12 @@ def main():
             tname = "F16" if args.dtype == "f16" else "BF16"
             if dom == "k_conv_slab":  # one plan label, three instantiations (map width 64 / 32 / 16): launch-weighted mean
                 want = [f"k_conv_slab<Sdn{tname}, {w_}>" for w_ in (64, 32, 16)]
-            else:
-                want = [dom.replace("k_gemm<", f"k_gemm_dma<Sdn{tname}, ").replace(">", ",")]
+            else:                     # plan label k_gemm<NREP>[/ln] -> the symbol k_gemm_dma<T, NREP, WGM, NSTAGE, LNF> (LNF = 0 without /ln)
+                import re
+                nrep = dom[dom.index("<") + 1:dom.index(">")]
+                lnf = "[12]" if dom.endswith("/ln") else "0"
+                pat = re.compile(rf"k_gemm_dma<Sdn{tname}, {nrep}, \d+, \d+, {lnf}>")
+                want = sorted({kname for kname in rec_all if pat.search(kname)})
             hit = [rec for kname, rec in rec_all.items() if kname != "__meta__" and any(w_ in kname for w_ in want)]
             if hit:
                 traffic = sum(r["hbm_bytes_per_launch"] * r["launches"] for r in hit) / sum(r["launches"] for r in hit)
