@@ -239,7 +239,9 @@ struct Builder {
     o.gd.out_kind = out_kind; o.gd.n_valid = n_valid; o.gd.rows_per_batch = rows_per_batch; o.gd.ld_rowbias = ld_rowbias;
     o.a = a; o.a2 = a2; o.w = w; o.bias = bias; o.rowbias = rowbias; o.residual = residual; o.out = out;
     o.flops = 2.0 * (double)M * (double)(n_valid > 0 ? n_valid : N) * (double)K;
-    o.bytes = 2.0 * ((double)M * K + (double)N * K + (double)M * (act_ == SDN_ACT_GEGLU ? N / 2 : N));
+    // algorithmic bytes: A + W + the output, + the residual operand when the epilogue adds one (it is read once, 16 bit)
+    o.bytes = 2.0 * ((double)M * K + (double)N * K + (double)M * (act_ == SDN_ACT_GEGLU ? N / 2 : N)) +
+              (residual.space != SP_NONE ? 2.0 * (double)M * N : 0.0);
     snprintf(o.label, sizeof(o.label), "k_gemm<%d>", sdn_gemm_pick_tile((int)M, N, K, act_, residual.space != SP_NONE));
     push_gemm(o);
   }
@@ -270,7 +272,8 @@ struct Builder {
     o.gd.ld_rowbias = ld_rowbias;
     o.a = R(in); o.w = w; o.bias = bias; o.rowbias = rowbias; o.residual = residual; o.out = out;
     o.flops = 2.0 * (double)o.gd.M * (double)cout * (double)o.gd.K;
-    o.bytes = 2.0 * ((double)B * in.side * in.side * in.C + (double)n_pad * o.gd.K + (double)o.gd.M * cout);
+    o.bytes = 2.0 * ((double)B * in.side * in.side * in.C + (double)n_pad * o.gd.K + (double)o.gd.M * cout) +
+              (residual.space != SP_NONE ? 2.0 * (double)o.gd.M * cout : 0.0);      // + the residual map the epilogue adds
     if (Ho == in.side && sdn_conv_slab_shape_ok(o.gd.M, n_pad, in.C, in.side, stride, upsample, asym_pad, out_kind, n_valid) &&
         sdn_gemm_pick_tile(o.gd.M, n_pad, o.gd.K, SDN_ACT_NONE) == 10)
       snprintf(o.label, sizeof(o.label), "k_conv_slab");
