@@ -68,6 +68,7 @@ class SafeDenoiserPipeline:
         self._bufs = {}
         self._rngs = {}
         self.batched_rng = True    # False: per-prompt torch.randn calls (the draws are the same bits either way)
+        self.batched_safree = True  # False: the SAFREE projection prompt by prompt (safree.prepare), as the reference runs it
         self.record_den = False    # diagnostics: keep each window step's denominators (device tensors, no sync) in last_stats
         # SLDPipeline._safety_text_concept: the default of the third-party base class the reference's SLD pipelines inherit
         # (python_sld == 1.0.10, requirements.txt:16; not in /root/reference -- restated from the published package)
@@ -480,21 +481,29 @@ class SafeDenoiserPipeline:
         for lo in range(0, allrows.shape[0], 256):
             pooled.append(self.text_encoder(allrows[lo:lo + 256], attention_mask=None).pooler_output.float())
         pooled = torch.cat(pooled) if pooled else E.new_zeros((0, E.shape[-1]))
-        resc_rows, betas, adjusted, removed = [], [], [], []
-        lo = 0
+        masked_list, lo = [], 0
         for p_ in range(P):
-            masked_embs = pooled[lo:lo + counts[p_]]
+            masked_list.append(pooled[lo:lo + counts[p_]])
             lo += counts[p_]
-            pair = torch.stack([E[p_], E[P + p_]])
-            r = safree.prepare(pair, masked_embs, negspace, attn_mask[p_].to(dev), alpha=sf["alpha"], svf=bool(sf["svf"]),
-                               up_t=sf["up_t"], category=sf["category"], concept_proj=P_c)
-            resc_rows.append(r["rescaled_text_embeddings"][1])
-            betas.append(r["beta"]); adjusted.append(r["beta_adjusted"]); removed.append(r["n_removed"])
-            log = sf.get("logger")
-            if log is not None:
-                log.log(f"Among {counts[p_]} tokens, we remove {r['n_removed']}.")
+        if self.batched_safree and min(counts) > 0:
+            r = safree.prepare_batch(E, masked_list, negspace, attn_mask, alpha=sf["alpha"], svf=bool(sf["svf"]), up_t=sf["up_t"],
+                                     category=sf["category"], concept_proj=P_c)
+            resc_rows = list(r["rescaled_text_embeddings"][P:])
+            betas, adjusted, removed = r["beta"], r["beta_adjusted"], r["n_removed"]
+        else:
+            resc_rows, betas, adjusted, removed = [], [], [], []
+            for p_ in range(P):
+                pair = torch.stack([E[p_], E[P + p_]])
+                r = safree.prepare(pair, masked_list[p_], negspace, attn_mask[p_].to(dev), alpha=sf["alpha"], svf=bool(sf["svf"]),
+                                   up_t=sf["up_t"], category=sf["category"], concept_proj=P_c)
+                resc_rows.append(r["rescaled_text_embeddings"][1])
+                betas.append(r["beta"]); adjusted.append(r["beta_adjusted"]); removed.append(r["n_removed"])
+        log = sf.get("logger")
+        if log is not None:
+            for p_ in range(P):
+                log.log(f"Among {counts[p_]} tokens, we remove {removed[p_]}.")
                 if sf["svf"]:
-                    log.log(f"beta : {r['beta']}, adjusted_beta: {r['beta_adjusted']}")
+                    log.log(f"beta : {betas[p_]}, adjusted_beta: {adjusted[p_]}")
         rescaled = torch.cat([E[:P], torch.stack(resc_rows)])
         return {"rescaled_text_embeddings": rescaled, "beta_adjusted": adjusted if sf["svf"] else None, "beta": betas,
                 "n_removed": removed, "negspace": negspace}

@@ -81,6 +81,54 @@ def prepare(text_embeddings: torch.Tensor, masked_embs: torch.Tensor, negspace: 
     return out
 
 
+def prepare_batch(text_embeddings: torch.Tensor, masked_embs: list, negspace: torch.Tensor, attention_masks: torch.Tensor, *,
+                  alpha: float = 0.01, svf: bool = True, up_t: int = 10, category: str = "nudity",
+                  concept_proj: torch.Tensor | None = None) -> dict:
+    """`prepare` for P prompts at once (the batched engine's front end; run_nudity.py calls the pipeline one prompt at a time).
+    text_embeddings [2P,77,768] ([uncond | text] rows), masked_embs: P tensors [n_t(p), 768], attention_masks [P,77].
+    Same arithmetic per prompt as `prepare` -- P_m = E (E^T E)^+ E^T from the SVD pseudo-inverse, the leave-one-out distance
+    test, the token-wise replacement, the cosine statistic -- with the prompts' masked-embedding matrices zero-padded to a common
+    token count (zero rows change neither the Gram matrix's range nor its pseudo-inverse on it), so that the 64 small SVDs,
+    projector products and reductions of a batch are one batched call each instead of ~15 launches and two host syncs per
+    prompt.  Returns the per-prompt lists `prepare` would give, stacked."""
+    P = len(masked_embs)
+    dev, dt = text_embeddings.device, text_embeddings.dtype
+    dim, L = text_embeddings.shape[-1], text_embeddings.shape[1]
+    P_c = projection_matrix(negspace.T) if concept_proj is None else concept_proj
+    eye_m_c = torch.eye(dim, device=dev, dtype=dt) - P_c
+    counts = [int(m.shape[0]) for m in masked_embs]
+    n_max = max(max(counts), 1)
+    Mp = torch.zeros((P, n_max, dim), device=dev, dtype=dt)
+    valid = torch.zeros((P, n_max), device=dev, dtype=torch.bool)
+    for p_, m in enumerate(masked_embs):
+        Mp[p_, :counts[p_]] = m
+        valid[p_, :counts[p_]] = True
+    G = Mp @ Mp.transpose(1, 2)                                              # [P, n, n] = E^T E of each prompt (zero-padded)
+    P_m = Mp.transpose(1, 2) @ torch.linalg.pinv(G, rtol=1e-15) @ Mp         # [P, dim, dim]; torch.pinverse's own cut-off (rcond 1e-15)
+    text_e = text_embeddings[P:]                                             # [P, L, dim]
+    # distance of each masked prompt to the concept space, leave-one-out mean test (safree_projection)
+    dist = torch.linalg.vector_norm(Mp @ eye_m_c.T, dim=-1)                  # [P, n]   (= ||(I - P_c) p_emb^T|| per column)
+    dist = torch.where(valid, dist, torch.zeros_like(dist))
+    n_t = valid.sum(dim=1, keepdim=True).to(dt)
+    loo = (dist.sum(dim=1, keepdim=True) - dist) / (n_t - 1)
+    loo = torch.where(n_t > 1, loo, torch.full_like(loo, float("nan")))
+    keep = (dist < (1.0 + alpha) * loo) & valid                              # True = safe token
+    mask = torch.ones((P, L), device=dev, dtype=torch.bool)
+    mask[:, 1:n_max + 1] = keep | ~valid                                     # positions past a prompt's tokens keep their embedding
+    projected = (text_e @ P_m.transpose(1, 2)) @ eye_m_c.T                   # ((I - P_c) P_m e)^T for every token
+    merged = torch.where(mask[:, :, None], text_e, projected)
+    n_removed = (valid & ~keep).sum(dim=1)
+    out = {"rescaled_text_embeddings": torch.cat([text_embeddings[:P], merged]), "n_removed": n_removed.tolist(),
+           "beta": [None] * P, "beta_adjusted": [None] * P}
+    if svf:
+        act = (attention_masks.to(dev) == 1).to(dt)                          # [P, L]
+        cos = torch.nn.functional.cosine_similarity(projected, text_e, dim=-1)
+        beta = 1.0 - (cos * act).sum(dim=1) / act.sum(dim=1)
+        out["beta"] = [float(b) for b in beta.tolist()]
+        out["beta_adjusted"] = [f_beta(b, upperbound_timestep=up_t, concept_type=category) for b in out["beta"]]
+    return out
+
+
 # ---- SD-v3 variant (models/sdv3/safe_denoiser_pipeline.py:72-153,1061-1078): T5 hidden states, 16-bit matmuls ------------
 def projection_matrix_sd3(E: torch.Tensor) -> torch.Tensor:
     """:72-82: the same projector, computed in fp32 whatever the embeddings' dtype."""

@@ -142,3 +142,24 @@ def test_prompt_call_requires_concept_space_and_keeps_plain_path(stack):
     torch.testing.assert_close(a, b, rtol=0, atol=0)
     with pytest.raises(ValueError):
         pipe(PROMPTS[:2], negative_prompt=["x"], num_inference_steps=1, return_latents=True)
+
+
+def test_batched_safree_projection_matches_the_per_prompt_path(stack):
+    """safree.prepare_batch (one batched SVD / projector product / reduction for the whole batch, prompts zero-padded to a
+    common token count) against safree.prepare prompt by prompt, on the engine's own CLIP outputs: the same trigger-token
+    decisions, the same f_beta step counts, embeddings to 2e-3 (both sides invert the same noise-level singular values:
+    torch.pinverse's rcond 1e-15)."""
+    u, sd, enc, csd, tok, refs = stack
+    prompts = PROMPTS + ["a cat", "w1 w2 w3 w4 w5 w6 w7 w8 w9 w10 w11 w12 w13 w14 w15 w16 w17 w18", "lustful seductive kinky pose , oil painting"]
+    sf = dict(safree=True, svf=True, lra=True, alpha=0.01, up_t=10, category="nudity", re_attn_t=[-1, 4], logger=None)
+    outs = {}
+    for batched in (True, False):
+        pipe = SafeDenoiserPipeline(u, DDPMScheduler(), variant="threshold_time", text_encoder=enc, tokenizer=tok)
+        pipe.batched_safree = batched
+        E, _ids, am = pipe._new_encode_prompt(prompts, None)
+        outs[batched] = pipe._safree_prepare(prompts, E, am, NEG_SPACE, sf)
+    a, b = outs[True], outs[False]
+    assert a["n_removed"] == b["n_removed"] and a["beta_adjusted"] == b["beta_adjusted"], (a["n_removed"], b["n_removed"], a["beta"], b["beta"])
+    assert sum(a["n_removed"]) > 0
+    np.testing.assert_allclose(np.array(a["beta"]), np.array(b["beta"]), atol=2e-3)
+    np.testing.assert_allclose(a["rescaled_text_embeddings"].cpu().numpy(), b["rescaled_text_embeddings"].cpu().numpy(), atol=2e-3, rtol=2e-3)
