@@ -1,14 +1,16 @@
 """The denoising loop with per-step repellency projection -- batched over prompts.
 
 Call surface: the reference's `ModifiedSafreeDiffusionPipeline_Rep.__call__`
-(models/textuals_visual/modified_safree_diffusion_pipeline_threshold_time.py:352-375,598) restricted to the hot path:
-the tensor-level inputs the loop consumes (`prompt_embeddings`, `generator`, `latents`, `repellency_processor`,
-`safree_dict`, `negation_warmup_start/end`, `return_latents`, `output_type`).  The text encoder sits before the loop
- and is not part of this engine: pass CLIP hidden states as `prompt_embeddings`
-([2P,77,768] = chunk(2) -> [P uncond | P text], or [3P,...] with `lra`).  With a `vae` (safe_denoiser_amd.vae.
-AutoencoderKL, section 8f row 2) and `return_latents=False` the call ends like the reference's (:588-596):
-`decode_latents` -> NHWC float numpy in [0,1] (`output_type="np"`), PIL images ("pil", needs Pillow) or the uint8
-NHWC tensor numpy_to_pil would build, left on the device ("uint8"); otherwise latents come back.
+(models/textuals_visual/modified_safree_diffusion_pipeline_threshold_time.py:352-375,598) -- same argument order, names and
+defaults, so `run_nudity.py:439-460` runs verbatim: `pipe(prompt, num_images_per_prompt=1, guidance_scale=, num_inference_steps=,
+negative_prompt=, negative_prompt_space=, height=, width=, generator=, repellency_processor=, safree_dict=, **SLD config)`
+-> list of PIL images (`return_latents=True` = the parity tap, :585-586).  `from_pretrained(local_dir)` builds the stack from a
+diffusers-layout checkpoint directory (run_nudity.py:104-131).  With prompt strings the engine's CLIPTextModel encodes them and
+the SAFREE block (:458-486) runs inside the call; alternatively pass CLIP hidden states as `prompt_embeddings`
+([2P,77,768] = chunk(2) -> [P uncond | P text]; [3P,...] = + safety concept for the SLD families).  With a `vae`
+(safe_denoiser_amd.vae.AutoencoderKL) the call ends like the reference's (:588-596): `decode_latents` -> PIL images
+(`output_type="pil"`), NHWC float numpy in [0,1] ("np"), or the uint8 NHWC tensor numpy_to_pil would build, left on the device
+("uint8").
 
 What differs from the reference by design (results per sample are the same):
   * P prompts are denoised together (the reference is hard-wired to batch 1); every prompt keeps its OWN
@@ -16,7 +18,8 @@ What differs from the reference by design (results per sample are the same):
     re-noise draw, the step's variance draw, in that order (row S2) -- is exactly the reference's;
   * all per-element math is in libsdn kernels; the only host<->device traffic in the loop is ONE readback of the
     P is_negation flags per repellency-window step (the reference syncs three times per step per prompt), needed
-    only because the number of randn draws depends on the flag.
+    only because the number of randn draws depends on the flag;
+  * the per-prompt random draws of a step are one launch per kind (rng.py: bit-identical to torch.randn per generator).
 """
 from __future__ import annotations
 
