@@ -9,8 +9,11 @@ Restates the hot loop of models/sdv3/safe_denoiser_pipeline.py:1105-1165 on libs
         lat = x0r + sigma_next (sqrt(sigma_next) x1 + sqrt(1 - sigma_next) z - x0r)   (sdn_flow_renoise) :1159-1160
     else: lat = scheduler.step(v, t, lat)       (Euler)                                          :1165
     lat = lat.to(latents_dtype)   (the reference keeps fp16 latents between steps)               :1161,1167-1171
-Text encoders (CLIP x2 + T5), the SAFREE T5 projection and the VAE are outside the hot path: pass
-`prompt_embeds` [2P,333,4096] and `pooled_prompt_embeds` [2P,2048] ([P negative | P positive]), get latents back.
+Text encoders (CLIP x2 + T5) are outside the hot path: pass `prompt_embeds` [2P,333,4096] and
+`pooled_prompt_embeds` [2P,2048] ([P negative | P positive]).  `return_latents=True` (the engine-side default: the loop's own
+output) gives the latents; with a `vae` and `return_latents=False` the call ends like the reference's (:1195-1214) and returns
+`StableDiffusion3PipelineOutput(images=...)` -- `.images` as run_nudity_sdv3.py:351-360 reads it (`return_dict=False`: a tuple;
+`output_type="latent"`: the latents in `.images`).
 The reference draws z from the GLOBAL torch RNG (`randn_like`, :1159); so does this loop unless `noise_fn` is given.
 Known reference quirk kept out: with `repellency_processor=None` inside the window the reference reads undefined
 names (:1159); here that case simply takes the Euler step.
@@ -23,6 +26,14 @@ from typing import Callable, Optional
 import torch
 
 from . import _lib
+
+
+class StableDiffusion3PipelineOutput:
+    """What the reference's call returns (`pipe(...).images`, run_nudity_sdv3.py:351-360; safe_denoiser_pipeline.py:1214)."""
+    __slots__ = ("images",)
+
+    def __init__(self, images):
+        self.images = images
 
 
 class SD3SafeDenoiserPipeline:
@@ -43,11 +54,14 @@ class SD3SafeDenoiserPipeline:
             raise NotImplementedError("text encoders are outside the hot path: pass prompt_embeds [2P,T,4096] and "
                                       "pooled_prompt_embeds [2P,2048] ([P negative | P positive])")
         output_type = kwargs.get("output_type", "pil")
+        return_dict = kwargs.get("return_dict", True)
+        if output_type == "latent":                                          # the reference's own latent tap (:1195-1196)
+            return_latents = True
         if not return_latents:
             if self.vae is None:
                 raise NotImplementedError("no VAE attached: construct with vae=AutoencoderKL(**SD3_VAE_CONFIG) or use return_latents=True")
             if output_type not in ("pil", "np", "uint8"):
-                raise _lib.SdnError("output_type must be 'pil', 'np' or 'uint8'")
+                raise _lib.SdnError("output_type must be 'pil', 'np', 'uint8' or 'latent'")
         hi = kwargs.get("negation_warmup_start", 1000)
         lo = kwargs.get("negation_warmup_end", 780)
         dev = torch.device("cuda", torch.cuda.current_device())
@@ -127,14 +141,15 @@ class SD3SafeDenoiserPipeline:
             lat = rq(nxt).contiguous()
             nxt = torch.empty_like(lat)
         self.last_stats = {"window_steps": n_win, "prompts": P}
+        wrap = (lambda im: StableDiffusion3PipelineOutput(im) if return_dict else (im,))
         if return_latents:
-            return lat.to(latents_dtype)
+            return wrap(lat.to(latents_dtype)) if output_type == "latent" else lat.to(latents_dtype)
         # safe_denoiser_pipeline.py:1195-1199: latents / scaling_factor + shift_factor -> vae.decode -> postprocess
         lat = lat.to(latents_dtype).float()
         if output_type == "uint8":
-            return self.vae.decode_latents_uint8(lat)
+            return wrap(self.vae.decode_latents_uint8(lat))
         image = self.vae.decode_latents(lat)
         if output_type == "pil":
             from PIL import Image
-            return [Image.fromarray(im) for im in (image * 255).round().astype("uint8")]
-        return image
+            image = [Image.fromarray(im) for im in (image * 255).round().astype("uint8")]
+        return wrap(image)

@@ -239,3 +239,32 @@ def test_full_sd3_medium_matches_oracle():
     r_32 = rel_l2(y, OracleMMDiT(sd, None, act_dtype=None)(x, 812.0, e, pl))
     print(f"full SD3-medium MMDiT fp16: rel L2 vs the pure-fp32 oracle {r_32:.3e}   (measured once also vs the fp16-emulating oracle: 7.0e-4)")
     assert r_32 <= 5e-3
+
+
+def test_sd3_call_ends_like_the_reference_with_a_vae():
+    """run_nudity_sdv3.py:351-360 reads `pipe(...).images`: with a 16-channel VAE attached and return_latents=False the call
+    returns StableDiffusion3PipelineOutput(images=[PIL...]) (safe_denoiser_pipeline.py:1195-1214); output_type="latent" puts
+    the latents there; return_dict=False gives a tuple; the engine-side default (return_latents=True) hands back the latents."""
+    from safe_denoiser_amd.pipeline_sd3 import SD3SafeDenoiserPipeline, StableDiffusion3PipelineOutput
+    from safe_denoiser_amd.schedulers import FlowMatchEulerDiscreteScheduler
+    from safe_denoiser_amd.vae import SD3_VAE_CONFIG, AutoencoderKL
+    m = SD3Transformer2DModel(text_len=45, dtype=torch.float16, **SMALL)
+    m.load_state_dict(m.synthetic_state_dict(5))
+    v = AutoencoderKL(dtype=torch.float16, **dict(SD3_VAE_CONFIG, block_out_channels=(64, 128), layers_per_block=1, sample_size=32))
+    v.load_state_dict(v.synthetic_state_dict(6))
+    g = torch.Generator().manual_seed(7)
+    P = 2
+    emb, pooled = torch.randn(2 * P, 45, 128, generator=g).cuda(), torch.randn(2 * P, 64, generator=g).cuda()
+    pipe = SD3SafeDenoiserPipeline(m, FlowMatchEulerDiscreteScheduler(), vae=v)
+    gens = lambda: [torch.Generator(device="cuda").manual_seed(3 + i) for i in range(P)]
+    kw = dict(prompt_embeds=emb, pooled_prompt_embeds=pooled, num_inference_steps=4)
+    lat = pipe(generator=gens(), **kw)
+    assert torch.is_tensor(lat) and tuple(lat.shape) == (P, 16, 16, 16)
+    out = pipe(generator=gens(), return_latents=False, **kw)
+    assert isinstance(out, StableDiffusion3PipelineOutput) and len(out.images) == P and out.images[0].size == (32, 32)
+    as_latent = pipe(generator=gens(), output_type="latent", **kw)
+    assert torch.equal(as_latent.images, lat)
+    tup = pipe(generator=gens(), return_latents=False, output_type="uint8", return_dict=False, **kw)
+    assert isinstance(tup, tuple) and tup[0].dtype == torch.uint8 and tuple(tup[0].shape) == (P, 32, 32, 3)
+    import numpy as np
+    assert np.array_equal(np.asarray(out.images[1]), tup[0][1].cpu().numpy())
