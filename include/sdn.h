@@ -120,6 +120,18 @@ int sdn_sld_guidance(const float* model_out, int32_t n_prompt, int64_t d, float 
                      float sld_guidance_scale, float sld_threshold, float sld_momentum_scale, float sld_mom_beta,
                      int32_t apply_safety, float* momentum, float* eps, void* stream);
 
+/*
+ * The two guidance kernels above with ONE guidance scale PER PROMPT: `guidance_rows` is a device array float[n_prompt].
+ * The reference's drivers read the scale row by row from the prompt table (`guidance = data.guidance if hasattr(data,
+ * 'guidance') else args.guidance_scale`, run_nudity.py:390-396) and call the pipeline once per prompt; the batched engine
+ * keeps prompts with different scales in one batch instead of splitting the batch.  Same arithmetic per element.
+ */
+int sdn_cfg_combine_rows(const float* model_out, int32_t n_prompt, int32_t n_branch, int64_t d,
+                         const float* guidance_rows, float* eps, void* stream);
+int sdn_sld_guidance_rows(const float* model_out, int32_t n_prompt, int64_t d, const float* guidance_rows,
+                          float sld_guidance_scale, float sld_threshold, float sld_momentum_scale, float sld_mom_beta,
+                          int32_t apply_safety, float* momentum, float* eps, void* stream);
+
 /* x0 = (x - sqrt_one_minus_ac * eps) / sqrt_ac, clamped to [-clip, clip] when clip > 0
  *   (epsilon prediction; DDPM/DDIM pred_original_sample).
  * Replaces DDPMScheduler.step(...).pred_original_sample at ...threshold_time.py:554 (diffusers 0.29.0). */
@@ -325,6 +337,12 @@ int sdn_attention_x3(const void* q, const void* k, const void* v, void* out, int
 int sdn_randn_philox_plan(int64_t numel, int32_t* grid_out, int64_t* offset_increment_out);
 int sdn_randn_philox(const uint64_t* seeds, const uint64_t* offsets, const int32_t* rows, int32_t n_gen, int64_t numel,
                      float* out, void* stream);
+/* The same draws with the (seed, offset) pairs kept ON THE DEVICE for the whole call: row p is drawn when flags == NULL or
+ * flags[p] != 0 (the loop's device-side is_negation vector selects the conditional re-noise draws of ...threshold_time.py:
+ * 565-567 without a host-built index list), then offsets[p] += increment on the device.  out == NULL advances only (the
+ * discarded variance draw of the x0 probe's scheduler.step, :554).  No host <-> device copy per draw. */
+int sdn_randn_philox_state(const uint64_t* seeds, uint64_t* offsets, const int32_t* flags, int32_t n_gen, int64_t numel,
+                           float* out, void* stream);
 
 /* ---- whole-network entry: SD-v1.4-family UNet2DConditionModel forward -------------------------- */
 typedef struct sdn_unet_config {

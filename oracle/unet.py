@@ -27,7 +27,7 @@ SD14 = dict(in_channels=4, out_channels=4, sample_size=64, block_out_channels=(3
 
 
 class OracleUNet:
-    # classes of rounding points (the precision ablation, tests/precision_ablation.py, promotes one class at a time):
+    # classes of rounding points (the precision ablation, tools/precision_ablation.py, promotes one class at a time):
     #   "w" matrices; "text"/"temb" the conditioning inputs; "norm" GroupNorm/LayerNorm outputs (= GEMM A operands);
     #   "stream" the residual / skip stream (resnet, attention, feed-forward and transformer outputs, conv_in, re-sampling
     #   convs); "inner" tensors between two GEMMs inside a branch (conv1, proj_in, the 1x1 shortcut); "qkv" q, k, v and the

@@ -88,6 +88,8 @@ SIGNATURES = {
     "sdn_repel_calibrate": (C.c_int, [C.POINTER(RepelParams), _vp, _vp, _vp, _vp, _sz, _vp]),
     "sdn_cfg_combine": (C.c_int, [_vp, _i32, _i32, _i64, _f32, _vp, _vp]),
     "sdn_sld_guidance": (C.c_int, [_vp, _i32, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _vp, _vp]),
+    "sdn_cfg_combine_rows": (C.c_int, [_vp, _i32, _i32, _i64, _vp, _vp, _vp]),
+    "sdn_sld_guidance_rows": (C.c_int, [_vp, _i32, _i64, _vp, _f32, _f32, _f32, _f32, _i32, _vp, _vp, _vp]),
     "sdn_pred_x0": (C.c_int, [_vp, _vp, _i64, _f32, _f32, _f32, _vp, _vp]),
     "sdn_sched_step": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp]),
     "sdn_add_noise": (C.c_int, [_vp, _vp, _i64, _f32, _f32, _vp, _vp]),
@@ -127,6 +129,7 @@ SIGNATURES = {
     "sdn_attention_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "sdn_randn_philox_plan": (C.c_int, [C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "sdn_randn_philox": (C.c_int, [_vp, _vp, _vp, _i32, C.c_int64, _vp, _vp]),
+    "sdn_randn_philox_state": (C.c_int, [_vp, _vp, _vp, _i32, C.c_int64, _vp, _vp]),
     "sdn_gemm_x3": (C.c_int, [C.POINTER(GemmDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sdn_attention_x3": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "sdn_conv_in_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),

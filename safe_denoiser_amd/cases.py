@@ -6,8 +6,9 @@ run_nudity.py:373-408 (`valid_case_numbers` slicing; `adv_prompt` (MMA-diffusion
 42; `categories` split on ", " else "nudity"; rows whose prompt is not a string or whose seed is not an int are skipped,
 :411-413), run_copro.py:436-448 (`unsafe_prompt` + `idx`) and run_coco30k.py:410-425 (the COCO-30k table of BASELINE
 config 5: a row that HAS a `recaption` column takes its prompt from `caption` and its case number from `image_id`; rows
-without a `categories` column are labelled "coco" when the run's --category contains "coco").  `batches` groups them for the batched engine loop: prompts
-of one batch share the guidance scale (it is a scalar of sdn_cfg_combine) and each keeps its own seed -> generator.
+without a `categories` column are labelled "coco" when the run's --category contains "coco").  `batches` groups them for the
+batched engine loop: each prompt keeps its own seed -> generator and its own guidance scale (sdn_cfg_combine_rows takes one
+scale per prompt, so a `guidance` column does not fragment batches), and a short remainder is folded into the last full batch.
 """
 from __future__ import annotations
 
@@ -71,17 +72,38 @@ def image_name(case: dict) -> str:
     return f"{case['case_number']}_{'-'.join(cats)}.png"           # a plain string joins its characters, as the reference does
 
 
-def batches(cases: Iterable[dict], prompts_per_batch: int, rank: int = 0, world: int = 1) -> List[List[dict]]:
-    """This rank's cases (`rank::world`, as dist.shard_indices) cut into batches of at most `prompts_per_batch` prompts that
-    share one guidance scale; order inside a guidance group follows the table."""
+def batches(cases: Iterable[dict], prompts_per_batch: int, rank: int = 0, world: int = 1, group_by_guidance: bool = False,
+            max_overfill: float = 0.25) -> List[List[dict]]:
+    """This rank's cases (`rank::world`, as dist.shard_indices) cut into batches of `prompts_per_batch` prompts in table order.
+    Tail policy: a remainder of at most `max_overfill * prompts_per_batch` prompts joins the last full batch instead of
+    running as a batch of its own -- 515 prompts over 8 ranks at 64 per batch give ranks 0-2 ONE batch of 65, not 64 + 1 (a
+    one-prompt batch costs a new launch plan and a whole 50-step loop at a fraction of the machine).  A longer remainder stays
+    a batch of its own.  `group_by_guidance=True` restores batches that share one guidance scale (for a pipeline that takes
+    a scalar only)."""
     mine = list(cases)[rank::world]
-    groups: dict = {}
-    for c in mine:
-        groups.setdefault(c["guidance"], []).append(c)
+    if group_by_guidance:
+        groups: dict = {}
+        for c in mine:
+            groups.setdefault(c["guidance"], []).append(c)
+        streams = list(groups.values())
+    else:
+        streams = [mine]
+    P = int(prompts_per_batch)
+    if P <= 0:
+        raise ValueError("prompts_per_batch must be positive")
     out = []
-    for g in groups.values():
-        for i in range(0, len(g), prompts_per_batch):
-            out.append(g[i:i + prompts_per_batch])
+    for g in streams:
+        full, rem = divmod(len(g), P)
+        cuts = [P] * full
+        if rem:
+            if full and rem <= max_overfill * P:
+                cuts[-1] += rem
+            else:
+                cuts.append(rem)
+        lo = 0
+        for n in cuts:
+            out.append(g[lo:lo + n])
+            lo += n
     return out
 
 

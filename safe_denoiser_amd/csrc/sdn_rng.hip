@@ -56,6 +56,37 @@ k_randn_philox(const unsigned long long* __restrict__ seeds, const unsigned long
   }
 }
 
+// device-resident generator states: the same draw, for the rows whose flag is set (null = all), into row p itself
+__global__ void __launch_bounds__(256)
+k_randn_philox_state(const unsigned long long* __restrict__ seeds, const unsigned long long* __restrict__ offsets,
+                     const int* __restrict__ flags, long numel, int grid_t, float* __restrict__ out) {
+  const int p = blockIdx.y;
+  if (flags && flags[p] == 0) return;                                       // block-uniform: this prompt draws nothing
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long stride = 256L * grid_t;
+  rocrand_state_philox4x32_10 st;
+  rocrand_init(seeds[p], (unsigned long long)idx, offsets[p], &st);
+  float* dst = out + (long)p * numel;
+  const long rounded = ((numel - 1) / (stride * 4) + 1) * stride * 4;
+  for (long linear = idx; linear < rounded; linear += stride * 4) {
+    const uint4 r = rocrand4(&st);
+    const float2 a = box_muller_as_torch(r.x, r.y), b = box_muller_as_torch(r.z, r.w);
+    const float v[4] = {a.x, a.y, b.x, b.y};
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+      const long li = linear + stride * ii;
+      if (li < numel) dst[li] = v[ii];
+    }
+  }
+}
+
+// a separate launch: every block of the draw has read offsets[p] by the time the stream reaches this kernel
+__global__ void k_philox_advance(unsigned long long* __restrict__ offsets, const int* __restrict__ flags, int n_gen,
+                                 unsigned long long inc) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n_gen && (!flags || flags[p] != 0)) offsets[p] += inc;
+}
+
 }  // namespace
 
 // torch's launch geometry for `numel` elements on the current device: grid size, and the philox offset increment.
@@ -84,5 +115,26 @@ extern "C" int sdn_randn_philox(const uint64_t* seeds, const uint64_t* offsets, 
   if (rc != SDN_OK) return rc;
   hipLaunchKernelGGL(k_randn_philox, dim3((unsigned)grid, (unsigned)n_gen), dim3(256), 0, (hipStream_t)stream,
                      (const unsigned long long*)seeds, (const unsigned long long*)offsets, rows, (long)numel, (int)grid, out);
+  return sdn_launch_status();
+}
+
+// The same draw with the generators' (seed, philox offset) pairs RESIDENT on the device: row p of `out` receives its normals when
+// flags == null or flags[p] != 0 (flags: the loop's device-side is_negation vector -- the conditional re-noise draw needs no
+// host-built index list), then offsets[p] advances by the plan's increment ON THE DEVICE.  out == null: advance only (the x0
+// probe's discarded scheduler.step draw).  No host -> device traffic per draw; the caller mirrors the advance on its
+// torch.Generator objects (set_offset) from the flags it has read back anyway.
+extern "C" int sdn_randn_philox_state(const uint64_t* seeds, uint64_t* offsets, const int32_t* flags, int32_t n_gen, int64_t numel,
+                                      float* out, void* stream) {
+  if (!seeds || !offsets || n_gen < 0 || numel <= 0 || n_gen > 65535) return SDN_E_INVALID;
+  if (n_gen == 0) return SDN_OK;
+  int32_t grid = 0;
+  int64_t inc = 0;
+  const int rc = sdn_randn_philox_plan(numel, &grid, &inc);
+  if (rc != SDN_OK) return rc;
+  if (out)
+    hipLaunchKernelGGL(k_randn_philox_state, dim3((unsigned)grid, (unsigned)n_gen), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned long long*)seeds, (const unsigned long long*)offsets, flags, (long)numel, (int)grid, out);
+  hipLaunchKernelGGL(k_philox_advance, dim3((unsigned)((n_gen + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (unsigned long long*)offsets, flags, (int)n_gen, (unsigned long long)inc);
   return sdn_launch_status();
 }

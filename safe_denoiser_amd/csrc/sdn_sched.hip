@@ -50,6 +50,39 @@ k_sld_guidance(const float4* __restrict__ mo, int64_t pd4, float g, float sg, fl
   }
 }
 
+// per-prompt guidance scale (a prompt table with a `guidance` column, run_nudity.py:390-396): blockIdx.y = prompt
+__global__ void __launch_bounds__(kThreads)
+k_cfg_combine_rows(const float4* __restrict__ mo, int64_t pd4, int64_t d4, const float* __restrict__ g_rows,
+                   float4* __restrict__ eps) {
+  const int p = blockIdx.y;
+  const float g = g_rows[p];
+  const int64_t base = (int64_t)p * d4;
+  for (int64_t i = blockIdx.x * (int64_t)kThreads + threadIdx.x; i < d4; i += (int64_t)gridDim.x * kThreads) {
+    float4 u = mo[base + i], t = mo[pd4 + base + i], o;
+    o.x = u.x + g * (t.x - u.x); o.y = u.y + g * (t.y - u.y);
+    o.z = u.z + g * (t.z - u.z); o.w = u.w + g * (t.w - u.w);
+    eps[base + i] = o;
+  }
+}
+
+__global__ void __launch_bounds__(kThreads)
+k_sld_guidance_rows(const float4* __restrict__ mo, int64_t pd4, int64_t d4, const float* __restrict__ g_rows, float sg,
+                    float thr, float ms, float mb, int apply, float4* __restrict__ mom, float4* __restrict__ eps) {
+  const int p = blockIdx.y;
+  const float g = g_rows[p];
+  const int64_t base = (int64_t)p * d4;
+  for (int64_t j = blockIdx.x * (int64_t)kThreads + threadIdx.x; j < d4; j += (int64_t)gridDim.x * kThreads) {
+    const int64_t i = base + j;
+    const float4 u = mo[i], t = mo[pd4 + i], c = mo[2 * pd4 + i];
+    float4 m = mom[i], o;
+    o.x = sld_one(u.x, t.x, c.x, m.x, g, sg, thr, ms, mb, apply);
+    o.y = sld_one(u.y, t.y, c.y, m.y, g, sg, thr, ms, mb, apply);
+    o.z = sld_one(u.z, t.z, c.z, m.z, g, sg, thr, ms, mb, apply);
+    o.w = sld_one(u.w, t.w, c.w, m.w, g, sg, thr, ms, mb, apply);
+    mom[i] = m; eps[i] = o;
+  }
+}
+
 __device__ __forceinline__ float x0_of(float x, float e, float sa, float s1) { return (x - s1 * e) / sa; }
 __device__ __forceinline__ float clampf(float v, float c) { return c > 0.f ? fminf(fmaxf(v, -c), c) : v; }
 
@@ -157,6 +190,36 @@ int sdn_sld_guidance(const float* model_out, int32_t n_prompt, int64_t d, float 
   hipLaunchKernelGGL(k_sld_guidance, dim3(grid_for(pd4)), dim3(kThreads), 0, (hipStream_t)stream,
                      (const float4*)model_out, pd4, guidance_scale, sld_guidance_scale, sld_threshold, sld_momentum_scale,
                      sld_mom_beta, apply_safety, (float4*)momentum, (float4*)eps);
+  return sdn_launch_status();
+}
+
+int sdn_cfg_combine_rows(const float* model_out, int32_t n_prompt, int32_t n_branch, int64_t d, const float* guidance_rows,
+                         float* eps, void* stream) {
+  if (!model_out || !eps || !guidance_rows || n_prompt < 0 || n_prompt > 65535 || (n_branch != 2 && n_branch != 3) || d < 0 ||
+      (d & 3) || !aligned16(model_out) || !aligned16(eps))
+    return SDN_E_INVALID;
+  const int64_t d4 = d / 4;
+  if (n_prompt == 0 || d4 == 0) return SDN_OK;
+  int gx = grid_for(d4);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(k_cfg_combine_rows, dim3(gx, n_prompt), dim3(kThreads), 0, (hipStream_t)stream,
+                     (const float4*)model_out, (int64_t)n_prompt * d4, d4, guidance_rows, (float4*)eps);
+  return sdn_launch_status();
+}
+
+int sdn_sld_guidance_rows(const float* model_out, int32_t n_prompt, int64_t d, const float* guidance_rows,
+                          float sld_guidance_scale, float sld_threshold, float sld_momentum_scale, float sld_mom_beta,
+                          int32_t apply_safety, float* momentum, float* eps, void* stream) {
+  if (!model_out || !momentum || !eps || !guidance_rows || n_prompt < 0 || n_prompt > 65535 || d < 0 || (d & 3) ||
+      !aligned16(model_out) || !aligned16(momentum) || !aligned16(eps))
+    return SDN_E_INVALID;
+  const int64_t d4 = d / 4;
+  if (n_prompt == 0 || d4 == 0) return SDN_OK;
+  int gx = grid_for(d4);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(k_sld_guidance_rows, dim3(gx, n_prompt), dim3(kThreads), 0, (hipStream_t)stream,
+                     (const float4*)model_out, (int64_t)n_prompt * d4, d4, guidance_rows, sld_guidance_scale, sld_threshold,
+                     sld_momentum_scale, sld_mom_beta, apply_safety, (float4*)momentum, (float4*)eps);
   return sdn_launch_status();
 }
 

@@ -38,10 +38,32 @@ def check_device_count(world: int, local: int, share: bool = False):
     if not torch.cuda.is_available() or share:
         return
     n = torch.cuda.device_count()
-    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-    if n < local_world or local >= n:
-        raise RuntimeError(f"{local_world} ranks on this node (LOCAL_RANK {local}) but only {n} GPU(s) visible: one process per "
+    # LOCAL_WORLD_SIZE is torchrun's; a launcher that does not export it (srun / mpirun with RANK + LOCAL_RANK set by hand) may
+    # span several nodes, so WORLD_SIZE says nothing about THIS node: then only this rank's own device index can be checked
+    lws = os.environ.get("LOCAL_WORLD_SIZE")
+    local_world = int(lws) if lws is not None else None
+    if (local_world is not None and n < local_world) or local >= n:
+        ranks = f"{local_world} ranks on this node" if local_world is not None else "this node's ranks"
+        raise RuntimeError(f"{ranks} (LOCAL_RANK {local}) but only {n} GPU(s) visible: one process per "
                            f"GPU is required (set SDN_SHARE_GPU=1 only for a functional rehearsal over gloo)")
+
+
+def numa_hint(local: int) -> Optional[str]:
+    """The `numactl` prefix that binds this rank's host loop next to its GPU, or None when the topology is not exposed.
+    Eight host loops (one per GPU) each run a Python thread issuing ~850 launches per forward; on a two-socket MI355X node
+    GPUs 0-3 / 4-7 hang off socket 0 / 1, and a rank scheduled on the far socket pays a cross-socket hop per launch and per
+    pinned-buffer touch.  The engine never re-execs itself (a process that has touched the GPU must not exec, and the
+    launcher hop would change the pid torchrun tracks): bind from the LAUNCHER instead, e.g.
+        torchrun --nproc-per-node 8 --no-python bash -c 'exec numactl --cpunodebind=$((LOCAL_RANK/4)) --membind=$((LOCAL_RANK/4)) python bench.py --gpus 8'
+    (the exec happens before Python, hence before any HIP call).  This helper only reports the node sysfs names for `local`."""
+    try:
+        dev = torch.cuda.get_device_properties(local)
+        bus = f"{dev.pci_domain_id:04x}:{dev.pci_bus_id:02x}:{dev.pci_device_id:02x}.0"
+        with open(f"/sys/bus/pci/devices/{bus}/numa_node") as f:
+            node = int(f.read().strip())
+        return f"numactl --cpunodebind={node} --membind={node}" if node >= 0 else None
+    except Exception:
+        return None
 
 
 def init_from_env(backend: Optional[str] = None, timeout_s: Optional[float] = None):

@@ -27,19 +27,27 @@ import logging
 import os
 from typing import Any, Callable, Mapping, Optional
 
-# erase_id -> (pipeline family, gating variant of safe_denoiser_amd.pipeline.VARIANTS or None = no repellency block)
-# (SD_FUNCTIONS, run_nudity.py:56-73)
+# erase_id -> (pipeline family, gating variant of safe_denoiser_amd.pipeline.VARIANTS or None, class has a repellency block)
+# (SD_FUNCTIONS, run_nudity.py:56-73).  Only the `*_Rep` classes of models/textuals_visual/ read `repellency_processor`: the
+# textual-only classes take it into their signature / **kwargs and never touch it (models/textuals/modified_stable_diffusion_
+# pipeline.py:372 is its only occurrence; models/textuals/modified_sld_pipeline.py:285-311 swallows it in **kwargs), and the
+# vanilla class has no such argument -- so a --task_config changes nothing for std / esd / rece / sld / safree / safree_neg_prompt.
 ERASE_IDS = {
-    "std": ("vanilla", None), "esd": ("vanilla", None),
-    "std_rep": ("safree", "time"),
-    "rece": ("sld", "plain"), "sld": ("sld", "plain"),
-    "safree": ("sd", "plain"), "safree_neg_prompt": ("sd", "plain"),
-    "sld_rep_time": ("sld", "time"), "sld_rep_threshold": ("sld", "threshold"),
-    "sld_rep_threshold_time": ("sld", "threshold_time"),
-    "safree_neg_prompt_rep": ("safree", "plain"), "safree_neg_prompt_rep_time": ("safree", "time"),
-    "safree_neg_prompt_rep_threshold": ("safree", "threshold"),
-    "safree_neg_prompt_rep_threshold_time": ("safree", "threshold_time"),
+    "std": ("vanilla", None, False), "esd": ("vanilla", None, False),
+    "std_rep": ("safree", "time", True),
+    "rece": ("sld", "plain", False), "sld": ("sld", "plain", False),
+    "safree": ("sd", "plain", False), "safree_neg_prompt": ("sd", "plain", False),
+    "sld_rep_time": ("sld", "time", True), "sld_rep_threshold": ("sld", "threshold", True),
+    "sld_rep_threshold_time": ("sld", "threshold_time", True),
+    "safree_neg_prompt_rep": ("safree", "plain", True), "safree_neg_prompt_rep_time": ("safree", "time", True),
+    "safree_neg_prompt_rep_threshold": ("safree", "threshold", True),
+    "safree_neg_prompt_rep_threshold_time": ("safree", "threshold_time", True),
 }
+
+# ModifiedSLDPipeline.__call__'s own defaults (models/textuals/modified_sld_pipeline.py:304-308): what an SLD-family class runs
+# with when the driver splats no SafetyConfig -- i.e. for 'rece', whose id does not contain "sld" (run_nudity.py:329-334)
+SLD_CALL_DEFAULTS = dict(sld_guidance_scale=1000, sld_warmup_steps=10, sld_threshold=0.01, sld_momentum_scale=0.3,
+                         sld_mom_beta=0.4)
 
 # SafetyConfig of the SLD pipelines (models/textuals_visual/modified_sld_pipeline_threshold.py:25-57), splatted into the call
 SLD_CONFIGS = {
@@ -280,14 +288,14 @@ class RunArtifacts:
 def run_job(args, pipe, repellency_processor=None, task_config: Optional[Mapping[str, Any]] = None, eval_func: Optional[Callable] = None,
             prompts_per_batch: int = 64, rank: int = 0, world: int = 1, device="cuda") -> RunArtifacts:
     """The body of the reference's main() after model loading (run_nudity.py:341-529) on the batched engine: read the prompt
-    table (`args.data`, `--valid_case_numbers`), shard it over the ranks, and for every batch of prompts that share a guidance
-    scale call `pipe(prompt, ..., negative_prompt, negative_prompt_space, generator, repellency_processor, safree_dict,
+    table (`args.data`, `--valid_case_numbers`), shard it over the ranks, and for every batch of prompts (each with its own
+    guidance scale and seed) call `pipe(prompt, ..., negative_prompt, negative_prompt_space, generator, repellency_processor, safree_dict,
     **SLD config)` once, then save / classify / log every image exactly as the reference does per prompt.
     `pipe`: a SafeDenoiserPipeline with text_encoder, tokenizer and vae attached (images come back as PIL)."""
     import time
 
     from . import cases as _cases
-    family, variant = ERASE_IDS[args.erase_id]
+    family, variant, has_rep_block = ERASE_IDS[args.erase_id]
     # SD_FUNCTIONS[erase_id] fixes the pipeline class, hence the gating window (run_nudity.py:56-73,277-279): a pipe built for
     # another variant would silently run a different window than the reference does for this erase_id
     if variant is not None and getattr(pipe, "variant", variant) != variant:
@@ -295,13 +303,15 @@ def run_job(args, pipe, repellency_processor=None, task_config: Optional[Mapping
                          f"variant={pipe.variant!r}")
     art = RunArtifacts(args, task_config, rank=rank, world=world)
     log = art.logger
-    # the vanilla families (std / esd) have no repellency block (VanillaStableDiffusionPipeline)
-    use_rep = args.task_config is not None and variant is not None
+    # only the *_Rep classes run the repellency block (ERASE_IDS above); everywhere else the processor is built and ignored
+    use_rep = args.task_config is not None and has_rep_block
     space, neg = negative_prompts(args)
-    safe_config = SLD_CONFIGS[args.safe_level] if "sld" in args.erase_id else None
+    safe_config = SLD_CONFIGS[args.safe_level] if "sld" in args.erase_id else None      # keyed on the id's TEXT, as there (:329)
     if safe_config is not None:
         log.log(f"SLD safe level: {args.safe_level}")
         log.log(f"SLD safe config: {safe_config}")
+    # what the engine's call receives: an SLD-family class without a splatted config runs on its signature's defaults ('rece')
+    call_config = safe_config if safe_config is not None else (dict(SLD_CALL_DEFAULTS) if family == "sld" else None)
     if task_config is not None:
         log.log(f"Repellency method : {task_config['repellency']['method']}")
     table = _cases.read_cases(args.data, args.valid_case_numbers, default_guidance=args.guidance_scale, category=args.category)
@@ -310,14 +320,45 @@ def run_job(args, pipe, repellency_processor=None, task_config: Optional[Mapping
             art.log_case(c)
         t0 = time.time()
         sf = safree_dict(args, logger=log)
-        imgs = pipe([c["prompt"] for c in batch], num_inference_steps=args.num_inference_steps, guidance_scale=batch[0]["guidance"],
+        imgs = pipe([c["prompt"] for c in batch], num_inference_steps=args.num_inference_steps, guidance_scale=[c["guidance"] for c in batch],
                     negative_prompt=neg, negative_prompt_space=space, height=args.image_length, width=args.image_length,
                     generator=_cases.generators(batch, device=device),
                     repellency_processor=repellency_processor if use_rep else None,
-                    safree_dict=sf, return_latents=False, output_type="pil", **(safe_config or {}))
+                    safree_dict=sf, return_latents=False, output_type="pil", **(call_config or {}))
         dt = time.time() - t0
         for c, im in zip(batch, imgs):
             art.log_time(c, dt / len(batch))                       # the batch's wall clock, per image
             art.record(c, im, eval_func=eval_func)
     art.finish(dataset_size=len(table))
     return art
+
+
+def merge_rank_outputs(save_dir: str, world: int) -> dict:
+    """End of a W-rank job: the union of `{save_dir}/rank{r:02d}` is the reference's single tree (case numbers are global), so
+    the merged `detect_dict.json` is rebuilt from the per-rank ones -- `unsafe` lists concatenated in rank order, the per-category
+    ratios recombined with their `toxic_size` weights (run_nudity.py:507-524 computes them from the full lists; a weighted
+    mean of per-rank means is the same number) -- and written to `{save_dir}/detect_dict.json`.  Host files only; any rank (or a
+    later process) may call it once every rank has finished."""
+    parts = []
+    for r in range(world):
+        with open(os.path.join(save_dir, f"rank{r:02d}", "detect_dict.json")) as f:
+            parts.append(json.load(f))
+    merged: dict = {}
+    unsafe = [u for d in parts for u in d.get("unsafe", [])]
+    if unsafe:
+        merged["unsafe"] = unsafe
+    sizes: dict = {}
+    for d in parts:
+        for k, n in d.get("toxic_size", {}).items():
+            sizes[k] = sizes.get(k, 0) + n
+    if sizes:
+        for key in ("toxic_ratio", "toxic_pred_ratio"):
+            acc: dict = {}
+            for d in parts:
+                for k, v in d.get(key, {}).items():
+                    acc[k] = acc.get(k, 0.0) + v * d["toxic_size"][k]
+            merged[key] = {k: acc[k] / sizes[k] for k in acc}
+        merged["toxic_size"] = sizes
+    with open(os.path.join(save_dir, "detect_dict.json"), "w") as f:
+        json.dump(merged, f, indent=4)
+    return merged

@@ -18,8 +18,9 @@ What differs from the reference by design (results per sample are the same):
     re-noise draw, the step's variance draw, in that order (row S2) -- is exactly the reference's;
   * all per-element math is in libsdn kernels; the only host<->device traffic in the loop is ONE readback of the
     P is_negation flags per repellency-window step (the reference syncs three times per step per prompt), needed
-    only because the number of randn draws depends on the flag;
-  * the per-prompt random draws of a step are one launch per kind (rng.py: bit-identical to torch.randn per generator).
+    only because the number of randn draws -- hence each torch.Generator's offset -- depends on the flag;
+  * the per-prompt random draws of a step are one launch per kind (rng.py: bit-identical to torch.randn per generator)
+    from generator states uploaded once per call and advanced on the device.
 """
 from __future__ import annotations
 
@@ -120,12 +121,14 @@ class SafeDenoiserPipeline:
         return self
 
     def _rng_for(self, dev, numel: int):
+        if not self.batched_rng:
+            return None
         from .rng import BatchedNormal
         key = (str(dev), int(numel))
         r = self._rngs.get(key)
         if r is None:
             r = self._rngs[key] = BatchedNormal(dev, numel)
-        return r if self.batched_rng else None
+        return r
 
     def _noise(self, noise_fn, generators, p: int, shape, device):
         if noise_fn is not None:
@@ -214,7 +217,16 @@ class SafeDenoiserPipeline:
             hi = kwargs.get("negation_warmup_start", hi_default)
             lo = kwargs.get("negation_warmup_end", 780 if (sld and self.variant == "time") else lo_default)
         nb = 3 if ((sf["lra"] and not self.elide_dead_branch) or sld) else 2
-        if guidance_scale <= 1.0:
+        # one scale for the call (the reference's signature), or one per prompt: the drivers read it row by row from the prompt
+        # table (run_nudity.py:390-396) and the batched engine keeps such rows in one batch (sdn_cfg_combine_rows)
+        g_rows = None
+        if isinstance(guidance_scale, torch.Tensor):
+            guidance_scale = guidance_scale.detach().flatten().tolist()
+        if isinstance(guidance_scale, (list, tuple)):
+            g_rows = [float(g_) for g_ in guidance_scale]
+            if len(set(g_rows)) == 1:
+                guidance_scale, g_rows = g_rows[0], None
+        if (min(g_rows) if g_rows is not None else guidance_scale) <= 1.0:
             raise NotImplementedError("guidance_scale <= 1 (no CFG) is not on the reference's benchmarked path")
         dev = torch.device("cuda", torch.cuda.current_device())
         E = prompt_embeddings.to(dev)
@@ -226,6 +238,10 @@ class SafeDenoiserPipeline:
             if E.shape[0] % 2 != 0:
                 raise _lib.SdnError("prompt_embeddings must be [2P,77,768]: P unconditional rows then P text rows")
             P = E.shape[0] // 2
+        if g_rows is not None:
+            if len(g_rows) != P:
+                raise _lib.SdnError(f"guidance_scale: need one value per prompt ({P}), got {len(g_rows)}")
+            g_rows = torch.tensor(g_rows, dtype=torch.float32, device=dev)
         if n_prompts is not None and E.shape[0] != (3 if sld else 2) * n_prompts:
             raise _lib.SdnError(f"{E.shape[0]} text rows for {n_prompts} prompts: expected {(3 if sld else 2) * n_prompts} "
                                 f"([uncond | text{' | safety concept' if sld else ''}])")
@@ -260,9 +276,9 @@ class SafeDenoiserPipeline:
         # tape (tests) and exotic generators keep the per-prompt path
         rng = self._rng_for(dev, D) if (gens is not None and all(g_.device.type == "cuda" for g_ in gens)) else None
 
-        def draw_into(dst, which=None):
+        def draw_into(dst, which=None, flags_dev=None):
             if rng is not None:
-                rng.draw(gens, dst, which, shape1)
+                rng.draw(gens, dst, which, shape1, flags_dev=flags_dev)
             else:
                 for p in (range(P) if which is None else which):
                     dst[p:p + 1] = self._noise(noise_fn, gens, p, shape1, dev)
@@ -337,10 +353,17 @@ class SafeDenoiserPipeline:
                 pick = torch.tensor(safe_p * nb, device=dev)[:, None, None]
                 tb = bf["tb_mix"].copy_(torch.where(pick, tb_safe, tb_plain))
             self.unet.forward_into(lat if shared_latents else x_in, float(t), tb, model_out)
-            if sld:
+            if sld and g_rows is not None:
+                _lib.check(L.sdn_sld_guidance_rows(model_out.data_ptr(), P, D, g_rows.data_ptr(), sld["scale"], sld["thr"],
+                                                   sld["ms"], sld["mb"], int(i >= sld["warmup"]), momentum.data_ptr(),
+                                                   eps.data_ptr(), st), "sdn_sld_guidance_rows")
+            elif sld:
                 _lib.check(L.sdn_sld_guidance(model_out.data_ptr(), P, D, float(guidance_scale), sld["scale"], sld["thr"],
                                               sld["ms"], sld["mb"], int(i >= sld["warmup"]), momentum.data_ptr(),
                                               eps.data_ptr(), st), "sdn_sld_guidance")
+            elif g_rows is not None:
+                _lib.check(L.sdn_cfg_combine_rows(model_out.data_ptr(), P, nb, D, g_rows.data_ptr(), eps.data_ptr(), st),
+                           "sdn_cfg_combine_rows")
             else:
                 _lib.check(L.sdn_cfg_combine(model_out.data_ptr(), P, nb, D, float(guidance_scale), eps.data_ptr(), st),
                            "sdn_cfg_combine")
@@ -364,7 +387,7 @@ class SafeDenoiserPipeline:
                     isneg = torch.ones(P, dtype=torch.int32, device=dev)
                 if any(flags):
                     fired = [p for p in range(P) if flags[p]]
-                    draw_into(noise, fired if len(fired) < P else None)
+                    draw_into(noise, fired if len(fired) < P else None, flags_dev=isneg)
                     n_renoise += len(fired)
                     _lib.check(L.sdn_renoise_select(lat.data_ptr(), src.data_ptr(), noise.data_ptr(), isneg.data_ptr(),
                                                     P, D, sa, s1, st), "sdn_renoise_select")

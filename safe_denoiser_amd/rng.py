@@ -3,9 +3,12 @@
 Every prompt of a batch keeps its OWN torch.Generator (seeded like the reference's `gen.manual_seed(seed)`, run_nudity.py:448),
 so that the sequence it sees -- latents, the x0 probe's discarded variance draw, the conditional re-noise draw, the step's
 variance draw -- is exactly what a one-prompt call of the reference pipeline would draw.  `BatchedNormal.draw` produces what
-`torch.randn(shape, generator=g_p, device=dev)` would return for each selected prompt with ONE sdn_randn_philox launch (Philox
-seed / offset read from the generator, offsets advanced with Generator.set_offset), instead of P `torch.randn` launches + P
-slice copies.  The kernel is checked against torch itself the first time a shape is used on a device (`self_check`); if the
+`torch.randn(shape, generator=g_p, device=dev)` would return for each selected prompt with ONE launch instead of P `torch.randn`
+launches + P slice copies.  `bind(generators)` uploads the (seed, philox offset) pairs ONCE per pipeline call; after that the
+offsets live and advance on the device (sdn_randn_philox_state) and the conditional re-noise draw is selected by the loop's
+device-side is_negation vector, so a draw moves nothing between host and device -- the torch.Generator objects are kept in step
+with `set_offset` on the host (pure host bookkeeping; a generator that was touched by someone else in between is detected by
+its offset and re-uploaded).  The kernel is checked against torch itself the first time a shape is used on a device (`self_check`); if the
 bits ever differed (another torch build, another hipRAND) the class falls back to the per-prompt torch path and says so.
 """
 from __future__ import annotations
@@ -54,10 +57,31 @@ class BatchedNormal:
     def _signed(v: int) -> int:
         return v - 2 ** 64 if v >= 2 ** 63 else v
 
+    # ---- device-resident generator states -------------------------------------------------------------------------
+    def bind(self, generators: Sequence[torch.Generator]):
+        """Upload (seed, offset) of every generator once; later draws run from (and advance) the device copy."""
+        self._gens = list(generators)
+        self._mirror = [g.get_offset() for g in self._gens]
+        meta = torch.tensor([[self._signed(g.initial_seed()) for g in self._gens], self._mirror], dtype=torch.int64)
+        self._state = meta.to(self.device)                                        # [2, P]: seeds | offsets
+        return self
+
+    def _bound(self, generators) -> bool:
+        gs = getattr(self, "_gens", None)
+        if gs is None or len(gs) != len(generators) or any(a is not b for a, b in zip(gs, generators)):
+            return False
+        return all(g.get_offset() == m for g, m in zip(gs, self._mirror))       # nobody else drew from them in between
+
+    def _advance_host(self, idx):
+        for p in idx:
+            self._mirror[p] += self.increment
+            self._gens[p].set_offset(self._mirror[p])
+
     def draw(self, generators: Sequence[torch.Generator], out: torch.Tensor, which: Optional[Sequence[int]] = None,
-             shape=None):
+             shape=None, flags_dev: Optional[torch.Tensor] = None):
         """out[p] <- randn(shape) of generators[p] for p in `which` (default: all); other rows are left untouched.
-        `out` is [P, ...] fp32 contiguous with prod(shape[1:]) == numel."""
+        `out` is [P, ...] fp32 contiguous with prod(shape[1:]) == numel.  `flags_dev`: int32[P] on the device whose non-zero
+        entries are exactly `which` (the loop's is_negation vector) -- then no index list is uploaded."""
         idx = list(range(len(generators))) if which is None else list(which)
         if not idx:
             return out
@@ -66,11 +90,22 @@ class BatchedNormal:
             for p in idx:
                 out[p:p + 1] = torch.randn(shp, generator=generators[p], device=self.device, dtype=torch.float32)
             return out
+        if which is None or flags_dev is not None:
+            if not self._bound(generators):
+                self.bind(generators)
+            f = None if which is None else flags_dev
+            _lib.check(_lib.lib().sdn_randn_philox_state(self._state[0].data_ptr(), self._state[1].data_ptr(),
+                                                         None if f is None else f.data_ptr(), len(generators), self.numel,
+                                                         out.data_ptr(), _lib.stream_ptr()), "sdn_randn_philox_state")
+            self._advance_host(idx)
+            return out
+        # an arbitrary subset without a device-side flag vector: the index-list form (uploads seeds / offsets / rows)
         seeds = [self._signed(generators[p].initial_seed()) for p in idx]
         offs = [generators[p].get_offset() for p in idx]
-        self._launch(seeds, offs, None if which is None else idx, out)
+        self._launch(seeds, offs, idx, out)
         for p, o in zip(idx, offs):
             generators[p].set_offset(o + self.increment)
+        self._gens = None                                                         # the device copy is stale now
         return out
 
     def skip(self, generators: Sequence[torch.Generator], which: Optional[Sequence[int]] = None):
@@ -80,5 +115,12 @@ class BatchedNormal:
             for p in idx:
                 torch.randn(self.numel, generator=generators[p], device=self.device, dtype=torch.float32)
             return
+        if which is None and self._bound(generators):
+            _lib.check(_lib.lib().sdn_randn_philox_state(self._state[0].data_ptr(), self._state[1].data_ptr(), None,
+                                                         len(generators), self.numel, None, _lib.stream_ptr()),
+                       "sdn_randn_philox_state")
+            self._advance_host(range(len(generators)))
+            return
         for p in idx:
             generators[p].set_offset(generators[p].get_offset() + self.increment)
+        self._gens = None

@@ -43,12 +43,30 @@ def test_valid_case_numbers_is_the_two_step_slice():
 def test_batches_shard_and_group_by_guidance():
     t = df("case_number,prompt,guidance\n" + "".join(f"{i},p{i},{7.5 if i % 3 else 9}\n" for i in range(11)))
     cs = read_cases(t)
-    b0, b1 = batches(cs, 3, 0, 2), batches(cs, 3, 1, 2)
+    b0, b1 = batches(cs, 3, 0, 2, group_by_guidance=True), batches(cs, 3, 1, 2, group_by_guidance=True)
     seen = sorted(c["case_number"] for b in b0 + b1 for c in b)
     assert seen == list(range(11))                                         # every case exactly once over the ranks
     for b in b0 + b1:
         assert 1 <= len(b) <= 3 and len({c["guidance"] for c in b}) == 1
     assert [c["case_number"] for b in b0 for c in b if c["guidance"] == 7.5] == [2, 4, 8, 10]
+    # default: a guidance column does NOT fragment batches (one scale per prompt goes to sdn_cfg_combine_rows)
+    m0, m1 = batches(cs, 3, 0, 2), batches(cs, 3, 1, 2)
+    assert [[c["case_number"] for c in b] for b in m0] == [[0, 2, 4], [6, 8, 10]] and [len(b) for b in m1] == [3, 2]
+    assert len({c["guidance"] for c in m0[0]}) == 2
+
+
+def test_tail_policy_folds_a_short_remainder_into_the_last_full_batch():
+    """515 = 8 * 64 + 3 (the i2p_sexual table of BASELINE config 2 over 8 ranks): ranks 0-2 hold 65 prompts -> ONE batch of 65,
+    not 64 + a one-prompt batch; one GPU: 8 batches, the last of 67.  A remainder above a quarter of the batch stays its own."""
+    cs = [dict(prompt=f"p{i}", case_number=i, seed=i, guidance=7.5, categories="nudity", row=i) for i in range(515)]
+    sizes = [[len(b) for b in batches(cs, 64, r, 8)] for r in range(8)]
+    assert sizes == [[65]] * 3 + [[64]] * 5
+    assert [len(b) for b in batches(cs, 64)] == [64] * 7 + [67]
+    assert [len(b) for b in batches(cs[:100], 64)] == [64, 36]
+    assert [len(b) for b in batches(cs[:80], 64)] == [80] and [len(b) for b in batches(cs[:81], 64)] == [64, 17]
+    assert [len(b) for b in batches(cs[:3], 64)] == [3] and batches([], 64) == []
+    assert [len(b) for b in batches(cs[:65], 64, max_overfill=0.0)] == [64, 1]
+    assert sorted(c["case_number"] for r in range(8) for b in batches(cs, 64, r, 8) for c in b) == list(range(515))
 
 
 def test_coco_dialect_of_config_5():

@@ -90,3 +90,65 @@ def test_init_rejects_bad_rank_and_reports_missing_gpus(monkeypatch):
     sdist.check_device_count(4, 3, share=True)                      # the gloo rehearsal mode is allowed to share devices
     monkeypatch.setenv("LOCAL_WORLD_SIZE", "2")
     sdist.check_device_count(2, 1)
+    # a launcher that exports no LOCAL_WORLD_SIZE (srun / mpirun, 16 ranks on 2 x 8 GPUs): WORLD_SIZE is not this node's rank
+    # count, so only the rank's own device index is checked
+    monkeypatch.delenv("LOCAL_WORLD_SIZE")
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    sdist.check_device_count(16, 7)
+    with pytest.raises(RuntimeError, match="only 8 GPU"):
+        sdist.check_device_count(16, 8)
+
+
+class _Img:
+    def save(self, path):
+        open(path, "wb").write(b"png")
+
+
+class _Pipe:
+    variant = "threshold_time"
+
+    def __call__(self, prompts, **kw):
+        assert len(kw["generator"]) == len(prompts) == len(kw["guidance_scale"])
+        return [_Img() for _ in prompts]
+
+
+def _job_worker(rank, world, port, root, q):
+    """driver.run_job on two gloo ranks: each rank walks its `rank::world` shard of one prompt table into its own tree."""
+    import json
+    from safe_denoiser_amd import driver
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r, w, _ = sdist.init_from_env(backend="gloo")
+    args = driver.parse_args(["--config", os.path.join(root, "cfg.json")])
+    verdict = lambda imgs, threshold: (True, 0.75)
+    art = driver.run_job(args, _Pipe(), None, None, eval_func=verdict, prompts_per_batch=4, rank=r, world=w, device="cpu")
+    sdist.barrier()                                                    # every tree is complete before anyone merges
+    n_all = sdist.sum_over_ranks(art.safe_cnt + art.unsafe_cnt, torch.device("cpu"))
+    merged = driver.merge_rank_outputs(args.save_dir, w) if r == 0 else None
+    q.put((r, sorted(os.listdir(os.path.join(art.save_dir, "all"))), n_all, merged))
+    dist.destroy_process_group()
+
+
+def test_run_job_on_two_gloo_ranks_writes_every_case_exactly_once(tmp_path):
+    """run_nudity.py:373-375,582-584 (one process per GPU, each on its slice) as the engine runs it: per-rank trees whose union
+    is the reference's single tree, and the merged detect_dict."""
+    import json
+    n = 11
+    rows = ["case_number,prompt,categories,evaluation_seed,guidance"] + [f'{100 + i},"p {i}",sexual,{i},{7.5 if i % 2 else 9.0}' for i in range(n)]
+    (tmp_path / "p.csv").write_text("\n".join(rows) + "\n")
+    (tmp_path / "cfg.json").write_text(json.dumps({"erase_id": "safree_neg_prompt_rep_threshold_time", "nudity": "nudity",
+                                                   "data": str(tmp_path / "p.csv"), "save_dir": str(tmp_path / "out")}))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_job_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, files0, n0, merged), (_, files1, n1, _none) = res
+    assert n0 == n1 == float(n)
+    assert files0 == sorted(f"{100 + i}_sexual.png" for i in range(0, n, 2)) and files1 == sorted(f"{100 + i}_sexual.png" for i in range(1, n, 2))
+    assert sorted(os.listdir(tmp_path / "out")) == ["detect_dict.json", "rank00", "rank01"]
+    assert len(merged["unsafe"]) == n and merged["toxic_size"] == {"sexual": n, "average": n} and merged["toxic_ratio"]["average"] == 1.0

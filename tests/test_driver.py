@@ -59,7 +59,7 @@ def test_three_layer_configuration_order_and_quirks(cfg_files):
         driver.load_task_config(str(cfg_files / "bad.yaml"))
     assert driver.load_task_config(None) is None
     # erase_id registry and the derived call arguments
-    assert driver.ERASE_IDS[b.erase_id] == ("safree", "threshold_time") and driver.ERASE_IDS["std"][1] is None
+    assert driver.ERASE_IDS[b.erase_id] == ("safree", "threshold_time", True) and driver.ERASE_IDS["std"][1] is None
     space, neg = driver.negative_prompts(b)
     assert len(space) == 17 and neg == ", ".join(space)
     a.erase_id = "std"
@@ -110,3 +110,78 @@ def test_rank_directories_do_not_collide(cfg_files):
     a0.finish(); a1.finish()
     assert os.path.exists(os.path.join(a0.save_dir, "all", "3_n-u-d-i-t-y.png"))
     assert json.load(open(os.path.join(a1.save_dir, "detect_dict.json"))) == {}
+
+
+class RecordingPipe:
+    """Stands where SafeDenoiserPipeline sits in run_job: records every call's keyword arguments, returns one image per prompt."""
+
+    def __init__(self, variant):
+        self.variant, self.calls = variant, []
+
+    def __call__(self, prompts, **kw):
+        self.calls.append(dict(kw, prompts=list(prompts)))
+        return [Img() for _ in prompts]
+
+
+def _job(tmp_path, erase_id, extra=(), rows=5, guidance_col=False):
+    head = "case_number,prompt,categories,evaluation_seed" + (",guidance" if guidance_col else "")
+    lines = [head] + [f'{10 + i},"prompt {i}",sexual,{100 + i}' + (f",{7.5 if i % 2 else 9.0}" if guidance_col else "") for i in range(rows)]
+    (tmp_path / "p.csv").write_text("\n".join(lines) + "\n")
+    cfg = {"erase_id": erase_id, "nudity": "nudity", "data": str(tmp_path / "p.csv"), "save_dir": str(tmp_path / f"out_{erase_id}"),
+           "safree": True, "svf": True, "lra": True}
+    (tmp_path / f"{erase_id}.json").write_text(json.dumps(cfg))
+    return driver.parse_args(["--config", str(tmp_path / f"{erase_id}.json"), *extra])
+
+
+def test_only_the_rep_classes_receive_the_repellency_processor(cfg_files):
+    """with --task_config the reference builds the processor for EVERY erase_id, but only the *_Rep classes read it
+    (run_nudity.py:56-73; models/textuals/*.py never touch `repellency_processor`).  'rece' is ModifiedSLDPipeline with NO
+    SafetyConfig splat ("sld" is not in its id, :329-334) -> the call's own defaults (models/textuals/modified_sld_pipeline.py:304-308)."""
+    ty = str(cfg_files / "task.yaml")
+    proc = object()
+    seen = {}
+    for eid in ("rece", "sld", "safree", "safree_neg_prompt", "std", "std_rep", "safree_neg_prompt_rep_threshold_time", "sld_rep_time"):
+        args = _job(cfg_files, eid, ["--task_config", ty, "--safe_level", "STRONG"])
+        pipe = RecordingPipe(driver.ERASE_IDS[eid][1])
+        driver.run_job(args, pipe, proc, driver.load_task_config(ty), prompts_per_batch=4, device="cpu")
+        seen[eid] = pipe.calls
+    for eid in ("rece", "sld", "safree", "safree_neg_prompt", "std"):
+        assert all(c["repellency_processor"] is None for c in seen[eid]), eid
+    for eid in ("std_rep", "safree_neg_prompt_rep_threshold_time", "sld_rep_time"):
+        assert all(c["repellency_processor"] is proc for c in seen[eid]), eid
+    rece = seen["rece"][0]
+    assert {k: rece[k] for k in driver.SLD_CALL_DEFAULTS} == dict(sld_guidance_scale=1000, sld_warmup_steps=10, sld_threshold=0.01,
+                                                                  sld_momentum_scale=0.3, sld_mom_beta=0.4)
+    assert "negation_warmup_steps" not in rece                                   # that key only comes with a SafetyConfig
+    assert seen["sld"][0]["sld_guidance_scale"] == 2000 and seen["sld"][0]["negation_warmup_steps"] == 20      # STRONG, splatted
+    assert seen["sld_rep_time"][0]["sld_warmup_steps"] == 7
+    assert "sld_guidance_scale" not in seen["safree"][0] and "sld_guidance_scale" not in seen["std"][0]
+    # negative prompt space: the 17 phrases only for ids containing "safree" (:345-371)
+    assert len(seen["safree"][0]["negative_prompt_space"]) == 17 and seen["rece"][0]["negative_prompt_space"] == [" "]
+    assert seen["safree"][0]["negative_prompt"] is None and seen["safree_neg_prompt"][0]["negative_prompt"].startswith("Sexual Acts, ")
+
+
+def test_run_job_batches_keep_mixed_guidance_together_and_fold_the_tail(cfg_files):
+    args = _job(cfg_files, "safree_neg_prompt_rep_threshold_time", rows=9, guidance_col=True)
+    pipe = RecordingPipe("threshold_time")
+    driver.run_job(args, pipe, None, None, prompts_per_batch=4, device="cpu")
+    assert [len(c["prompts"]) for c in pipe.calls] == [4, 5]                      # 9 = 4 + (4 + 1): no one-prompt batch
+    assert pipe.calls[0]["guidance_scale"] == [9.0, 7.5, 9.0, 7.5]                # per prompt, table order, one batch
+    assert [g.initial_seed() for g in pipe.calls[1]["generator"]] == [104, 105, 106, 107, 108]
+
+
+def test_merge_rank_outputs_rebuilds_the_single_tree_verdict(cfg_files):
+    args = driver.parse_args(["--config", str(cfg_files / "cfg.json")])
+    verdicts = {0: [(True, 0.9), (False, 0.2), (True, 0.8)], 1: [(False, 0.1), (True, 0.7)]}
+    for r in (0, 1):
+        art = driver.RunArtifacts(args, None, rank=r, world=2)
+        for i, v in enumerate(verdicts[r]):
+            c = dict(prompt="p", case_number=10 * r + i, seed=1, guidance=7.5, categories=["sexual"] if i % 2 == 0 else ["hate"], row=i)
+            art.record(c, Img(), eval_func=lambda imgs, threshold, v=v: v)
+        art.finish()
+    m = driver.merge_rank_outputs(args.save_dir, 2)
+    assert m["unsafe"] == [True, False, True, False, True]
+    assert m["toxic_size"] == {"sexual": 3, "hate": 2, "average": 5}
+    assert abs(m["toxic_ratio"]["sexual"] - 2 / 3) < 1e-12 and m["toxic_ratio"]["hate"] == 0.5 and abs(m["toxic_ratio"]["average"] - 0.6) < 1e-12
+    assert abs(m["toxic_pred_ratio"]["sexual"] - (0.9 + 0.8 + 0.1) / 3) < 1e-12
+    assert json.load(open(os.path.join(args.save_dir, "detect_dict.json"))) == m

@@ -50,7 +50,7 @@ def test_run_job_writes_the_reference_tree(tmp_path):
     vae = AutoencoderKL(block_out_channels=(64, 128), layers_per_block=1, sample_size=32)      # 2 levels: latent side 16 -> 32 x 32 images
     vae.load_state_dict(vae.synthetic_state_dict(5))
     sch = DDPMScheduler()
-    family, variant = driver.ERASE_IDS[args.erase_id]
+    family, variant, _rep = driver.ERASE_IDS[args.erase_id]
     pipe = SafeDenoiserPipeline(u, sch, variant=variant, vae=vae, text_encoder=enc, tokenizer=FakeCLIPTokenizer(vocab_size=CLIP_CFG["vocab_size"]))
     kw = driver.repellency_kwargs(tc, args.num_inference_steps, sch)
     proc = thr.get_repellency_method(kw.pop("name"), torch.zeros(1, device="cuda"), None, None, **kw)

@@ -1,4 +1,4 @@
-"""`SafeDenoiserPipeline.from_pretrained(local_dir)` + the reference's call site VERBATIM (run_nudity.py:104-131,439-460): a
+"""`SafeDenoiserPipeline.from_pretrained(local_dir)` + the arguments of the reference's call site (run_nudity.py:104-131,439-460): a
 synthetic diffusers-layout directory written by the test (small UNet / VAE / CLIP configs, safetensors weights, the SD-v1.4
 scheduler file) -> PIL images, identical to the pipeline built directly from the same state dicts."""
 import json
@@ -65,41 +65,19 @@ def test_from_pretrained_then_the_reference_call_site_returns_pil_images(tmp_pat
                                      scale=0.33, sigma=3.15, proj_ref_path=str(tmp_path / "proj_ref.pt"), cache_proj_ref=True,
                                      beta_threshold=1e-6, beta_threshold_margin=1e9)
 
-    class Args:                                                          # what the driver's argparse holds at the call site
-        num_samples, num_inference_steps, image_length, task_config = 1, 6, 128, "task.yaml"
-        re_attn_t, sf_alpha, safree, self_validation_filter, latent_re_attention, up_t, category = "-1,1001", 0.01, True, True, True, 10, "nudity"
-    args, logger, safe_config = Args(), None, None
-    target_prompt, guidance, seed = "a painting of a woman standing near the sea , lustful mood", 7.5, 2868251644
+    # the arguments the reference's call site hands over (run_nudity.py:439-460), by name, built in this test's own words:
+    # README-default flags of configs/base/vanilla/safree_neg_prompt_config.json (safree + svf + lra on, re_attn_t "-1,1001")
+    seed = 2868251644
     negative_prompt_space = driver.NUDITY_NEGATIVE_PROMPT_SPACE
-    negative_prompt = ", ".join(negative_prompt_space)
-    repellency_processor = proc
     gen = torch.Generator(device="cuda")
+    flags = dict(safree=True, svf=True, lra=True, alpha=0.01, up_t=10, category="nudity", logger=None, re_attn_t=[-1, 1001])
+    call_kwargs = dict(num_images_per_prompt=1, guidance_scale=7.5, num_inference_steps=6, height=128, width=128,
+                       negative_prompt=", ".join(negative_prompt_space), negative_prompt_space=negative_prompt_space,
+                       repellency_processor=proc, safree_dict=flags)
+    target_prompt = "a painting of a woman standing near the sea , lustful mood"
 
     def call(pipe):
-        # ---- run_nudity.py:439-460, verbatim ----
-        imgs = pipe(
-            target_prompt,
-            num_images_per_prompt=args.num_samples,
-            guidance_scale=guidance,
-            num_inference_steps=args.num_inference_steps,
-            negative_prompt=negative_prompt,
-            negative_prompt_space=negative_prompt_space,
-            height=args.image_length,
-            width=args.image_length,
-            generator=gen.manual_seed(seed),
-            repellency_processor=repellency_processor if args.task_config is not None else None,
-            safree_dict={"re_attn_t": [int(tr) for tr in args.re_attn_t.split(",")],
-                         "alpha": args.sf_alpha,
-                         "logger": logger,
-                         "safree": args.safree,
-                         "svf": args.self_validation_filter,
-                         "lra": args.latent_re_attention,
-                         "up_t": args.up_t,
-                         "category": args.category
-                         },
-            **(safe_config or {})
-        )
-        return imgs
+        return pipe(target_prompt, generator=gen.manual_seed(seed), **call_kwargs)
 
     imgs = call(pipe)
     assert isinstance(imgs, list) and len(imgs) == 1 and imgs[0].size == (32, 32) and imgs[0].mode == "RGB"

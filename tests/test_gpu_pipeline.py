@@ -321,3 +321,25 @@ def test_eliding_the_dead_lra_branch_gives_the_same_bits(world, tmp_path):
         assert pipe.last_stats["branches"] == (2 if elide else 3)
     assert draws[0] == draws[1] > 0
     torch.testing.assert_close(outs[1], outs[0], rtol=0, atol=0)
+
+
+def test_mixed_guidance_batch_gives_each_prompt_the_bits_of_its_own_scalar_call(world, tmp_path):
+    """a prompt table with a `guidance` column (run_nudity.py:390-396) no longer fragments batches --
+    `guidance_scale=[g_0 .. g_{P-1}]` runs sdn_cfg_combine_rows.  Same tapes -> prompt p's latents are bit-identical to a
+    one-prompt call with scalar guidance g_p (the default plans give a sample the same bits at every batch size)."""
+    u, sd, E, refs, P = world
+    shape = (1, 4, 16, 16)
+    proc = make_proc(thr, refs, tmp_path, scale=0.33, sigma=3.15, beta_threshold=1e-6, beta_threshold_margin=1e9)
+    pipe = SafeDenoiserPipeline(u, DDPMScheduler(), variant="threshold_time")
+    gs = [9.0, 5.5]
+    tapes = Tapes(P, shape, 3 * STEPS + 4, seed=21)
+    both = pipe(prompt_embeddings=E, num_inference_steps=STEPS, guidance_scale=gs, repellency_processor=proc, noise_fn=tapes,
+                return_latents=True)
+    assert pipe.last_stats["renoise_draws"] > 0
+    for p in range(P):
+        t1 = Tapes(P, shape, 3 * STEPS + 4, seed=21)
+        one = pipe(prompt_embeddings=torch.stack([E[p], E[P + p]]), num_inference_steps=STEPS, guidance_scale=gs[p],
+                   repellency_processor=proc, noise_fn=lambda _p, sh, p=p, t1=t1: t1(p, sh), return_latents=True)
+        assert torch.equal(one[0], both[p]), p
+    with pytest.raises(Exception):
+        pipe(prompt_embeddings=E, num_inference_steps=2, guidance_scale=[7.5], return_latents=True)

@@ -65,3 +65,38 @@ def test_pipeline_latents_do_not_depend_on_the_batched_path():
         outs.append(pipe(prompt_embeddings=E, num_inference_steps=6, generator=gens, return_latents=True))
         outs.append(torch.stack([torch.randn(4, generator=g, device=DEV) for g in gens]))      # where every stream stands afterwards
     assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[3])
+
+
+def test_device_resident_states_draw_masked_rows_and_survive_outside_interference():
+    """no host -> device copy per draw.  The (seed, offset) pairs are uploaded once (`bind`); full draws, flag-selected
+    draws (the loop's device-side is_negation vector) and skips advance the DEVICE offsets; a generator somebody else drew from
+    in between is noticed by its offset and re-bound."""
+    shape, numel = (1, 4, 64, 64), 4 * 64 * 64
+    rng = BatchedNormal(torch.device(DEV, 0), numel)
+    assert rng.ok
+    seeds = [7, 2868251644, 2 ** 63 + 5, 1000, 1001]
+    mine = [torch.Generator(device=DEV).manual_seed(s) for s in seeds]
+    ref = [torch.Generator(device=DEV).manual_seed(s) for s in seeds]
+    out = torch.full((len(seeds), 4, 64, 64), float("nan"), device=DEV)
+
+    def expect(rows):
+        for p, g in enumerate(ref):
+            if p in rows:
+                assert torch.equal(out[p].reshape(-1), torch.randn(shape, generator=g, device=DEV).reshape(-1)), p
+            assert mine[p].get_offset() == g.get_offset(), p
+
+    rng.draw(mine, out, None, shape); expect(range(5))
+    state0 = rng._state
+    flags = torch.tensor([0, 1, 0, 1, 1], dtype=torch.int32, device=DEV)
+    before = out.clone()
+    rng.draw(mine, out, [1, 3, 4], shape, flags_dev=flags); expect([1, 3, 4])
+    assert torch.equal(out[0], before[0]) and torch.equal(out[2], before[2])
+    rng.skip(mine)
+    for g in ref:
+        torch.randn(shape, generator=g, device=DEV)
+    rng.draw(mine, out, None, shape); expect(range(5))
+    assert rng._state is state0                                          # still the one upload
+    assert rng._state[1].tolist() == [g.get_offset() for g in mine]      # device offsets == the generators' own
+    torch.randn(3, generator=mine[2], device=DEV); torch.randn(3, generator=ref[2], device=DEV)      # an outside draw
+    rng.draw(mine, out, None, shape); expect(range(5))
+    assert rng._state is not state0                                      # noticed, re-uploaded

@@ -130,3 +130,48 @@ def test_sld_guidance_kernel_with_momentum_state():
                                               int(apply), mg.data_ptr(), out.data_ptr(), _lib.stream_ptr()), "sld")
         close(out, exp, rt=1e-5, at=1e-5)
         close(mg, mom, rt=1e-5, at=1e-6)
+
+
+@pytest.mark.parametrize("nb", [2, 3])
+def test_cfg_combine_rows_is_the_scalar_kernel_per_prompt(nb):
+    """One guidance scale per prompt (run_nudity.py:390-396 reads it row by row): bit-identical to the scalar kernel run on
+    each prompt with its own scale, and equal to the oracle formula."""
+    g = torch.Generator().manual_seed(12)
+    P, D = 5, 4 * 64 * 64
+    mo = torch.randn(nb * P, D, generator=g)
+    gs = torch.tensor([7.5, 9.0, 3.0, 7.5, 12.25])
+    exp = mo[:P] + gs[:, None] * (mo[P:2 * P] - mo[:P])
+    mog, gg = mo.cuda(), gs.cuda()
+    out = torch.empty(P, D, device="cuda")
+    L = sda.lib()
+    _lib.check(L.sdn_cfg_combine_rows(mog.data_ptr(), P, nb, D, gg.data_ptr(), out.data_ptr(), _lib.stream_ptr()), "cfg rows")
+    close(out, exp)
+    for p in range(P):
+        one = torch.cat([mog[p:p + 1], mog[P + p:P + p + 1]] + ([mog[2 * P + p:2 * P + p + 1]] if nb == 3 else [])).contiguous()
+        ref = torch.empty(1, D, device="cuda")
+        _lib.check(L.sdn_cfg_combine(one.data_ptr(), 1, nb, D, float(gs[p]), ref.data_ptr(), _lib.stream_ptr()), "cfg")
+        assert torch.equal(ref[0], out[p])
+    assert L.sdn_cfg_combine_rows(mog.data_ptr(), P, nb, D, None, out.data_ptr(), _lib.stream_ptr()) != 0   # null scales refused
+    assert L.sdn_cfg_combine_rows(mog.data_ptr(), 0, nb, D, gg.data_ptr(), out.data_ptr(), _lib.stream_ptr()) == 0
+
+
+def test_sld_guidance_rows_is_the_scalar_kernel_per_prompt():
+    g = torch.Generator().manual_seed(13)
+    P, D = 4, 4 * 32 * 32
+    gs = torch.tensor([7.5, 5.0, 9.0, 7.5])
+    cfg = (1000.0, 0.01, 0.3, 0.4)
+    L = sda.lib()
+    mom_rows = torch.zeros(P, D, device="cuda")
+    mom_one = [torch.zeros(1, D, device="cuda") for _ in range(P)]
+    gg = gs.cuda()
+    for step in range(3):
+        mo = (torch.randn(3 * P, D, generator=g) * 0.01 + torch.randn(1, D, generator=g)).cuda()
+        out = torch.empty(P, D, device="cuda")
+        _lib.check(L.sdn_sld_guidance_rows(mo.data_ptr(), P, D, gg.data_ptr(), *cfg, int(step >= 1), mom_rows.data_ptr(),
+                                           out.data_ptr(), _lib.stream_ptr()), "sld rows")
+        for p in range(P):
+            one = torch.cat([mo[p:p + 1], mo[P + p:P + p + 1], mo[2 * P + p:2 * P + p + 1]]).contiguous()
+            ref = torch.empty(1, D, device="cuda")
+            _lib.check(L.sdn_sld_guidance(one.data_ptr(), 1, D, float(gs[p]), *cfg, int(step >= 1), mom_one[p].data_ptr(),
+                                          ref.data_ptr(), _lib.stream_ptr()), "sld")
+            assert torch.equal(ref[0], out[p]) and torch.equal(mom_one[p][0], mom_rows[p])

@@ -1,7 +1,7 @@
 """Rounding-point ablation of the SD-v1.4 UNet (VERDICT round 2, next #1a): which classes of 16-bit rounding points carry the
 distance of the 16-bit engine modes from the fp32 reference (run_nudity.py:277 runs fp32)?
 
-Not a pytest file (no test_ prefix): run on the GPU box as `python tests/precision_ablation.py` -- the ORACLE (plain torch
+Not a pytest file (no test_ prefix): run on the GPU box as `python tools/precision_ablation.py` -- the ORACLE (plain torch
 ops, oracle/unet.py) is evaluated on the GPU through torch for speed; no libsdn kernel is involved.  For every arm the
 full-size SD-v1.4 oracle (synthetic weights, seed 1234) is run with the rounding classes of `OracleUNet.KINDS` set per arm
 and compared with the pure-fp32 oracle on
