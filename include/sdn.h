@@ -545,10 +545,13 @@ typedef struct sdn_clip_config {
   int32_t hidden_size, intermediate_size;/* 768, 3072                                                  */
   int32_t num_layers, num_heads;         /* 12, 12 (head dim must be 64)                               */
   int32_t max_position_embeddings;       /* 77 = the sequence length every call uses                   */
-  int32_t dtype;                         /* 0 = bf16, 1 = fp16 storage                                 */
+  int32_t dtype;                         /* 0 = bf16, 1 = fp16 storage; 2 = fp32 storage on the f32-input matrix cores; 3 = fp32
+                                          * storage with bf16x3 split-operand GEMMs (sdn_gemm_x3) -- the reference loads the text
+                                          * encoder in fp32 like the rest of the pipeline (run_nudity.py:277 -> load_sd(...,
+                                          * torch.float32)); modes 2 / 3 take f32 weights and return f32 hidden states */
 } sdn_clip_config;
 int sdn_clip_create(const sdn_clip_config* cfg_host, sdn_unet** out_host);
-/* last_hidden_state [B, 77, hidden] 16-bit (after final_layer_norm) = text_model(input_ids [B, 77] int32,
+/* last_hidden_state [B, 77, hidden] (16-bit, or f32 for dtype 2 / 3; after final_layer_norm) = text_model(input_ids [B, 77] int32,
  * attention_mask [B, 77] int32 with 1 = attend / 0 = padding, or NULL).  Attention is causal, as in CLIP. */
 int sdn_clip_forward(sdn_unet* clip, const void* weights, const int32_t* input_ids, const int32_t* attention_mask,
                      void* last_hidden_state, int32_t batch, void* workspace, size_t workspace_bytes, void* stream);
@@ -558,6 +561,12 @@ int sdn_clip_embed(int32_t dtype, const int32_t* input_ids, const void* token_em
 int sdn_masked_attention(int32_t dtype, const void* q, const void* k, const void* v, void* out, const int32_t* key_mask,
                          int32_t causal, int32_t batch, int32_t heads, int32_t n, int32_t head_dim, int32_t ldq,
                          int32_t ldk, int32_t ldv, int32_t ldo, float scale, void* stream);
+/* the same two blocks on f32 storage (dtype 2 / 3 plans): exact f32 products on the f32-input matrix cores */
+int sdn_clip_embed_f32(const int32_t* input_ids, const void* token_embedding, const void* position_embedding, int64_t rows,
+                       int32_t seq_len, int32_t hidden, int32_t vocab, void* out, void* stream);
+int sdn_masked_attention_f32(const void* q, const void* k, const void* v, void* out, const int32_t* key_mask, int32_t causal,
+                             int32_t batch, int32_t heads, int32_t n, int32_t head_dim, int32_t ldq, int32_t ldk, int32_t ldv,
+                             int32_t ldo, float scale, void* stream);
 
 /* Graph mode for launch-bound (small) batches: sdn_unet_forward / sdn_mmdit_forward capture their ~850 launches into a
  * hipGraph once per (batch, operand addresses) and replay it afterwards -- one launch per forward plus a one-float store

@@ -43,7 +43,10 @@ def clip_state_dict_shapes(cfg: dict | None = None) -> dict:
 
 
 class OracleCLIPText:
-    def __init__(self, state_dict: dict, config: dict | None = None, act_dtype=None):
+    def __init__(self, state_dict: dict, config: dict | None = None, act_dtype=None, device=None):
+        """`device`: evaluate the same torch ops there (a full-size encoder over ~100 sequences is minutes on a few host cores);
+        the arithmetic is unchanged fp32 (callers switch TF32 off)."""
+        self.device = device
         self.cfg = dict(SD14_CLIP)
         if config:
             self.cfg.update(config)
@@ -54,18 +57,21 @@ class OracleCLIPText:
             v = v.detach().float()
             if act_dtype is not None and v.dim() > 1:
                 v = v.to(act_dtype).float()
-            self.sd[k] = v
+            self.sd[k] = v if device is None else v.to(device)
 
     def q(self, x):
         return x if self.q_dtype is None else x.to(self.q_dtype).float()
 
     def __call__(self, input_ids: torch.Tensor, attention_mask: torch.Tensor | None = None) -> torch.Tensor:
         c, P = self.cfg, self.sd
+        if self.device is not None:
+            input_ids = input_ids.to(self.device)
+            attention_mask = None if attention_mask is None else attention_mask.to(self.device)
         b, n = input_ids.shape
         C_, H = c["hidden_size"], c["num_attention_heads"]
         d = C_ // H
         x = self.q(P["embeddings.token_embedding.weight"][input_ids.long()] + P["embeddings.position_embedding.weight"][:n][None])
-        bias = torch.full((n, n), float("-inf")).triu_(1)[None, None]                     # causal: key <= query
+        bias = torch.full((n, n), float("-inf"), device=input_ids.device).triu_(1)[None, None]   # causal: key <= query
         if attention_mask is not None:
             bias = bias + torch.where(attention_mask[:, None, None, :] != 0, 0.0, float("-inf"))
         for l in range(c["num_hidden_layers"]):

@@ -166,6 +166,8 @@ SIGNATURES = {
     "sdn_clip_embed": (C.c_int, [_i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "sdn_masked_attention": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                        _f32, _vp]),
+    "sdn_clip_embed_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
+    "sdn_masked_attention_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "sdn_unet_prepare": (C.c_int, [_vp, _vp, _vp]),
     "sdn_unet_set_graph_mode": (None, [_vp, _i32]),
     "sdn_unet_set_split_k": (None, [_vp, _i32]),

@@ -29,10 +29,20 @@ class TextEncoderOutput(tuple):
 
 
 class CLIPTextModel(UNet2DConditionModel):
-    def __init__(self, dtype=torch.bfloat16, **config):
-        if dtype not in (torch.bfloat16, torch.float16):
-            raise _lib.SdnError("storage dtype must be torch.bfloat16 or torch.float16")
+    def __init__(self, dtype=torch.bfloat16, precision: str | None = None, **config):
+        """dtype = bf16 / fp16 storage, or torch.float32 = the plan's fp32 storage mode on the f32-input matrix cores;
+        precision = "bf16x3" = fp32 storage with split-operand GEMMs on the bf16 matrix cores (the UNet's tolerance-meeting
+        mode).  The reference loads the text encoder in fp32 with the rest of the pipeline (run_nudity.py:277 -> load_sd(...,
+        torch.float32)); its hidden states feed every cross-attention AND the SAFREE decisions (trigger-token mask, beta ->
+        step count), so the fp32-storage modes are what a seed-for-seed comparison from token ids needs."""
+        if precision not in (None, "fp32", "bf16x3"):
+            raise _lib.SdnError('precision must be None, "fp32" or "bf16x3"')
+        if precision is not None:
+            dtype = torch.float32
+        if dtype not in (torch.bfloat16, torch.float16, torch.float32):
+            raise _lib.SdnError("storage dtype must be torch.bfloat16, torch.float16 or torch.float32")
         self.dtype = dtype
+        self.precision = precision or ("fp32" if dtype == torch.float32 else None)
         self.latent_repeat = 1
         cfg = dict(SD14_CLIP_CONFIG)
         cfg.update(config)
@@ -40,7 +50,7 @@ class CLIPTextModel(UNet2DConditionModel):
         c = _lib.ClipConfig(vocab_size=cfg["vocab_size"], hidden_size=cfg["hidden_size"],
                             intermediate_size=cfg["intermediate_size"], num_layers=cfg["num_hidden_layers"],
                             num_heads=cfg["num_attention_heads"], max_position_embeddings=cfg["max_position_embeddings"],
-                            dtype=0 if dtype == torch.bfloat16 else 1)
+                            dtype=3 if self.precision == "bf16x3" else {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}[dtype])
         h = C.c_void_p()
         _lib.check(_lib.lib().sdn_clip_create(C.byref(c), C.byref(h)), "sdn_clip_create")
         self._h = h

@@ -281,10 +281,12 @@ k_layernorm_f32(const float* __restrict__ x, long rows, int c, float eps, const 
 // O^T[dim][query] += V^T . P^T takes register s of the score accumulator directly as the B operand of its k-step s
 // (k-step s, lane group g  <->  key 4g + s on both operands).  Exponentials are expf(x - max): the reference's softmax.
 // ================================================================================================
-template <int HD>
+// MASK (CLIP text encoder, sdn_masked_attention_f32): causal key <= query and an optional per-sample key-padding mask [B, nk].
+template <int HD, bool MASK = false>
 __global__ void __launch_bounds__(256)
 k_attention_f32(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, float* __restrict__ out,
-                int heads, int nq, int nk, int ldq, int ldk, int ldv, int ldo, float scale) {
+                int heads, int nq, int nk, int ldq, int ldk, int ldv, int ldo, float scale, int causal = 0,
+                const int* __restrict__ kmask = nullptr) {
   constexpr int DB = (HD + 15) / 16, DP = DB * 16;                          // head dim padded to whole 16-column blocks
   constexpr int KS = HD / 4;                                               // k-steps of the score product (HD % 4 == 0)
   constexpr int LDK = ((HD + 29) / 32) * 32 + 2;                            // rows 2 banks apart mod 32: conflict-free reads
@@ -328,16 +330,23 @@ k_attention_f32(const float* __restrict__ q, const float* __restrict__ k, const 
     float tmax = -INFINITY;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      if (k0 + 4 * fq + e >= nk) st[e] = -INFINITY;
+      const int key = k0 + 4 * fq + e;
+      int visible = key < nk ? 1 : 0;
+      if (MASK) {                                                          // branch-free: one clamped load + integer logic
+        const int mk = kmask ? kmask[(long)b * nk + (key < nk ? key : nk - 1)] : 1;
+        visible &= (mk != 0) & ((causal == 0) | (key <= qi));
+      }
+      st[e] = visible ? st[e] : -INFINITY;
       tmax = fmaxf(tmax, st[e]);
     }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
     const float mnew = fmaxf(mrun, tmax);
-    const float alpha = expf(mrun - mnew);                                  // first tile: exp(-inf) = 0
+    const float mref = (MASK && mnew == -INFINITY) ? 0.f : mnew;            // nothing visible yet: every p below is exp(-inf) = 0
+    const float alpha = expf(mrun - mref);                                  // first tile: exp(-inf) = 0
     float psum = 0.f;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { st[e] = expf(st[e] - mnew); psum += st[e]; }
+    for (int e = 0; e < 4; ++e) { st[e] = expf(st[e] - mref); psum += st[e]; }
     psum += __shfl_xor(psum, 16, 64);
     psum += __shfl_xor(psum, 32, 64);
     lrun = lrun * alpha + psum;
@@ -361,6 +370,21 @@ k_attention_f32(const float* __restrict__ q, const float* __restrict__ k, const 
       const int dim = d * 16 + 4 * fq + e;
       if (dim < HD) op[dim] = o[d][e] * inv;
     }
+}
+
+// CLIPTextEmbeddings in f32: out[b, t, :] = token_embedding[ids[b, t]] + position_embedding[t]
+__global__ void __launch_bounds__(256)
+k_clip_embed_f32(const int* __restrict__ ids, const float* __restrict__ tok, const float* __restrict__ pos, long rows, int n, int C,
+                 int vocab, float* __restrict__ out) {
+  const int c4 = C / 4;
+  const long total = rows * c4;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long r = e / c4; const int c = (int)(e - r * c4) * 4;
+    int id = ids[r]; id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);       // out-of-range ids are clamped, not faulted on
+    const f32x4 a = *reinterpret_cast<const f32x4*>(tok + (long)id * C + c);
+    const f32x4 p = *reinterpret_cast<const f32x4*>(pos + (long)(r % n) * C + c);
+    *reinterpret_cast<f32x4*>(out + r * C + c) = a + p;
+  }
 }
 
 // conv_in: 3x3, pad 1, fp32 NCHW latent -> NHWC f32; one thread per (pixel, output channel).  w is [Cout][ky][kx][Cin].
@@ -920,4 +944,36 @@ int sdn_temb_f32(float timestep, const float* t_dev, int batch, int dim, void* o
 
 extern "C" int sdn_timestep_embed_f32(float timestep, int32_t batch, int32_t dim, void* out, void* stream) {
   return sdn_temb_f32(timestep, nullptr, batch, dim, out, stream);
+}
+
+// CLIP text encoder in the fp32-storage modes (dtype 2 / 3 of sdn_clip_config): the causal (+ key padding) attention of its 12
+// heads of 64 runs on the f32-input matrix cores in BOTH modes -- it is 1.7 % of the encoder's FLOPs (77 keys), and exact f32
+// products keep the softmax's inputs at the reference's precision.
+extern "C" int sdn_masked_attention_f32(const void* q, const void* k, const void* v, void* out, const int32_t* key_mask,
+                                        int32_t causal, int32_t batch, int32_t heads, int32_t n, int32_t head_dim, int32_t ldq,
+                                        int32_t ldk, int32_t ldv, int32_t ldo, float scale, void* stream) {
+  if (!q || !k || !v || !out || batch < 0 || heads <= 0 || n <= 0 || head_dim != 64 || (!causal && !key_mask) || ldq < heads * 64 ||
+      ldk < heads * 64 || ldv < heads * 64 || ldo < heads * 64 || ((ldk | ldv) & 3) ||
+      ((reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v)) & 15))
+    return SDN_E_INVALID;
+  if (batch == 0) return SDN_OK;
+  const long blocks = (long)batch * heads * ((n + 63) / 64);
+  if (blocks > 0x7fffffffL) return SDN_E_INVALID;
+  hipLaunchKernelGGL((k_attention_f32<64, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float*)q,
+                     (const float*)k, (const float*)v, (float*)out, heads, n, n, ldq, ldk, ldv, ldo, scale, causal ? 1 : 0, key_mask);
+  return sdn_launch_status();
+}
+
+extern "C" int sdn_clip_embed_f32(const int32_t* input_ids, const void* token_embedding, const void* position_embedding, int64_t rows,
+                                  int32_t seq_len, int32_t hidden, int32_t vocab, void* out, void* stream) {
+  if (!input_ids || !token_embedding || !position_embedding || !out || rows < 0 || seq_len <= 0 || hidden <= 0 || (hidden & 3) ||
+      vocab <= 0 || ((reinterpret_cast<uintptr_t>(token_embedding) | reinterpret_cast<uintptr_t>(position_embedding) |
+                      reinterpret_cast<uintptr_t>(out)) & 15))
+    return SDN_E_INVALID;
+  if (rows == 0) return SDN_OK;
+  long g = (rows * (hidden / 4) + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(k_clip_embed_f32, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, input_ids, (const float*)token_embedding,
+                     (const float*)position_embedding, (long)rows, seq_len, hidden, vocab, (float*)out);
+  return sdn_launch_status();
 }

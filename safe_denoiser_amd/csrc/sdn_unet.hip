@@ -1145,7 +1145,7 @@ struct Builder {
       Act qkv = act(rows, 3 * C, n, 0);
       gemm(rows, 3 * C, C, R(ln), qkvw, qkvb, R(qkv));
       Act at = act(rows, C, n, 0);
-      { Op o; o.kind = OP_MATTN; o.a = R(qkv); o.k = Ref{SP_WS, qkv.off + (int64_t)C * 2}; o.v = Ref{SP_WS, qkv.off + (int64_t)2 * C * 2};
+      { Op o; o.kind = OP_MATTN; o.a = R(qkv); o.k = Ref{SP_WS, qkv.off + (int64_t)C * es}; o.v = Ref{SP_WS, qkv.off + (int64_t)2 * C * es};
         o.out = R(at); o.batch = B; o.heads = H; o.nq = n; o.nk = n; o.hd = C / H; o.ldq = o.ldk = o.ldv = 3 * C; o.ldo = C;
         o.scale = 1.0f / sqrtf((float)o.hd);
         o.flops = 4.0 * B * H * (double)n * n * o.hd; o.bytes = 2.0 * 4.0 * rows * C;
@@ -1177,7 +1177,7 @@ Plan* get_plan(sdn_unet* u, int batch) {
   p.batch = batch;
   Builder b{u, &p};
   b.B = batch;
-  b.es = (!u->is_clip && !u->is_vae && !u->is_mmdit && u->cfg.dtype >= 2) ? 4 : 2;
+  b.es = (!u->is_vae && !u->is_mmdit && u->cfg.dtype >= 2) ? 4 : 2;       // fp32 storage: SD-v1.4 UNet and CLIP text encoder plans
   if (u->is_clip) b.build_clip(); else if (u->is_vae_encoder) b.build_vae_encoder(); else if (u->is_vae) b.build_vae(); else if (u->is_mmdit) b.build_mmdit(); else b.build();
   return &p;
 }
@@ -1286,11 +1286,12 @@ int sdn_clip_create(const sdn_clip_config* cfg, sdn_unet** out) {
   if (cfg->vocab_size <= 0 || cfg->hidden_size <= 0 || cfg->hidden_size % 128 != 0 || cfg->hidden_size > 1024 ||
       cfg->intermediate_size <= 0 || cfg->intermediate_size % 128 != 0 || cfg->num_layers <= 0 || cfg->num_heads <= 0 ||
       cfg->hidden_size != 64 * cfg->num_heads || cfg->max_position_embeddings <= 0 || cfg->max_position_embeddings > 4096 ||
-      cfg->dtype < 0 || cfg->dtype > 1)
+      cfg->dtype < 0 || cfg->dtype > 3)
     return SDN_E_INVALID;
   sdn_unet* u = new sdn_unet();
   memset(&u->cfg, 0, sizeof(u->cfg));
   u->cfg.dtype = cfg->dtype;
+  if (cfg->dtype >= 2) { u->gn_fuse = false; u->ln_fold = false; u->ff_fuse = false; }   // fp32-storage modes: the plain operator chain
   u->ccfg = *cfg;
   u->is_clip = true;
   get_plan(u, 1);
@@ -1461,6 +1462,13 @@ static int launch_ops(sdn_unet* u, Plan* p, const char* W, const char* WS, const
           break;
         case OP_REPEAT:
           rc = sdn_repeat(P(o.a), (size_t)o.rows, o.c1, (void*)P(o.out), stream);
+          break;
+        case OP_CLIP_EMBED:
+          rc = sdn_clip_embed_f32((const int32_t*)P(o.a), P(o.w), P(o.bias), o.rows, o.hw, o.c1, o.c2, (void*)P(o.out), stream);
+          break;
+        case OP_MATTN:                               // 1.7 % of the encoder's FLOPs: exact f32 products in both fp32-storage modes
+          rc = sdn_masked_attention_f32(P(o.a), P(o.k), P(o.v), (void*)P(o.out), (const int32_t*)u->clip_mask, 1, o.batch, o.heads,
+                                        o.nq, o.hd, o.ldq, o.ldk, o.ldv, o.ldo, o.scale, stream);
           break;
         default:
           rc = SDN_E_INVALID;
@@ -1640,7 +1648,7 @@ static void drop_graphs(sdn_unet* u) {
 
 void sdn_unet_set_split_k(sdn_unet* u, int32_t on) {
   if (!u || u->split_k == (on != 0)) return;
-  if (!u->is_mmdit && !u->is_vae && !u->is_clip && u->cfg.dtype >= 2) return;   // fp32-storage modes have no split-K form
+  if (!u->is_mmdit && !u->is_vae && u->cfg.dtype >= 2) return;   // fp32-storage modes have no split-K form
   u->split_k = on != 0;
   drop_graphs(u);
   u->plans.clear();                                            // plans are rebuilt with / without partial buffers

@@ -110,7 +110,10 @@ class SafeDenoiserPipeline:
             vae = AutoencoderKL(dtype=dt16, **ck.vae_kwargs(ck.read_config(os.path.join(model_dir, "vae"))))
             vae.load_state_dict(ck.load_weights(os.path.join(model_dir, "vae"), weights_variant), device=device)
         if os.path.isdir(os.path.join(model_dir, "text_encoder")):
-            enc = CLIPTextModel(dtype=dt16, **ck.clip_kwargs(ck.read_config(os.path.join(model_dir, "text_encoder"))))
+            # the reference loads the text encoder in the pipeline's dtype (run_nudity.py:277: fp32): an fp32 / bf16x3 UNet gets the
+            # text encoder in the same precision mode -- its states feed every cross-attention and the SAFREE decisions
+            enc_kw = dict(dtype=dt16) if unet.precision is None else dict(precision=unet.precision)
+            enc = CLIPTextModel(**enc_kw, **ck.clip_kwargs(ck.read_config(os.path.join(model_dir, "text_encoder"))))
             enc.load_state_dict(ck.load_weights(os.path.join(model_dir, "text_encoder"), weights_variant), device=device)
         if tokenizer is None:
             tokenizer = ck.load_tokenizer(model_dir)
@@ -224,8 +227,9 @@ class SafeDenoiserPipeline:
             guidance_scale = guidance_scale.detach().flatten().tolist()
         if isinstance(guidance_scale, (list, tuple)):
             g_rows = [float(g_) for g_ in guidance_scale]
-            if len(set(g_rows)) == 1:
-                guidance_scale, g_rows = g_rows[0], None
+            if not g_rows:
+                raise _lib.SdnError("guidance_scale: empty list")
+            guidance_scale = g_rows[0]
         if (min(g_rows) if g_rows is not None else guidance_scale) <= 1.0:
             raise NotImplementedError("guidance_scale <= 1 (no CFG) is not on the reference's benchmarked path")
         dev = torch.device("cuda", torch.cuda.current_device())
@@ -241,7 +245,8 @@ class SafeDenoiserPipeline:
         if g_rows is not None:
             if len(g_rows) != P:
                 raise _lib.SdnError(f"guidance_scale: need one value per prompt ({P}), got {len(g_rows)}")
-            g_rows = torch.tensor(g_rows, dtype=torch.float32, device=dev)
+            # equal scales take the scalar kernel (same bits either way)
+            g_rows = None if len(set(g_rows)) == 1 else torch.tensor(g_rows, dtype=torch.float32, device=dev)
         if n_prompts is not None and E.shape[0] != (3 if sld else 2) * n_prompts:
             raise _lib.SdnError(f"{E.shape[0]} text rows for {n_prompts} prompts: expected {(3 if sld else 2) * n_prompts} "
                                 f"([uncond | text{' | safety concept' if sld else ''}])")
@@ -515,15 +520,15 @@ class SafeDenoiserPipeline:
             r = safree.prepare_batch(E, masked_list, negspace, attn_mask, alpha=sf["alpha"], svf=bool(sf["svf"]), up_t=sf["up_t"],
                                      category=sf["category"], concept_proj=P_c)
             resc_rows = list(r["rescaled_text_embeddings"][P:])
-            betas, adjusted, removed = r["beta"], r["beta_adjusted"], r["n_removed"]
+            betas, adjusted, removed, masks = r["beta"], r["beta_adjusted"], r["n_removed"], list(r["token_mask"])
         else:
-            resc_rows, betas, adjusted, removed = [], [], [], []
+            resc_rows, betas, adjusted, removed, masks = [], [], [], [], []
             for p_ in range(P):
                 pair = torch.stack([E[p_], E[P + p_]])
                 r = safree.prepare(pair, masked_list[p_], negspace, attn_mask[p_].to(dev), alpha=sf["alpha"], svf=bool(sf["svf"]),
                                    up_t=sf["up_t"], category=sf["category"], concept_proj=P_c)
                 resc_rows.append(r["rescaled_text_embeddings"][1])
-                betas.append(r["beta"]); adjusted.append(r["beta_adjusted"]); removed.append(r["n_removed"])
+                betas.append(r["beta"]); adjusted.append(r["beta_adjusted"]); removed.append(r["n_removed"]); masks.append(r["token_mask"])
         log = sf.get("logger")
         if log is not None:
             for p_ in range(P):
@@ -532,7 +537,7 @@ class SafeDenoiserPipeline:
                     log.log(f"beta : {betas[p_]}, adjusted_beta: {adjusted[p_]}")
         rescaled = torch.cat([E[:P], torch.stack(resc_rows)])
         return {"rescaled_text_embeddings": rescaled, "beta_adjusted": adjusted if sf["svf"] else None, "beta": betas,
-                "n_removed": removed, "negspace": negspace}
+                "n_removed": removed, "negspace": negspace, "token_mask": torch.stack(masks)}
 
     def decode_latents(self, latents: torch.Tensor, output_type: str = "np"):
         """Steps 8-10 of the reference's __call__ (...threshold_time.py:588-596)."""

@@ -50,6 +50,11 @@ def safree_projection(input_embeddings: torch.Tensor, p_emb: torch.Tensor, maske
     return torch.cat([uncond_e, merged.unsqueeze(0)]), int(n_t - keep.sum())
 
 
+def token_keep_mask(text_e: torch.Tensor, rescaled_e: torch.Tensor) -> torch.Tensor:
+    """[.., L] bool: True where the projection left the token's embedding as it was (the `mask` of safree_projection)."""
+    return (text_e == rescaled_e).all(dim=-1)
+
+
 def projection_and_orthogonal(input_embeddings, masked_proj, concept_proj):
     """(I - P_c) P_m applied to every token (:44-54)."""
     dim = masked_proj.shape[0]
@@ -69,7 +74,8 @@ def prepare(text_embeddings: torch.Tensor, masked_embs: torch.Tensor, negspace: 
     P_m = projection_matrix(masked_embs.T)
     rescaled, n_removed = safree_projection(text_embeddings, masked_embs, P_m, P_c, alpha=alpha,
                                             max_length=text_embeddings.shape[1])
-    out = {"rescaled_text_embeddings": rescaled, "n_removed": n_removed, "beta_adjusted": None, "beta": None}
+    out = {"rescaled_text_embeddings": rescaled, "n_removed": n_removed, "beta_adjusted": None, "beta": None,
+           "token_mask": token_keep_mask(text_embeddings[1], rescaled[1])}
     if svf:
         proj_ort = projection_and_orthogonal(text_embeddings, P_m, P_c)
         act = attention_mask.reshape(-1) == 1
@@ -90,7 +96,12 @@ def prepare_batch(text_embeddings: torch.Tensor, masked_embs: list, negspace: to
     test, the token-wise replacement, the cosine statistic -- with the prompts' masked-embedding matrices zero-padded to a common
     token count (zero rows change neither the Gram matrix's range nor its pseudo-inverse on it), so that the 64 small SVDs,
     projector products and reductions of a batch are one batched call each instead of ~15 launches and two host syncs per
-    prompt.  Returns the per-prompt lists `prepare` would give, stacked."""
+    prompt.  The masked-prompt Gram matrices are near-singular (the rows are one prompt with one token changed), and the
+    reference's rcond of 1e-15 inverts whatever singular values rounding left there; a BATCHED fp32 SVD on padded matrices
+    rounds differently from the per-prompt one, which can move a trigger-token test or f_beta's round across its edge
+    (ADVICE r3).  So the Gram matrix, its pseudo-inverse and the projector P_m are formed in float64 here (P x n x n, n <= 75:
+    microseconds) -- the exact projector the reference's fp32 chain approximates -- and cast to the working dtype once.
+    Returns the per-prompt lists `prepare` would give, stacked."""
     P = len(masked_embs)
     dev, dt = text_embeddings.device, text_embeddings.dtype
     dim, L = text_embeddings.shape[-1], text_embeddings.shape[1]
@@ -103,8 +114,9 @@ def prepare_batch(text_embeddings: torch.Tensor, masked_embs: list, negspace: to
     for p_, m in enumerate(masked_embs):
         Mp[p_, :counts[p_]] = m
         valid[p_, :counts[p_]] = True
-    G = Mp @ Mp.transpose(1, 2)                                              # [P, n, n] = E^T E of each prompt (zero-padded)
-    P_m = Mp.transpose(1, 2) @ torch.linalg.pinv(G, rtol=1e-15) @ Mp         # [P, dim, dim]; torch.pinverse's own cut-off (rcond 1e-15)
+    Md = Mp.double()
+    G = Md @ Md.transpose(1, 2)                                              # [P, n, n] = E^T E of each prompt (zero-padded), float64
+    P_m = (Md.transpose(1, 2) @ torch.linalg.pinv(G, rtol=1e-15, hermitian=True) @ Md).to(dt)   # [P, dim, dim]; torch.pinverse's cut-off (rcond 1e-15)
     text_e = text_embeddings[P:]                                             # [P, L, dim]
     # distance of each masked prompt to the concept space, leave-one-out mean test (safree_projection)
     dist = torch.linalg.vector_norm(Mp @ eye_m_c.T, dim=-1)                  # [P, n]   (= ||(I - P_c) p_emb^T|| per column)
@@ -119,7 +131,7 @@ def prepare_batch(text_embeddings: torch.Tensor, masked_embs: list, negspace: to
     merged = torch.where(mask[:, :, None], text_e, projected)
     n_removed = (valid & ~keep).sum(dim=1)
     out = {"rescaled_text_embeddings": torch.cat([text_embeddings[:P], merged]), "n_removed": n_removed.tolist(),
-           "beta": [None] * P, "beta_adjusted": [None] * P}
+           "beta": [None] * P, "beta_adjusted": [None] * P, "token_mask": mask}
     if svf:
         act = (attention_masks.to(dev) == 1).to(dt)                          # [P, L]
         cos = torch.nn.functional.cosine_similarity(projected, text_e, dim=-1)

@@ -1,0 +1,181 @@
+"""Token ids -> final latents, END TO END, against the pure-fp32 chain the reference runs.
+
+The reference loads the WHOLE pipeline in fp32 (run_nudity.py:277 -> load_sd(..., torch.float32)): text encoder
+(...threshold_time.py:231-349), SAFREE projection + self-validation filter (:458-486), 50 DDPM steps of the UNet on three
+guidance branches with per-prompt text switching + repellency + re-noise (:511-582).  Earlier rounds demonstrated the north
+star's tolerance (final latents <= 1e-3 rel) only from `prompt_embeddings` in; here the SAME token ids go through
+    oracle CLIP (fp32, pinned to transformers) -> oracle SAFREE (float64 numpy, pinned to the reference's helpers)
+        -> oracle.pipeline.denoise_one(lra=True, text_safe=..., use_safe_fn=i <= beta_adjusted)   [one prompt at a time]
+and through the product's call `pipe(prompts, negative_prompt=, negative_prompt_space=, safree_dict=, repellency_processor=)`
+[all prompts in one batch] in every precision mode, full SD-v1.4 size (859.5 M-parameter UNet, 123 M-parameter text encoder,
+synthetic weights), same per-prompt noise tapes.  Per prompt the test reports the DISCRETE decisions -- the trigger-token mask
+and f_beta's step count, where a 16-bit text encoder can diverge categorically rather than by rounding -- and, for the
+prompts whose decisions agree, the final-latents distance.  Acceptance: in the fp32-storage modes (fp32 plan, bf16x3) every
+prompt's decisions agree and its latents are within 1e-3; the 16-bit modes are recorded (decision-agreement rate + distance)
+and bounded at measured + 25 %.  The record lands in gpurun_out/round4_e2e_ids.json (copied to profiles/)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pipeline as opipe
+from oracle import repellency as orp
+from oracle import safree as osf
+from oracle import schedulers as osch
+from oracle.clip import OracleCLIPText
+from oracle.unet import OracleUNet
+from safe_denoiser_amd.clip import CLIPTextModel
+from safe_denoiser_amd.pipeline import SafeDenoiserPipeline
+from safe_denoiser_amd.repellency import repellency_methods_threshold as thr
+from safe_denoiser_amd.schedulers import DDPMScheduler
+from safe_denoiser_amd.unet import UNet2DConditionModel
+from tests.test_gpu_pipeline import Tapes, rel_l2
+from tests.test_gpu_safree_call import NEG_SPACE
+from tests_support.fake_tokenizer import FakeCLIPTokenizer
+
+pytestmark = pytest.mark.gpu
+
+PROMPTS = ["a painting of a woman standing near the sea , lustful mood",
+           "portrait photo of an old fisherman , dramatic light , 85mm",
+           "two cats asleep on a red sofa",
+           "seductive pose , erotic art , oil on canvas , museum lighting , highly detailed",
+           "an empty street at night after the rain , neon signs reflected in puddles , cinematic still",
+           "nude figure study in charcoal",
+           "a bowl of fruit on a wooden table next to a window , morning light , still life by an old master",
+           "kinky latex outfit fashion editorial , studio flash"]
+STEPS = 50
+SF = dict(safree=True, svf=True, lra=True, alpha=0.01, up_t=10, category="nudity", re_attn_t=[-1, 1001], logger=None)
+PARAMS = dict(sigma=3.15, scale=0.33, beta_threshold=1e-6, beta_threshold_margin=1e9)       # the gate fires at every window step
+MODES = {"fp32": dict(precision="fp32"), "bf16x3": dict(precision="bf16x3"), "fp16": dict(dtype=torch.float16),
+         "bf16": dict(dtype=torch.bfloat16)}
+# 16-bit modes: distance of the agreeing prompts, measured on MI355X (round 4) + 25 %
+BOUND_16 = {"fp16": 5.8e-3, "bf16": 3.7e-2}      # measured 4.65e-3 / 2.94e-2 (profiles/round4_e2e_ids.json)
+
+
+class DevTapes:
+    """The same per-prompt tape served on a device (the oracle evaluated by torch on the GPU)."""
+
+    def __init__(self, tapes, dev):
+        self.t, self.dev = tapes, dev
+
+    def __call__(self, p, shape):
+        return self.t(p, shape).to(self.dev)
+
+
+def _oracle_chain(csd, usd, tok, refs, shape):
+    """fp32 truth, prompt by prompt, as the reference would run it (torch ops; the two networks evaluated on the GPU with TF32 off)."""
+    torch.backends.cuda.matmul.allow_tf32 = False
+    torch.backends.cudnn.allow_tf32 = False
+    P = len(PROMPTS)
+    neg_prompt = ", ".join(NEG_SPACE)
+    oenc = OracleCLIPText(csd, None, act_dtype=None, device="cuda")
+    t = tok(PROMPTS, padding="max_length", max_length=77, truncation=True)
+    ids, am = t.input_ids, t.attention_mask
+    nids = tok([neg_prompt] * P, padding="max_length", max_length=77, truncation=True).input_ids
+    E = torch.cat([oenc(nids), oenc(ids)]).double().cpu().numpy()                   # [2P,77,768]: uncond | text
+    sp = tok(NEG_SPACE, padding="max_length", max_length=77, truncation=True)
+    negspace = oenc(sp.input_ids, sp.attention_mask)[torch.arange(len(NEG_SPACE)), sp.input_ids.argmax(-1)].double().cpu().numpy()
+    preps = []
+    for p, prompt in enumerate(PROMPTS):
+        row = tok([prompt], padding="longest").input_ids
+        n_real = row.shape[1] - 2
+        rows = row.repeat(n_real, 1)
+        for i in range(n_real):
+            rows[i, i + 1] = 0                                                       # _masked_encode_prompt (:211-229)
+        padded = torch.full((n_real, 77), tok.eos_token_id, dtype=rows.dtype)
+        padded[:, :rows.shape[1]] = rows
+        masked = oenc(padded)[torch.arange(n_real), padded.argmax(-1)].double().cpu().numpy()
+        preps.append(osf.prepare(np.stack([E[p], E[P + p]]), masked, negspace, am[p].numpy(), alpha=SF["alpha"], up_t=SF["up_t"],
+                                 category=SF["category"]))
+    del oenc
+    unet = OracleUNet(usd, None, act_dtype=None, device="cuda")
+    tapes = Tapes(P, shape, 3 * STEPS + 4, seed=77)
+    lat, draws = [], []
+    for p in range(P):
+        pair = torch.from_numpy(np.stack([E[p], E[P + p]])).float().cuda()
+        safe = torch.from_numpy(preps[p]["rescaled"]).float().cuda()
+        ba = preps[p]["beta_adjusted"]
+        o, st = opipe.denoise_one(unet, osch.DDPM(), pair, p, DevTapes(tapes, "cuda"), num_inference_steps=STEPS,
+                                  repel=dict(flavour="threshold", proj_refs=refs.cuda(), **PARAMS), lra=True, text_safe=safe,
+                                  use_safe_fn=lambda i, ba=ba: i <= ba)
+        lat.append(o.cpu()); draws.append(st["renoise_draws"])
+    del unet
+    torch.cuda.empty_cache()
+    return preps, torch.cat(lat), draws, tapes.cur
+
+
+def test_token_ids_to_latents_against_the_fp32_chain_in_every_precision_mode(tmp_path):
+    P = len(PROMPTS)
+    usd = UNet2DConditionModel(text_len=77).synthetic_state_dict(1234)
+    csd = CLIPTextModel().synthetic_state_dict(31)
+    tok = FakeCLIPTokenizer()
+    g = torch.Generator().manual_seed(9)
+    refs = orp.channel_normalise(torch.randn(64, 4, 64, 64, generator=g))
+    shape = (1, 4, 64, 64)
+    preps, lat_o, draws_o, cur_o = _oracle_chain(csd, usd, tok, refs, shape)
+    print("oracle chain: removed tokens", [q["n_removed"] for q in preps], "beta_adjusted", [q["beta_adjusted"] for q in preps],
+          "smallest relative trigger-test margin", ["%.1e" % q["margin"] for q in preps])
+    path = str(tmp_path / "pr.pt")
+    torch.save(refs, path)
+    res = {}
+    for name, kw in MODES.items():
+        u = UNet2DConditionModel(text_len=77, latent_repeat=3, **kw)
+        u.load_state_dict(usd)
+        enc = CLIPTextModel(**kw)
+        enc.load_state_dict(csd)
+        proc = thr.get_repellency_method("kernel_fast", torch.zeros(1, device="cuda"), None, None, 50, 1000, 0.00085, 0.012, n_embed=4,
+                                         proj_ref_path=path, cache_proj_ref=True, **PARAMS)
+        per_mode = {}
+        for batched in (True, False):
+            pipe = SafeDenoiserPipeline(u, DDPMScheduler(), variant="threshold_time", text_encoder=enc, tokenizer=tok)
+            pipe.batched_safree = batched
+            tapes = Tapes(P, shape, 3 * STEPS + 4, seed=77)
+            if batched:
+                lat = pipe(PROMPTS, num_inference_steps=STEPS, guidance_scale=7.5, negative_prompt=", ".join(NEG_SPACE),
+                           negative_prompt_space=NEG_SPACE, repellency_processor=proc, safree_dict=SF, noise_fn=tapes, return_latents=True)
+                prep = pipe.last_safree
+            else:                                                   # the per-prompt SAFREE path: decisions only (the loop is the same)
+                E, _ids, am = pipe._new_encode_prompt(PROMPTS, ", ".join(NEG_SPACE))
+                prep = pipe._safree_prepare(PROMPTS, E, am, NEG_SPACE, SF)
+            mask_ok = [bool(np.array_equal(prep["token_mask"][p].cpu().numpy(), preps[p]["mask"])) for p in range(P)]
+            beta_ok = [prep["beta_adjusted"][p] == preps[p]["beta_adjusted"] for p in range(P)]
+            rec = {"mask_equal": mask_ok, "beta_adjusted_equal": beta_ok, "beta_adjusted": list(prep["beta_adjusted"]),
+                   "n_removed": list(prep["n_removed"]),
+                   "beta_abs_err": [abs(prep["beta"][p] - preps[p]["beta"]) for p in range(P)]}
+            if batched:
+                rec["latents_rel_l2"] = [rel_l2(lat[p:p + 1], lat_o[p:p + 1]) for p in range(P)]
+                rec["renoise_draws_equal"] = pipe.last_stats["renoise_draws"] == sum(draws_o) and tapes.cur == cur_o
+            per_mode["batched_safree" if batched else "per_prompt_safree"] = rec
+        r = per_mode["batched_safree"]
+        agree = [m and b for m, b in zip(r["mask_equal"], r["beta_adjusted_equal"])]
+        r["decisions_agree"] = agree
+        r["decision_agreement_rate"] = sum(agree) / P
+        per_mode["per_prompt_safree"]["decision_agreement_rate"] = sum(m and b for m, b in zip(
+            per_mode["per_prompt_safree"]["mask_equal"], per_mode["per_prompt_safree"]["beta_adjusted_equal"])) / P
+        res[name] = per_mode
+        ok = [e for e, a in zip(r["latents_rel_l2"], agree) if a]
+        print(f"ids -> latents, {name:6s}: decisions agree on {sum(agree)}/{P} prompts (per-prompt SAFREE path: "
+              f"{per_mode['per_prompt_safree']['decision_agreement_rate'] * P:.0f}/{P}); latents rel L2 of the agreeing prompts "
+              f"max {max(ok) if ok else float('nan'):.2e}; all prompts {['%.1e' % e for e in r['latents_rel_l2']]}")
+        del u, enc, pipe
+        torch.cuda.empty_cache()
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    json.dump({"what": "token ids -> final latents, full SD-v1.4 + full CLIP text encoder (synthetic weights), README-default call "
+                       "(safree + svf + lra, 3 branches, 50 DDPM steps, repellency gate firing at all 11 window steps), 8 prompts in one "
+                       "batch vs the pure-fp32 oracle chain run prompt by prompt on the same tapes",
+               "source": "tests/test_gpu_e2e_ids.py", "north_star_bound": 1e-3, "prompts": PROMPTS,
+               "oracle": {"n_removed": [q["n_removed"] for q in preps], "beta_adjusted": [q["beta_adjusted"] for q in preps],
+                          "beta": [q["beta"] for q in preps], "min_relative_trigger_margin": [q["margin"] for q in preps]},
+               "modes": res}, open(os.path.join(out_dir, "round4_e2e_ids.json"), "w"), indent=1)
+    for name in ("fp32", "bf16x3"):
+        r = res[name]["batched_safree"]
+        assert all(r["decisions_agree"]), (name, r)
+        assert all(res[name]["per_prompt_safree"]["mask_equal"]) and all(res[name]["per_prompt_safree"]["beta_adjusted_equal"]), name
+        assert r["renoise_draws_equal"] and max(r["latents_rel_l2"]) <= 1e-3, (name, r["latents_rel_l2"])
+    for name in ("fp16", "bf16"):
+        r = res[name]["batched_safree"]
+        ok = [e for e, a in zip(r["latents_rel_l2"], r["decisions_agree"]) if a]
+        assert not ok or max(ok) <= BOUND_16[name], (name, ok)

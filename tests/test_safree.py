@@ -95,3 +95,31 @@ def test_sd3_mask_to_onp_matches_reference_goldens():
         np.testing.assert_array_equal(out["inv_vector"].numpy(), z[f"{name}/inv"])
         np.testing.assert_allclose(out["rescaled_text_embeddings"].float().numpy(), z[f"{name}/rescaled"], atol=2e-2, rtol=2e-2)
         assert out["rescaled_text_embeddings"].shape == (2, 333, ie.shape[-1])
+
+
+def test_oracle_prepare_and_f_beta_are_pinned_to_the_reference_goldens():
+    """oracle.safree.prepare / f_beta (the float64 truth of tests/test_gpu_e2e_ids.py) against the reference's own helpers: the
+    f_beta grid exactly; rescaled embeddings, removed-token count and the projected text to the goldens' precision; the product's
+    per-prompt and batched paths report the same token mask."""
+    z, names = _gold()
+    rows = iter(z["f_beta/out"])
+    for btype in ("sigmoid", "tanh"):
+        for concept in ("nudity", "artists-VanGogh"):
+            for up_t in (10, 20):
+                want = next(rows)
+                assert [osf.f_beta(float(v), btype=btype, upperbound_timestep=up_t, concept_type=concept) for v in z["f_beta/z"]] == list(want)
+    for name in names:
+        ie, neg, p_emb = (z[f"{name}/{k}"] for k in ("ie", "neg", "p_emb"))
+        tol = 1e-9 if ie.dtype == np.float64 else 2e-3
+        am = np.zeros(77); am[:p_emb.shape[0] + 2] = 1
+        o = osf.prepare(ie, p_emb, neg, am, alpha=float(z[f"{name}/alpha"]))
+        assert o["n_removed"] == int(z[f"{name}/n_removed"]), name
+        np.testing.assert_allclose(o["rescaled"], z[f"{name}/rescaled"], atol=tol, rtol=tol)
+        assert o["mask"].sum() == 77 - o["n_removed"]
+        t = torch.from_numpy(ie).double()
+        pr = safree.prepare(t, torch.from_numpy(p_emb).double(), torch.from_numpy(neg).double(), torch.from_numpy(am), alpha=float(z[f"{name}/alpha"]))
+        assert np.array_equal(pr["token_mask"].numpy(), o["mask"]) and pr["beta_adjusted"] == o["beta_adjusted"]
+        assert abs(pr["beta"] - o["beta"]) <= 1e-9
+        pb = safree.prepare_batch(torch.cat([t[:1], t[:1], t[1:], t[1:]]), [torch.from_numpy(p_emb).double()] * 2, torch.from_numpy(neg).double(),
+                                  torch.from_numpy(np.stack([am, am])), alpha=float(z[f"{name}/alpha"]))
+        assert np.array_equal(pb["token_mask"][1].numpy(), o["mask"]) and pb["beta_adjusted"] == [o["beta_adjusted"]] * 2
