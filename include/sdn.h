@@ -208,6 +208,9 @@ typedef struct sdn_gemm_desc {
   int32_t asym_pad;         /* CONV3X3, stride 2 only: 1 = zero padding (0,1,0,1) (right/bottom only: the VAE encoder's
                                Downsample2D(padding=0) + F.pad) instead of 1 on every side             */
   int32_t split_k;          /* number of k-loop slices for sdn_gemm_splitk_* (0 / 1 = none); plain sdn_gemm_* rejects > 1 */
+  int32_t x3_out;           /* sdn_gemm_bf16 inside the bf16x3 plan (see "bf16x3 by operand expansion" below): 0 = off;
+                               1 = out is F32 [M, ldc]; 2 = GEGLU, out is a bf16 triple [M, 3 ldc]; 3 = out is a bf16 triple.
+                               With any of them `residual` is F32 [M, ldc] and out_kind is ignored                        */
 } sdn_gemm_desc;
 
 /* out = act((A.W^T + bias[n] + rowbias[b(m), n]) * rowgate[b(m), n] + residual[m, n])   (rowgate NULL = 1).
@@ -327,6 +330,27 @@ int sdn_gemm_x3(const sdn_gemm_desc* d_host, const void* a, const void* a2, cons
 int sdn_attention_x3(const void* q, const void* k, const void* v, void* out, int32_t batch, int32_t heads,
                      int32_t nq, int32_t nk, int32_t head_dim, int32_t ldq, int32_t ldk, int32_t ldv,
                      int32_t ldo, float scale, void* stream);
+
+/* ---- bf16x3 by operand expansion (round 4): the same three-term products as sdn_gemm_x3, on the LDS-DMA tiles of sdn_gemm_bf16.
+ * A tensor x [rows, C] that a GEMM will read is kept as the bf16 TRIPLE [rows, 3C] = [hi(C) | lo(C) | hi(C)], hi = bf16(x),
+ * lo = bf16(x - hi) (x = hi + lo to 2^-17); its weight W [N, K] as [N, 3K] with every K-group g (K itself, or the Cin of one
+ * conv tap) expanded to [hi(g) | hi(g) | lo(g)].  Then  A' . W'^T = a_hi w_hi + a_lo w_hi + a_hi w_lo  is ONE bf16 GEMM with three
+ * times the k loop -- both operands arrive by LDS-DMA, no staging registers, no split arithmetic inside the loop (sdn_gemm_x3
+ * splits f32 operands on the fly and is bound by moving them through registers into LDS: DESIGN.md).  sdn_gemm_bf16 with
+ * sdn_gemm_desc.x3_out != 0 (K, Cin = the EXPANDED sizes) adds an F32 residual and writes F32 rows or the next GEMM's triple.
+ *   sdn_split3: f32 [rows, c1] (++ f32 [rows, c2]) -> triple [rows, 3 (c1 + c2)]  (raw residual-stream tensors, text states)
+ *   sdn_expand3_weights: f32 W [rows, cols] -> bf16 [rows, 3 cols], group = cols, or the Cin of a [O][ky][kx][Cin] conv weight
+ *   sdn_groupnorm_f32 / sdn_layernorm_f32 / sdn_attention_x3 with `triple_out` write their result in that form directly. */
+int sdn_split3(const float* x, const float* x2, int64_t rows, int32_t c1, int32_t c2, void* out_triple, void* stream);
+int sdn_expand3_weights(const float* w, int64_t rows, int32_t cols, int32_t group, void* out_bf16, void* stream);
+int sdn_groupnorm_f32_triple(const void* x, const void* x2, int32_t batch, int32_t hw, int32_t c1, int32_t c2, int32_t groups,
+                             float eps, int32_t silu, const float* gamma, const float* beta, void* out_triple, float* stats_ws,
+                             void* stream);
+int sdn_layernorm_f32_triple(const void* x, int64_t rows, int32_t c, float eps, const float* gamma, const float* beta,
+                             void* out_triple, void* stream);
+int sdn_attention_x3_triple(const void* q, const void* k, const void* v, void* out_triple, int32_t batch, int32_t heads, int32_t nq,
+                            int32_t nk, int32_t head_dim, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo, float scale,
+                            void* stream);
 
 /* ---- random draws (row S2): P per-prompt generators in one launch ------------------------------------------------
  * Replaces the per-prompt `torch.randn(latents_shape, generator=gen)` calls behind prepare_latents / scheduler.step /

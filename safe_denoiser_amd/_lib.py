@@ -35,7 +35,7 @@ class RepelParams(C.Structure):
 class GemmDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("M", "N", "K", "a_mode", "K1", "Hs", "Ws", "Cin", "Ho", "Wo", "stride",
                                          "upsample", "act", "out_kind", "rows_per_batch", "ld_rowbias", "ld_rowgate",
-                                         "residual_bcast", "n_valid", "ldc", "asym_pad", "split_k")]
+                                         "residual_bcast", "n_valid", "ldc", "asym_pad", "split_k", "x3_out")]
 
 
 class UnetConfig(C.Structure):
@@ -166,6 +166,11 @@ SIGNATURES = {
     "sdn_clip_embed": (C.c_int, [_i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "sdn_masked_attention": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                        _f32, _vp]),
+    "sdn_split3": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),
+    "sdn_expand3_weights": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
+    "sdn_groupnorm_f32_triple": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "sdn_layernorm_f32_triple": (C.c_int, [_vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp]),
+    "sdn_attention_x3_triple": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "sdn_clip_embed_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "sdn_masked_attention_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "sdn_unet_prepare": (C.c_int, [_vp, _vp, _vp]),

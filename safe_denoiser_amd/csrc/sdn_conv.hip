@@ -124,6 +124,16 @@ k_conv_slab(const GemmArgs g) {
       for (int i = 0; i < 4; ++i) acc[i][j] += rb;
     }
   }
+  if (g.x3_out && g.residual) {                              // bf16x3 plan: f32 residual [M, ldc], in the shadow of the first k-tile's DMA
+    const float* resf = reinterpret_cast<const float*>(g.residual);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wm * 64 + i * 16 + fr;
+      const float* rp = resf + (long)(m < g.M ? m : 0) * g.ldc + n0 + wn * 16 * NREP + fq * 4;
+#pragma unroll
+      for (int j = 0; j < NREP; ++j) acc[i][j] += *reinterpret_cast<const f32x4*>(rp + j * 16);
+    }
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -242,9 +252,9 @@ static int launch_slab(const GemmArgs& g, hipStream_t st) {
 // Launches the slab form when the convolution suits it; SDN_GEMM_NOT_SLAB = the caller keeps the implicit-GEMM kernel.
 int dispatch_conv_slab(int dtype, const GemmArgs& g, hipStream_t st) {
   if (g.a_mode != 1 || g.Hs != g.Ws || g.Ho != g.Hs || g.Wo != g.Ws ||
-      !sdn_conv_slab_shape_ok(g.M, g.N, g.Cin, g.Ws, g.stride, g.upsample, g.conv_off, g.out_kind, g.n_valid))
+      !sdn_conv_slab_shape_ok(g.M, g.N, g.Cin, g.Ws, g.stride, g.upsample, g.conv_off, g.x3_out ? SDN_OUT_BF16 : g.out_kind, g.n_valid))
     return SDN_GEMM_NOT_SLAB;
-  if (g.kt_per_split != 0 || g.rowgate || g.act != 0 || g.stamps || g.dbg || (g.residual && !g.res_lds) ||
+  if (g.kt_per_split != 0 || g.rowgate || g.act != 0 || g.stamps || g.dbg || (g.residual && !g.res_lds && !g.x3_out) ||
       (g.rowbias && g.rows_per_batch != g.Hs * g.Ws))
     return SDN_GEMM_NOT_SLAB;
   return dtype == 0 ? launch_slab<SdnBF16>(g, st) : launch_slab<SdnF16>(g, st);

@@ -29,6 +29,26 @@ __device__ __forceinline__ float gelu_tanh_f(float v) {
 }
 __device__ __forceinline__ float quick_gelu_f(float v) { return v / (1.f + expf(-1.702f * v)); }
 
+// bf16 hi | lo | hi TRIPLE form of an f32 tensor (include/sdn.h, "bf16x3 by operand expansion"): element (row, c) of a
+// [rows, C] tensor lives at out16[row * 3C + c] (hi), [.. + C] (lo), [.. + 2C] (hi again)
+__device__ __forceinline__ unsigned short bf16_rne(float v) {
+  __bf16 h = (__bf16)v;
+  return *reinterpret_cast<unsigned short*>(&h);
+}
+__device__ __forceinline__ void store_triple1(unsigned short* row3, int C, int c, float v) {
+  const unsigned short hi = bf16_rne(v);
+  const unsigned short lo = bf16_rne(v - __uint_as_float((unsigned)hi << 16));
+  row3[c] = hi; row3[C + c] = lo; row3[2 * C + c] = hi;
+}
+__device__ __forceinline__ void store_triple2(unsigned short* row3, int C, int c, float v0, float v1) {     // c even
+  const unsigned h0 = bf16_rne(v0), h1 = bf16_rne(v1);
+  const unsigned l0 = bf16_rne(v0 - __uint_as_float(h0 << 16)), l1 = bf16_rne(v1 - __uint_as_float(h1 << 16));
+  const unsigned hi = h0 | (h1 << 16), lo = l0 | (l1 << 16);
+  *reinterpret_cast<unsigned*>(row3 + c) = hi;
+  *reinterpret_cast<unsigned*>(row3 + C + c) = lo;
+  *reinterpret_cast<unsigned*>(row3 + 2 * C + c) = hi;
+}
+
 // ================================================================================================
 // GEMM / implicit conv:  C[M,N] = A[M,K] . W[N,K]^T, 64 x 64 tile, BK = 16, 4 waves (one per SIMD); wave w owns rows
 // 16w..16w+15 of the tile and all 64 columns = 4 accumulators of v_mfma_f32_16x16x4_f32 in the SWAPPED orientation
@@ -173,7 +193,7 @@ k_gemm_f32(const GemmArgsF g) {
 // ================================================================================================
 __global__ void __launch_bounds__(256)
 k_groupnorm_f32(const float* __restrict__ x, const float* __restrict__ x2, int hw, int c1, int c2, int groups, float eps,
-                int silu, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ out) {
+                int silu, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ out, int triple) {
   __shared__ double red[2][4];
   __shared__ float stat[2];
   const int C = c1 + c2, cpg = C / groups;
@@ -215,14 +235,15 @@ k_groupnorm_f32(const float* __restrict__ x, const float* __restrict__ x2, int h
     const float2 v = *reinterpret_cast<const float2*>(src + (long)p * ld);
     float o0 = (v.x - mean) * rstd * ga0 + be0, o1 = (v.y - mean) * rstd * ga1 + be1;      // centred first: |mean| >> std must not cancel
     if (silu) { o0 = silu_f(o0); o1 = silu_f(o1); }
-    *reinterpret_cast<float2*>(dst + (long)p * C) = make_float2(o0, o1);
+    if (triple) store_triple2(reinterpret_cast<unsigned short*>(out) + ((long)b * hw + p) * 3 * C, C, c, o0, o1);
+    else *reinterpret_cast<float2*>(dst + (long)p * C) = make_float2(o0, o1);
   }
 }
 
 // general form (odd channels per group, or an odd split of a concatenated input): one element per access
 __global__ void __launch_bounds__(256)
 k_groupnorm_f32_any(const float* __restrict__ x, const float* __restrict__ x2, int hw, int c1, int c2, int groups, float eps,
-                    int silu, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ out) {
+                    int silu, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ out, int triple) {
   __shared__ double red[2][4];
   __shared__ float stat[2];
   const int C = c1 + c2, cpg = C / groups;
@@ -252,7 +273,102 @@ k_groupnorm_f32_any(const float* __restrict__ x, const float* __restrict__ x2, i
     const int p = (int)(e / cpg), c = ch0 + (int)(e - (long)p * cpg);
     float v = (at(e) - mean) * rstd * gamma[c] + beta[c];
     if (silu) v = silu_f(v);
-    out[((long)b * hw + p) * C + c] = v;
+    if (triple) store_triple1(reinterpret_cast<unsigned short*>(out) + ((long)b * hw + p) * 3 * C, C, c, v);
+    else out[((long)b * hw + p) * C + c] = v;
+  }
+}
+
+// ---- GroupNorm, row-major form (round 4): whole 4C-byte rows are read (float4 per lane, coalesced) instead of one group's
+// 40 ... 320-byte slice per pixel.  A sample's [hw, C] matrix is cut into `nchunk` row chunks; pass 1 leaves one (sum, sum of
+// squares) pair per (sample, chunk, group) in DOUBLE (|mean| >> std must not cancel), reduced in a fixed order; pass 2 sums the
+// chunk partials (fixed order), normalises its chunk and writes f32 rows or the bf16 hi|lo|hi triple.  8 + 4 (or 6) bytes per
+// element instead of three strided passes.
+constexpr int GN_MAXC = 2560;
+__global__ void __launch_bounds__(256)
+k_gn_rows_stats(const float* __restrict__ x, const float* __restrict__ x2, int hw, int c1, int c2, int groups, int rows_per_chunk,
+                double* __restrict__ part) {
+  __shared__ double ls[GN_MAXC], lq[GN_MAXC];
+  const int C = c1 + c2, cq = C / 4, cpg = C / groups;
+  const int nchunk = (hw + rows_per_chunk - 1) / rows_per_chunk;
+  const int b = blockIdx.x / nchunk, ch = blockIdx.x - b * nchunk;
+  const int r0 = ch * rows_per_chunk, r1 = min(hw, r0 + rows_per_chunk);
+  // thread -> column quads qd, qd + 256, ... (all rows of the chunk): per-column sums stay in one thread, no cross-thread order
+  for (int qd = threadIdx.x; qd < cq; qd += 256) {
+    const int c = qd * 4;
+    const float* src = c < c1 ? x + ((long)b * hw) * c1 + c : x2 + ((long)b * hw) * c2 + (c - c1);
+    const int ld = c < c1 ? c1 : c2;
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+#pragma unroll 8
+    for (int r = r0; r < r1; ++r) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src + (long)r * ld);
+      const double a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
+      s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+      q0 = fma(a0, a0, q0); q1 = fma(a1, a1, q1); q2 = fma(a2, a2, q2); q3 = fma(a3, a3, q3);
+    }
+    ls[c] = s0; ls[c + 1] = s1; ls[c + 2] = s2; ls[c + 3] = s3;
+    lq[c] = q0; lq[c + 1] = q1; lq[c + 2] = q2; lq[c + 3] = q3;
+  }
+  __syncthreads();
+  if (threadIdx.x < groups) {
+    double s = 0, q = 0;
+    for (int c = threadIdx.x * cpg; c < (threadIdx.x + 1) * cpg; ++c) { s += ls[c]; q += lq[c]; }
+    double* o = part + (((long)b * nchunk + ch) * groups + threadIdx.x) * 2;
+    o[0] = s; o[1] = q;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_gn_rows_apply(const float* __restrict__ x, const float* __restrict__ x2, int hw, int c1, int c2, int groups, float eps, int silu,
+                const float* __restrict__ gamma, const float* __restrict__ beta, int rows_per_chunk, const double* __restrict__ part,
+                float* __restrict__ out, int triple) {
+  __shared__ float smean[64], srstd[64];
+  const int C = c1 + c2, cq = C / 4, cpg = C / groups;
+  const int nchunk = (hw + rows_per_chunk - 1) / rows_per_chunk;
+  const int b = blockIdx.x / nchunk, ch = blockIdx.x - b * nchunk;
+  if (threadIdx.x < groups) {
+    double s = 0, q = 0;
+    for (int k = 0; k < nchunk; ++k) {
+      const double* pp = part + (((long)b * nchunk + k) * groups + threadIdx.x) * 2;
+      s += pp[0]; q += pp[1];
+    }
+    const double n = (double)hw * cpg, mean = s / n;
+    double var = q / n - mean * mean;                                        // biased variance, as torch's group_norm
+    if (var < 0.0) var = 0.0;
+    smean[threadIdx.x] = (float)mean; srstd[threadIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const int r0 = ch * rows_per_chunk, r1 = min(hw, r0 + rows_per_chunk);
+  for (int qd = threadIdx.x; qd < cq; qd += 256) {
+    const int c = qd * 4;
+    const float* src = c < c1 ? x + ((long)b * hw) * c1 + c : x2 + ((long)b * hw) * c2 + (c - c1);
+    const int ld = c < c1 ? c1 : c2;
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c);
+    float mu[4], rs[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const int g = (c + e) / cpg; mu[e] = smean[g]; rs[e] = srstd[g]; }
+#pragma unroll 4
+    for (int r = r0; r < r1; ++r) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src + (long)r * ld);
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = (v[e] - mu[e]) * rs[e] * ga[e] + be[e];                       // centred first: |mean| >> std must not cancel
+        if (silu) o[e] = silu_f(o[e]);
+      }
+      const long row = (long)b * hw + r;
+      if (triple) {
+        unsigned short* row3 = reinterpret_cast<unsigned short*>(out) + row * 3 * C;
+        const unsigned h0 = bf16_rne(o[0]), h1 = bf16_rne(o[1]), h2 = bf16_rne(o[2]), h3 = bf16_rne(o[3]);
+        const unsigned l0 = bf16_rne(o[0] - __uint_as_float(h0 << 16)), l1 = bf16_rne(o[1] - __uint_as_float(h1 << 16));
+        const unsigned l2 = bf16_rne(o[2] - __uint_as_float(h2 << 16)), l3 = bf16_rne(o[3] - __uint_as_float(h3 << 16));
+        const uint2 hi = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16)), lo = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
+        *reinterpret_cast<uint2*>(row3 + c) = hi;
+        *reinterpret_cast<uint2*>(row3 + C + c) = lo;
+        *reinterpret_cast<uint2*>(row3 + 2 * C + c) = hi;
+      } else {
+        *reinterpret_cast<f32x4*>(out + row * C + c) = (f32x4){o[0], o[1], o[2], o[3]};
+      }
+    }
   }
 }
 
@@ -260,7 +376,7 @@ k_groupnorm_f32_any(const float* __restrict__ x, const float* __restrict__ x2, i
 // LayerNorm over the last axis: one wave per row, two passes over registers / L1 (mean, then centred sum of squares).
 __global__ void __launch_bounds__(256)
 k_layernorm_f32(const float* __restrict__ x, long rows, int c, float eps, const float* __restrict__ gamma,
-                const float* __restrict__ beta, float* __restrict__ out) {
+                const float* __restrict__ beta, float* __restrict__ out, int triple) {
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
@@ -271,6 +387,16 @@ k_layernorm_f32(const float* __restrict__ x, long rows, int c, float eps, const 
   float q = 0.f;
   for (int i = lane; i < c; i += 64) { const float d = xr[i] - mean; q = fmaf(d, d, q); }
   const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)c + eps);
+  if (triple) {
+    unsigned short* row3 = reinterpret_cast<unsigned short*>(out) + row * 3 * c;
+    if ((c & 1) == 0) {
+      for (int i = 2 * lane; i < c; i += 128)
+        store_triple2(row3, c, i, (xr[i] - mean) * rstd * gamma[i] + beta[i], (xr[i + 1] - mean) * rstd * gamma[i + 1] + beta[i + 1]);
+    } else {
+      for (int i = lane; i < c; i += 64) store_triple1(row3, c, i, (xr[i] - mean) * rstd * gamma[i] + beta[i]);
+    }
+    return;
+  }
   for (int i = lane; i < c; i += 64) out[row * c + i] = (xr[i] - mean) * rstd * gamma[i] + beta[i];
 }
 
@@ -622,7 +748,7 @@ k_gemm_x3(const GemmArgsF g) {
 template <int HD, int QS>
 __global__ void __launch_bounds__(256)
 k_attention_x3(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, float* __restrict__ out,
-               int heads, int nq, int nk, int ldq, int ldk, int ldv, int ldo, float scale) {
+               int heads, int nq, int nk, int ldq, int ldk, int ldv, int ldo, float scale, int triple) {
   constexpr int NB = (HD + 31) / 32, HDP = NB * 32;                         // score product: head dim in blocks of 32
   constexpr int DB = (HD + 15) / 16, DP = DB * 16;                          // output dims in blocks of 16
   constexpr int LK = HDP + 8, LV = 40;                                      // LDS row lengths (bf16 elements)
@@ -759,6 +885,18 @@ k_attention_x3(const float* __restrict__ q, const float* __restrict__ k, const f
     const int qi = qb * QB + 64 * s + wid * 16 + fr;
     if (qi >= nq) continue;
     const float inv = 1.0f / lrun[s];
+    if (triple) {                                                           // [hi(ldo) | lo(ldo) | hi(ldo)] rows: the to_out GEMM's A operand
+      unsigned short* row3 = reinterpret_cast<unsigned short*>(out) + ((long)b * nq + qi) * 3 * ldo;
+#pragma unroll
+      for (int d = 0; d < DB; ++d) {
+        const int dim = d * 16 + 4 * fq;                                    // HD % 4 == 0: a quad is valid or not as a whole
+        if (dim < HD) {
+          store_triple2(row3, ldo, h * HD + dim, o[s][d][0] * inv, o[s][d][1] * inv);
+          store_triple2(row3, ldo, h * HD + dim + 2, o[s][d][2] * inv, o[s][d][3] * inv);
+        }
+      }
+      continue;
+    }
     float* op = out + ((long)b * nq + qi) * ldo + h * HD;
 #pragma unroll
     for (int d = 0; d < DB; ++d)
@@ -767,6 +905,41 @@ k_attention_x3(const float* __restrict__ q, const float* __restrict__ k, const f
         const int dim = d * 16 + 4 * fq + e;
         if (dim < HD) op[dim] = o[s][d][e] * inv;
       }
+  }
+}
+
+// f32 [rows, c1] (++ f32 [rows, c2]) -> triple [rows, 3 (c1 + c2)]: raw residual-stream tensors a GEMM reads (shortcut convs over
+// the skip concatenation, down / up-sampling convs, proj_out), text states.  One pass: 4 B read, 6 B written per element.
+__global__ void __launch_bounds__(256)
+k_split3(const float* __restrict__ x, const float* __restrict__ x2, long rows, int c1, int c2, unsigned short* __restrict__ out) {
+  const int C = c1 + c2, cq = C / 4;                                         // c1, c2 % 4 == 0 (host-checked)
+  const long total = rows * cq;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long r = e / cq; const int c = (int)(e - r * cq) * 4;
+    const f32x4 v = c < c1 ? *reinterpret_cast<const f32x4*>(x + r * c1 + c) : *reinterpret_cast<const f32x4*>(x2 + r * c2 + (c - c1));
+    unsigned short* row3 = out + r * 3 * C;
+    const unsigned h0 = bf16_rne(v[0]), h1 = bf16_rne(v[1]), h2 = bf16_rne(v[2]), h3 = bf16_rne(v[3]);
+    const unsigned l0 = bf16_rne(v[0] - __uint_as_float(h0 << 16)), l1 = bf16_rne(v[1] - __uint_as_float(h1 << 16));
+    const unsigned l2 = bf16_rne(v[2] - __uint_as_float(h2 << 16)), l3 = bf16_rne(v[3] - __uint_as_float(h3 << 16));
+    const uint2 hi = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16)), lo = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
+    *reinterpret_cast<uint2*>(row3 + c) = hi;
+    *reinterpret_cast<uint2*>(row3 + C + c) = lo;
+    *reinterpret_cast<uint2*>(row3 + 2 * C + c) = hi;
+  }
+}
+
+// f32 W [rows, cols] -> bf16 [rows, 3 cols]: every K-group of `group` columns (cols itself, or the Cin of one tap of a
+// [O][ky][kx][Cin] conv weight) becomes [hi(group) | hi(group) | lo(group)] -- the partner of the activations' [hi | lo | hi]
+__global__ void __launch_bounds__(256)
+k_expand3_weights(const float* __restrict__ w, long rows, int cols, int group, unsigned short* __restrict__ out) {
+  const long total = rows * cols;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long r = e / cols; const int c = (int)(e - r * cols);
+    const int gi = c / group, ci = c - gi * group;
+    const float v = w[e];
+    const unsigned short hi = bf16_rne(v), lo = bf16_rne(v - __uint_as_float((unsigned)hi << 16));
+    unsigned short* o = out + r * 3 * cols + (long)gi * 3 * group + ci;
+    o[0] = hi; o[group] = hi; o[2 * group] = lo;
   }
 }
 
@@ -846,41 +1019,73 @@ extern "C" int sdn_gemm_x3(const sdn_gemm_desc* d, const void* a, const void* a2
   return gemm_f32_storage(1, d, a, a2, w, bias, rowbias, rowgate, residual, out, stream);
 }
 
-extern "C" int sdn_groupnorm_f32(const void* x, const void* x2, int32_t batch, int32_t hw, int32_t c1, int32_t c2,
-                                 int32_t groups, float eps, int32_t silu, const float* gamma, const float* beta, void* out,
-                                 float* stats_ws, void* stream) {
+static int groupnorm_f32_impl(int triple, const void* x, const void* x2, int32_t batch, int32_t hw, int32_t c1, int32_t c2,
+                              int32_t groups, float eps, int32_t silu, const float* gamma, const float* beta, void* out,
+                              float* stats_ws, void* stream) {
   (void)stats_ws;                                                           // the 16-bit kernels' scratch: not needed here
   if (!x || !gamma || !beta || !out || batch < 0 || hw <= 0 || c1 <= 0 || c2 < 0 || groups <= 0 || (c2 > 0 && !x2) ||
       (c1 + c2) % groups != 0)
     return SDN_E_INVALID;
   if (batch == 0) return SDN_OK;
   const int cpg = (c1 + c2) / groups;
+  // row-major two-pass form (coalesced rows; chunk partials in the caller's scratch: B * 129 * groups * 2 floats cover 64 chunks)
+  if (stats_ws && (c1 & 3) == 0 && (c2 & 3) == 0 && c1 + c2 <= GN_MAXC && groups <= 64 && al16(x) && (!x2 || al16(x2)) && al16(gamma) &&
+      al16(beta) && (reinterpret_cast<uintptr_t>(stats_ws) & 7) == 0 && (reinterpret_cast<uintptr_t>(out) & (triple ? 7 : 15)) == 0 &&
+      !getenv("SDN_GN_F32_OLD")) {
+    int rpc = 16;                                                            // rows per chunk: >= 16, at most 64 chunks per sample
+    while ((hw + rpc - 1) / rpc > 64) rpc *= 2;
+    const int nchunk = (hw + rpc - 1) / rpc;
+    hipLaunchKernelGGL(k_gn_rows_stats, dim3((unsigned)(batch * nchunk)), dim3(256), 0, (hipStream_t)stream, (const float*)x,
+                       (const float*)x2, hw, c1, c2, groups, rpc, (double*)stats_ws);
+    hipLaunchKernelGGL(k_gn_rows_apply, dim3((unsigned)(batch * nchunk)), dim3(256), 0, (hipStream_t)stream, (const float*)x,
+                       (const float*)x2, hw, c1, c2, groups, eps, silu, gamma, beta, rpc, (const double*)stats_ws, (float*)out, triple);
+    return sdn_launch_status();
+  }
   const bool pairs = (cpg & 1) == 0 && (c1 & 1) == 0 && cpg <= 512 && (reinterpret_cast<uintptr_t>(x) & 7) == 0 &&
                      (reinterpret_cast<uintptr_t>(out) & 7) == 0 && (!x2 || (reinterpret_cast<uintptr_t>(x2) & 7) == 0);
   if (pairs)
     hipLaunchKernelGGL(k_groupnorm_f32, dim3((unsigned)(batch * groups)), dim3(256), 0, (hipStream_t)stream, (const float*)x,
-                       (const float*)x2, hw, c1, c2, groups, eps, silu, gamma, beta, (float*)out);
+                       (const float*)x2, hw, c1, c2, groups, eps, silu, gamma, beta, (float*)out, triple);
   else
     hipLaunchKernelGGL(k_groupnorm_f32_any, dim3((unsigned)(batch * groups)), dim3(256), 0, (hipStream_t)stream, (const float*)x,
-                       (const float*)x2, hw, c1, c2, groups, eps, silu, gamma, beta, (float*)out);
+                       (const float*)x2, hw, c1, c2, groups, eps, silu, gamma, beta, (float*)out, triple);
   return sdn_launch_status();
 }
+extern "C" int sdn_groupnorm_f32(const void* x, const void* x2, int32_t batch, int32_t hw, int32_t c1, int32_t c2,
+                                 int32_t groups, float eps, int32_t silu, const float* gamma, const float* beta, void* out,
+                                 float* stats_ws, void* stream) {
+  return groupnorm_f32_impl(0, x, x2, batch, hw, c1, c2, groups, eps, silu, gamma, beta, out, stats_ws, stream);
+}
+extern "C" int sdn_groupnorm_f32_triple(const void* x, const void* x2, int32_t batch, int32_t hw, int32_t c1, int32_t c2,
+                                        int32_t groups, float eps, int32_t silu, const float* gamma, const float* beta,
+                                        void* out_triple, float* stats_ws, void* stream) {
+  return groupnorm_f32_impl(1, x, x2, batch, hw, c1, c2, groups, eps, silu, gamma, beta, out_triple, stats_ws, stream);
+}
 
-extern "C" int sdn_layernorm_f32(const void* x, int64_t rows, int32_t c, float eps, const float* gamma, const float* beta,
-                                 void* out, void* stream) {
-  if (!x || !gamma || !beta || !out || rows < 0 || c <= 0) return SDN_E_INVALID;
+static int layernorm_f32_impl(int triple, const void* x, int64_t rows, int32_t c, float eps, const float* gamma, const float* beta,
+                              void* out, void* stream) {
+  if (!x || !gamma || !beta || !out || rows < 0 || c <= 0 || (triple && (reinterpret_cast<uintptr_t>(out) & 3))) return SDN_E_INVALID;
   if (rows == 0) return SDN_OK;
   hipLaunchKernelGGL(k_layernorm_f32, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)x,
-                     (long)rows, c, eps, gamma, beta, (float*)out);
+                     (long)rows, c, eps, gamma, beta, (float*)out, triple);
   return sdn_launch_status();
 }
+extern "C" int sdn_layernorm_f32(const void* x, int64_t rows, int32_t c, float eps, const float* gamma, const float* beta,
+                                 void* out, void* stream) {
+  return layernorm_f32_impl(0, x, rows, c, eps, gamma, beta, out, stream);
+}
+extern "C" int sdn_layernorm_f32_triple(const void* x, int64_t rows, int32_t c, float eps, const float* gamma, const float* beta,
+                                        void* out_triple, void* stream) {
+  return layernorm_f32_impl(1, x, rows, c, eps, gamma, beta, out_triple, stream);
+}
 
-static int attention_f32_storage(int x3, const void* q, const void* k, const void* v, void* out, int32_t batch, int32_t heads,
+static int attention_f32_storage(int x3, int triple, const void* q, const void* k, const void* v, void* out, int32_t batch, int32_t heads,
                                  int32_t nq, int32_t nk, int32_t head_dim, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo,
                                  float scale, void* stream) {
   if (!q || !k || !v || !out || batch < 0 || heads <= 0 || nq <= 0 || nk <= 0) return SDN_E_INVALID;
   if (!al16(k) || !al16(v) || (ldk & 3) || (ldv & 3)) return SDN_E_INVALID;
   if (x3 && (!al16(q) || (ldq & 3))) return SDN_E_INVALID;                   // the split kernel fetches Q as float4
+  if (triple && (!x3 || (ldo & 1) || (reinterpret_cast<uintptr_t>(out) & 3))) return SDN_E_INVALID;
   if (batch == 0) return SDN_OK;
   const long grid = (long)batch * heads * ((nq + 63) / 64);
   if (grid > 0x7fffffffL) return SDN_E_INVALID;
@@ -892,13 +1097,13 @@ static int attention_f32_storage(int x3, const void* q, const void* k, const voi
     const int QS_ = QSMAX < qs_cap ? QSMAX : qs_cap;                                                                                        \
     if (QS_ >= 4 && nq >= 256)                                                                                        \
       hipLaunchKernelGGL((k_attention_x3<HD, (QSMAX >= 4 ? 4 : 1)>), dim3((unsigned)((long)batch * heads * ((nq + 255) / 256))),  \
-                         dim3(256), 0, (hipStream_t)stream, qf, kf, vf, (float*)out, heads, nq, nk, ldq, ldk, ldv, ldo, scale); \
+                         dim3(256), 0, (hipStream_t)stream, qf, kf, vf, (float*)out, heads, nq, nk, ldq, ldk, ldv, ldo, scale, triple); \
     else if (QS_ >= 2 && nq >= 128)                                                                                   \
       hipLaunchKernelGGL((k_attention_x3<HD, (QSMAX >= 2 ? 2 : 1)>), dim3((unsigned)((long)batch * heads * ((nq + 127) / 128))),  \
-                         dim3(256), 0, (hipStream_t)stream, qf, kf, vf, (float*)out, heads, nq, nk, ldq, ldk, ldv, ldo, scale); \
+                         dim3(256), 0, (hipStream_t)stream, qf, kf, vf, (float*)out, heads, nq, nk, ldq, ldk, ldv, ldo, scale, triple); \
     else                                                                                                              \
       hipLaunchKernelGGL((k_attention_x3<HD, 1>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, qf, kf, vf, \
-                         (float*)out, heads, nq, nk, ldq, ldk, ldv, ldo, scale);                                      \
+                         (float*)out, heads, nq, nk, ldq, ldk, ldv, ldo, scale, triple);                              \
   } else hipLaunchKernelGGL((k_attention_f32<HD>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, qf, kf, vf, \
                             (float*)out, heads, nq, nk, ldq, ldk, ldv, ldo, scale)
   switch (head_dim) {
@@ -915,12 +1120,38 @@ static int attention_f32_storage(int x3, const void* q, const void* k, const voi
 extern "C" int sdn_attention_f32(const void* q, const void* k, const void* v, void* out, int32_t batch, int32_t heads,
                                  int32_t nq, int32_t nk, int32_t head_dim, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo,
                                  float scale, void* stream) {
-  return attention_f32_storage(0, q, k, v, out, batch, heads, nq, nk, head_dim, ldq, ldk, ldv, ldo, scale, stream);
+  return attention_f32_storage(0, 0, q, k, v, out, batch, heads, nq, nk, head_dim, ldq, ldk, ldv, ldo, scale, stream);
 }
 extern "C" int sdn_attention_x3(const void* q, const void* k, const void* v, void* out, int32_t batch, int32_t heads,
                                 int32_t nq, int32_t nk, int32_t head_dim, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo,
                                 float scale, void* stream) {
-  return attention_f32_storage(1, q, k, v, out, batch, heads, nq, nk, head_dim, ldq, ldk, ldv, ldo, scale, stream);
+  return attention_f32_storage(1, 0, q, k, v, out, batch, heads, nq, nk, head_dim, ldq, ldk, ldv, ldo, scale, stream);
+}
+extern "C" int sdn_attention_x3_triple(const void* q, const void* k, const void* v, void* out_triple, int32_t batch, int32_t heads,
+                                       int32_t nq, int32_t nk, int32_t head_dim, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo,
+                                       float scale, void* stream) {
+  return attention_f32_storage(1, 1, q, k, v, out_triple, batch, heads, nq, nk, head_dim, ldq, ldk, ldv, ldo, scale, stream);
+}
+
+extern "C" int sdn_split3(const float* x, const float* x2, int64_t rows, int32_t c1, int32_t c2, void* out_triple, void* stream) {
+  if (!x || !out_triple || rows < 0 || c1 <= 0 || c2 < 0 || (c1 & 3) || (c2 & 3) || (c2 > 0 && !x2) || !al16(x) || (x2 && !al16(x2)) ||
+      (reinterpret_cast<uintptr_t>(out_triple) & 7))
+    return SDN_E_INVALID;
+  if (rows == 0) return SDN_OK;
+  long g = (rows * ((c1 + c2) / 4) + 255) / 256;
+  if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(k_split3, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, x2, (long)rows, c1, c2, (unsigned short*)out_triple);
+  return sdn_launch_status();
+}
+
+extern "C" int sdn_expand3_weights(const float* w, int64_t rows, int32_t cols, int32_t group, void* out_bf16, void* stream) {
+  if (!w || !out_bf16 || rows < 0 || cols <= 0 || group <= 0 || cols % group != 0) return SDN_E_INVALID;
+  if (rows == 0) return SDN_OK;
+  long g = (rows * cols + 255) / 256;
+  if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(k_expand3_weights, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, w, (long)rows, cols, group,
+                     (unsigned short*)out_bf16);
+  return sdn_launch_status();
 }
 
 extern "C" int sdn_conv_in_f32(const float* latents_nchw, const void* w, const float* bias, int32_t batch, int32_t cin,

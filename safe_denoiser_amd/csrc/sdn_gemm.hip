@@ -245,6 +245,17 @@ k_gemm_dma(const GemmArgs g) {
     }
   }
 
+  if (g.x3_out && g.residual) {                              // bf16x3 plan: f32 residual [M, ldc], in the shadow of the first k-tile's DMA
+    const float* resf = reinterpret_cast<const float*>(g.residual);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wm * 64 + i * 16 + fr;
+      const float* rp = resf + (long)(m < g.M ? m : 0) * g.ldc + n0 + wn * 16 * NREP + fq * 4;
+#pragma unroll
+      for (int j = 0; j < NREP; ++j) acc[i][j] += *reinterpret_cast<const f32x4*>(rp + j * 16);
+    }
+  }
+
   if constexpr (NSTAGE == 2) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -567,7 +578,13 @@ static int sdn_gemm_impl(int dtype, const sdn_gemm_desc* d, const void* a, const
   const int n_valid = d->n_valid > 0 ? d->n_valid : d->N;
   if (n_valid > d->N) return SDN_E_INVALID;
   if (sdn_gemm_pick_nrep(d->N, d->act) == 0) return SDN_E_INVALID;
-  const int nrep = sdn_gemm_pick_tile(d->M, d->N, d->K, d->act, (residual || rowgate) ? 1 : 0);
+  const int x3 = d->x3_out;
+  if (x3 < 0 || x3 > 3 || (x3 && (dtype != 0 || rowgate || d->split_k > 1 || partials || ln_c || col_stats || n_valid != d->N)))
+    return SDN_E_INVALID;
+  if (x3 && ((x3 == 2) != (d->act == SDN_ACT_GEGLU) || (x3 != 2 && d->act != SDN_ACT_NONE) || (residual && !al16(residual)) || !al16(out)))
+    return SDN_E_INVALID;
+  // (in the bf16x3 plan the residual rides in the accumulators from the start: it is not an epilogue read)
+  const int nrep = sdn_gemm_pick_tile(d->M, d->N, d->K, d->act, ((residual && !x3) || rowgate) ? 1 : 0);
   if (!al16(a) || !al16(w) || (a2 && !al16(a2)) || (residual && (reinterpret_cast<uintptr_t>(residual) & 7)) ||
       (reinterpret_cast<uintptr_t>(out) & 7) || (bias && !al16(bias)) || (rowbias && !al16(rowbias)))
     return SDN_E_INVALID;
@@ -593,22 +610,24 @@ static int sdn_gemm_impl(int dtype, const sdn_gemm_desc* d, const void* a, const
     return SDN_E_INVALID;
   }
   if (d->act < 0 || d->act > 4 || d->out_kind < 0 || d->out_kind > 2) return SDN_E_INVALID;
-  if (d->act == SDN_ACT_GEGLU && (d->out_kind != SDN_OUT_BF16 || rowbias || rowgate || residual || n_valid != d->N))
+  if (d->act == SDN_ACT_GEGLU && ((d->out_kind != SDN_OUT_BF16 && !x3) || rowbias || rowgate || residual || n_valid != d->N))
     return SDN_E_INVALID;
   if ((rowbias || rowgate || d->residual_bcast || d->out_kind == SDN_OUT_F32_NCHW) && d->rows_per_batch <= 0) return SDN_E_INVALID;
   if (rowgate && !al16(rowgate)) return SDN_E_INVALID;
-  g.act = d->act; g.out_kind = d->out_kind; g.rows_per_batch = d->rows_per_batch; g.ld_rowbias = d->ld_rowbias;
+  g.x3_out = x3;
+  g.act = d->act; g.out_kind = x3 ? SDN_OUT_F32 : d->out_kind; g.rows_per_batch = d->rows_per_batch; g.ld_rowbias = d->ld_rowbias;
   g.ld_rowgate = d->ld_rowgate; g.residual_bcast = d->residual_bcast;
   g.n_valid = n_valid;
   g.ldc = d->ldc > 0 ? d->ldc : (d->act == SDN_ACT_GEGLU ? d->N / 2 : n_valid);
-  if (d->out_kind == SDN_OUT_BF16 && ((g.ldc & 7) || !al16(out))) return SDN_E_INVALID;
+  if (!x3 && d->out_kind == SDN_OUT_BF16 && ((g.ldc & 7) || !al16(out))) return SDN_E_INVALID;
+  if (x3 && (g.ldc & 3)) return SDN_E_INVALID;
   const int bn = 32 * nrep;
   const int bm = nrep >= 8 ? 256 : 128;
   g.tiles_m = (d->M + bm - 1) / bm; g.tiles_n = d->N / bn;
   {
     const long res_rows = d->residual_bcast ? (long)d->rows_per_batch : (long)d->M;
     const long res_bytes = res_rows * g.ldc * 2;
-    g.res_lds = residual != nullptr && al16(residual) && res_bytes < (1L << 31) && g_gemm_variant != 4;   // variant 4: per-fragment loads (A/B)
+    g.res_lds = !x3 && residual != nullptr && al16(residual) && res_bytes < (1L << 31) && g_gemm_variant != 4;   // variant 4: per-fragment loads (A/B)
     g.res_bytes = g.res_lds ? (unsigned)res_bytes : 0u;
   }
   if (col_stats) {                                              // column statistics ride on the staged 16-bit tile

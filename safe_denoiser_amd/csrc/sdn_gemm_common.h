@@ -26,6 +26,9 @@ struct GemmArgs {
   long split_stride;         // bytes between the partial outputs of consecutive slices
   int res_lds;               // residual goes through the LDS staging slab (16-bit staged output, offsets fit 31 bits)
   unsigned res_bytes;        // buffer size of the residual for the DMA's bounds check
+  int x3_out;                // bf16x3 plan (operands = bf16 hi|lo|hi triples, K = 3 x the logical K; sdn_gemm_x3t): the residual is F32
+                             // [M, ldc], added into the accumulators before the k loop, and the output goes straight from the
+                             // registers to global memory: 1 = f32 [M, ldc]; 2 = GEGLU, triple [M, 3 ldc]; 3 = triple [M, 3 ldc]
   unsigned long long* stamps; // diagnostics: 8 s_memtime stamp slots per workgroup (tools/gemm_stamps.py); nullptr in production
   int dbg;                   // timing-only ablations (tools/bench_gemm.py): 1 = no global stores, 2 = DMA only for k-tile 0
 };
@@ -49,6 +52,12 @@ __device__ __forceinline__ float erf_as(float x) {
   const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
   const float r = fmaf(-p * t, e, 1.0f);
   return copysignf(r, x);
+}
+// x = hi + lo to 2^-17 relative (16 mantissa bits): hi = bf16(x), lo = bf16(x - hi); packed pairs of four values
+__device__ __forceinline__ void split_hi_lo4(const f32x4 v, uint2& hi, uint2& lo) {
+  hi.x = pack_bf16(v[0], v[1]); hi.y = pack_bf16(v[2], v[3]);
+  lo.x = pack_bf16(v[0] - __uint_as_float(hi.x << 16), v[1] - __uint_as_float(hi.x & 0xffff0000u));
+  lo.y = pack_bf16(v[2] - __uint_as_float(hi.y << 16), v[3] - __uint_as_float(hi.y & 0xffff0000u));
 }
 __device__ __forceinline__ float gelu_erf_ref(float v) { return 0.5f * v * (1.f + erf_as(v * 0.70710678118654752f)); }
 // GELU (erf form) for a 16-BIT output: x * Phi(x) with Phi(x) = 1 / (1 + 2^(x (a + b x^2 + c x^4))), a quintic-argument logistic

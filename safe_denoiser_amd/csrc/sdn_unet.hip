@@ -24,6 +24,7 @@
 #include <string.h>
 
 #include <map>
+#include <set>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -37,7 +38,7 @@ enum Space { SP_NONE = 0, SP_W = 1, SP_WS = 2, SP_LATENTS = 3, SP_TEXT = 4, SP_O
 struct Ref { int space = SP_NONE; int64_t off = 0; };
 
 enum OpKind { OP_TEMB, OP_CONV_IN, OP_GEMM, OP_GN, OP_LN, OP_ATTN, OP_PATCHIFY, OP_UNPATCHIFY, OP_LATENT_MIX, OP_SOFTMAX,
-              OP_TRANSPOSE, OP_GAUSS, OP_REPEAT, OP_CLIP_EMBED, OP_MATTN, OP_ROWSTATS, OP_FFN };
+              OP_TRANSPOSE, OP_GAUSS, OP_REPEAT, OP_CLIP_EMBED, OP_MATTN, OP_ROWSTATS, OP_FFN, OP_SPLIT3 };
 
 struct Op {
   int kind;
@@ -47,6 +48,8 @@ struct Op {
   Ref col, cols1, cols2;     // GEMM: column partials to emit; GroupNorm: partials of its input(s) to reduce instead of reading
   Ref ln_c, ln_d, ln_stats;  // GEMM with LayerNorm folded in (sdn_gemm_ln_*); ln_stats unset = statistics inside the kernel
   int ln = 0;
+  int x3t = 0;               // bf16x3 plan: this GEMM runs on sdn_gemm_bf16 over triple operands (gd holds the EXPANDED K / Cin)
+  int tri_out = 0;           // bf16x3 plan: GroupNorm / LayerNorm / attention write the bf16 hi|lo|hi triple a GEMM will read
   int n1 = 0, mod = 0, ld_mod = 0, patch = 0;
   // GN / LN / conv_in / attention scalars
   int batch = 0, hw = 0, c1 = 0, c2 = 0, groups = 0, silu = 0;
@@ -104,6 +107,8 @@ struct Arena {                      // plan-time first-fit allocator with coales
 
 struct Act {                         // a bf16 [rows, C] activation living in the workspace
   int64_t off = -1, bytes = 0; int C = 0, hw = 0, side = 0;
+  int64_t content = 0;               // bytes of the tensor in the plan's storage type (== bytes except in the bf16x3 plan, whose
+                                     // slots are sized for the 6-byte-per-element triple form as well)
   int64_t st_off = -1, st_bytes = 0;   // column partials its producing GEMM leaves for the GroupNorm that reads it
 };
 
@@ -144,8 +149,9 @@ struct sdn_unet {
   bool ff_fuse = true;                  // FeedForward's output linear and the block's proj_out (no nonlinearity between them)
   bool ffn_fuse = true;                 // ... and the GEGLU projection in front of them: one launch, hidden activation in LDS (C = 320)
                                         // contracted into ONE GEMM over [ff | h3] with the product weight (sdn_linear_pair_fold)
-  struct FoldJob { int64_t w, gamma, beta, bias, wf, c, d; int rows, cols; int kind = 0; };   // kind 0: LayerNorm fold; 1: linear pair
+  struct FoldJob { int64_t w, gamma, beta, bias, wf, c, d; int rows, cols; int kind = 0; int group = 0; };   // kind 0: LayerNorm fold; 1: linear pair; 2: bf16x3 weight expansion (sdn_expand3_weights)
   std::vector<FoldJob> fold_jobs;       // what sdn_unet_prepare has to compute into the SDN_P_DERIVED regions
+  bool x3_expand = true;                // dtype 3: GEMM operands as bf16 triples on the LDS-DMA tiles (false: the f32-staging k_gemm_x3 everywhere)
   bool split_k = false;                 // sdn_unet_set_split_k: small-M GEMMs of the plan take the split-K form (off by
                                         // default: it changes fp32 summation order with the batch size, and batch rows are
                                         // otherwise bit-identical whatever the batch)
@@ -174,6 +180,9 @@ struct Builder {
   Arena arena;
   int B;
   int es = 2;                // bytes per activation / matrix-weight element: 2 (bf16 | f16 storage) or 4 (the fp32 precision mode)
+  bool x3t = false;          // bf16x3 by operand expansion (SD-v1.4 UNet plan, dtype 3): GEMM operands are bf16 hi|lo|hi triples
+  bool x3t_hold = false;     // ... except inside this scope (the per-sample time-embedding GEMMs: M = batch, nothing to gain)
+  std::set<int64_t> tri;     // workspace offsets that currently hold a triple (set by its producer, cleared by drop())
   Ref tproj;                 // f32 [B, tproj_total]
   int tproj_cursor = 0;      // column offset of the next resnet's slice
   Ref gn_stats;
@@ -209,8 +218,11 @@ struct Builder {
 
   // ---- activations ------------------------------------------------------------------------------
   Act act(int64_t rows, int C, int hw = 0, int side = 0, int esz = 0) {
+    const bool dflt = esz == 0;
     if (esz == 0) esz = es;
-    Act t; t.bytes = rows * C * esz; t.off = arena.alloc(t.bytes); t.C = C; t.hw = hw; t.side = side; return t;
+    Act t; t.content = rows * C * esz;
+    t.bytes = (x3t && dflt) ? rows * C * 6 : t.content;      // a default-typed slot may hold the f32 tensor or its triple
+    t.off = arena.alloc(t.bytes); t.C = C; t.hw = hw; t.side = side; return t;
   }
   // an activation a GroupNorm will read: its producer (a GEMM) also emits per-128-row-block column sums
   Act act_gn(int64_t rows, int C, int hw, int side) {
@@ -224,16 +236,56 @@ struct Builder {
   Ref pending_cols;                    // set by want_stats() for the NEXT emitted GEMM
   void want_stats(const Act& out) { pending_cols = out.st_off >= 0 ? Ref{SP_WS, out.st_off} : Ref(); }
   void drop(Act& t) {
-    if (t.off >= 0) arena.release(t.off, t.bytes);
+    if (t.off >= 0) { arena.release(t.off, t.bytes); tri.erase(t.off); }
     if (t.st_off >= 0) arena.release(t.st_off, t.st_bytes);
     t.off = -1; t.st_off = -1;
   }
   static Ref R(const Act& t) { return Ref{SP_WS, t.off}; }
 
+  // ---- bf16x3 by operand expansion (include/sdn.h) -------------------------------------------------
+  // expanded copy of an f32 weight region [rows, cols] (stacked matrices are contiguous, so w.off names the whole operand)
+  Ref x3_weight(Ref w, int rows, int cols, int group) {
+    const std::string name = "x3@" + std::to_string((long long)w.off);
+    const bool fresh = u->param_index.find(name) == u->param_index.end();
+    Ref d = derived(name, (int64_t)rows * 3 * cols * 2);
+    if (fresh) { sdn_unet::FoldJob j{w.off, -1, -1, -1, d.off, -1, -1, rows, cols}; j.kind = 2; j.group = group; u->fold_jobs.push_back(j); }
+    return d;
+  }
+  // the triple of an f32 tensor that no producer could write in that form (a raw residual-stream tensor, a skip concatenation)
+  Act split3(Ref a, Ref a2, int64_t rows, int c1, int c2, int hw = 0, int side = 0) {
+    Act t = act(rows, c1 + c2, hw, side);
+    Op o; o.kind = OP_SPLIT3; o.a = a; o.a2 = a2; o.rows = rows; o.c1 = c1; o.c2 = c2; o.out = R(t);
+    o.bytes = 10.0 * (double)rows * (c1 + c2);
+    snprintf(o.label, sizeof(o.label), "k_split3");
+    plan->ops.push_back(o);
+    tri.insert(t.off);
+    return t;
+  }
+  bool x3t_on(const Ref& a) const { return x3t && !x3t_hold && a.space == SP_WS; }
+
   // ---- op emitters ------------------------------------------------------------------------------
   void gemm(int64_t M, int N, int K, Ref a, Ref w, Ref bias, Ref out, int act_ = SDN_ACT_NONE, Ref residual = Ref(),
             int out_kind = SDN_OUT_BF16, int n_valid = 0, Ref a2 = Ref(), int K1 = 0, Ref rowbias = Ref(),
             int rows_per_batch = 0, int ld_rowbias = 0) {
+    if (x3t_on(a) && (act_ == SDN_ACT_NONE || act_ == SDN_ACT_GEGLU) && out_kind != SDN_OUT_F32_NCHW && n_valid == 0) {
+      // A' = [hi | lo | hi] (written by the producing GroupNorm / LayerNorm / attention / GEGLU epilogue, or by a split pass),
+      // W' = [hi | hi | lo]: one bf16 GEMM with three times the k loop; F32 residual, F32 (or, for GEGLU, triple) output
+      Act tmp; Ref au = a;
+      if (!tri.count(a.off)) { tmp = split3(a, a2, M, a2.space != SP_NONE ? K1 : K, a2.space != SP_NONE ? K - K1 : 0); au = R(tmp); }
+      Op o; o.kind = OP_GEMM; memset(&o.gd, 0, sizeof(o.gd));
+      o.x3t = 1;
+      o.gd.M = (int)M; o.gd.N = N; o.gd.K = 3 * K; o.gd.a_mode = SDN_A_PLAIN; o.gd.act = act_; o.gd.out_kind = SDN_OUT_F32;
+      o.gd.x3_out = act_ == SDN_ACT_GEGLU ? 2 : 1; o.gd.rows_per_batch = rows_per_batch; o.gd.ld_rowbias = ld_rowbias;
+      o.a = au; o.w = x3_weight(w, N, K, K); o.bias = bias; o.rowbias = rowbias; o.residual = residual; o.out = out;
+      o.flops = 2.0 * (double)M * (double)N * (double)K;
+      o.bytes = 6.0 * ((double)M * K + (double)N * K) + 4.0 * (double)M * (act_ == SDN_ACT_GEGLU ? 0.75 * N : N) +
+                (residual.space != SP_NONE ? 4.0 * (double)M * N : 0.0);
+      snprintf(o.label, sizeof(o.label), "k_gemm<%d>x3", sdn_gemm_pick_tile((int)M, N, 3 * K, act_));
+      push_gemm(o);
+      if (act_ == SDN_ACT_GEGLU) tri.insert(out.off);
+      if (tmp.off >= 0) drop(tmp);                            // stream order: the next op may reuse it
+      return;
+    }
     Op o; o.kind = OP_GEMM; memset(&o.gd, 0, sizeof(o.gd));
     o.gd.M = (int)M; o.gd.N = N; o.gd.K = K; o.gd.a_mode = SDN_A_PLAIN; o.gd.K1 = K1; o.gd.act = act_;
     o.gd.out_kind = out_kind; o.gd.n_valid = n_valid; o.gd.rows_per_batch = rows_per_batch; o.gd.ld_rowbias = ld_rowbias;
@@ -265,6 +317,30 @@ struct Builder {
                Ref rowbias, int ld_rowbias, int out_kind = SDN_OUT_BF16, int n_valid = 0, int asym_pad = 0) {
     const int Hi = upsample ? in.side * 2 : in.side;
     const int Ho = (Hi + (asym_pad ? 1 : 2) - 3) / stride + 1;
+    if (x3t_on(R(in))) {
+      // the same convolution over an input with 3 Cin channels per pixel ([hi | lo | hi]) and per-tap weights [hi | hi | lo]
+      Act tmp; Ref au = R(in);
+      if (!tri.count(in.off)) { tmp = split3(R(in), Ref(), (int64_t)B * in.side * in.side, in.C, 0, in.hw, in.side); au = R(tmp); }
+      Op o; o.kind = OP_GEMM; memset(&o.gd, 0, sizeof(o.gd));
+      o.x3t = 1;
+      o.gd.M = B * Ho * Ho; o.gd.N = n_pad; o.gd.K = 27 * in.C; o.gd.a_mode = SDN_A_CONV3X3;
+      o.gd.Hs = in.side; o.gd.Ws = in.side; o.gd.Cin = 3 * in.C; o.gd.Ho = Ho; o.gd.Wo = Ho; o.gd.stride = stride;
+      o.gd.upsample = upsample; o.gd.asym_pad = asym_pad; o.gd.n_valid = n_valid; o.gd.rows_per_batch = Ho * Ho; o.gd.ld_rowbias = ld_rowbias;
+      if (out_kind == SDN_OUT_F32_NCHW) { o.gd.out_kind = out_kind; o.gd.x3_out = 0; }     // conv_out: the general epilogue's NCHW f32 form
+      else { o.gd.out_kind = SDN_OUT_F32; o.gd.x3_out = 1; }
+      o.a = au; o.w = x3_weight(w, n_pad, 9 * in.C, in.C); o.bias = bias; o.rowbias = rowbias; o.residual = residual; o.out = out;
+      o.flops = 2.0 * (double)o.gd.M * (double)cout * 9.0 * in.C;
+      o.bytes = 6.0 * ((double)B * in.side * in.side * in.C + (double)n_pad * 9 * in.C) + 4.0 * (double)o.gd.M * cout +
+                (residual.space != SP_NONE ? 4.0 * (double)o.gd.M * cout : 0.0);
+      if (Ho == in.side && sdn_conv_slab_shape_ok(o.gd.M, n_pad, 3 * in.C, in.side, stride, upsample, asym_pad, SDN_OUT_BF16, n_valid) &&
+          sdn_gemm_pick_tile(o.gd.M, n_pad, o.gd.K, SDN_ACT_NONE) == 10)
+        snprintf(o.label, sizeof(o.label), "k_conv_slab/x3");
+      else
+        snprintf(o.label, sizeof(o.label), "k_gemm<%d>x3", sdn_gemm_pick_tile(o.gd.M, n_pad, o.gd.K, SDN_ACT_NONE));
+      push_gemm(o);
+      if (tmp.off >= 0) drop(tmp);
+      return;
+    }
     Op o; o.kind = OP_GEMM; memset(&o.gd, 0, sizeof(o.gd));
     o.gd.M = B * Ho * Ho; o.gd.N = n_pad; o.gd.K = 9 * in.C; o.gd.a_mode = SDN_A_CONV3X3;
     o.gd.Hs = in.side; o.gd.Ws = in.side; o.gd.Cin = in.C; o.gd.Ho = Ho; o.gd.Wo = Ho; o.gd.stride = stride;
@@ -285,6 +361,7 @@ struct Builder {
     Op o; o.kind = OP_GN; o.a = R(x); if (x2) o.a2 = R(*x2);
     o.batch = B; o.hw = x.hw; o.c1 = x.C; o.c2 = x2 ? x2->C : 0; o.groups = u->cfg.norm_groups; o.eps = eps;
     o.silu = silu; o.w = gamma; o.bias = beta; o.out = R(out); o.aux = gn_stats;
+    if (x3t) { o.tri_out = 1; tri.insert(out.off); }            // every GroupNorm of the UNet feeds a conv / linear
     if (x.st_off >= 0 && (!x2 || x2->st_off >= 0)) {             // statistics come with the inputs: apply pass only
       o.cols1 = Ref{SP_WS, x.st_off};
       if (x2) o.cols2 = Ref{SP_WS, x2->st_off};
@@ -296,6 +373,7 @@ struct Builder {
   void layernorm(const Act& x, Ref gamma, Ref beta, const Act& out) {
     Op o; o.kind = OP_LN; o.a = R(x); o.rows = (int64_t)B * x.hw; o.c1 = x.C; o.eps = 1e-5f; o.w = gamma; o.bias = beta;
     o.out = R(out);
+    if (x3t) { o.tri_out = 1; tri.insert(out.off); }            // ... and every LayerNorm a projection
     o.bytes = 2.0 * 2.0 * (double)o.rows * x.C;
     snprintf(o.label, sizeof(o.label), "k_layernorm");
     plan->ops.push_back(o);
@@ -337,8 +415,8 @@ struct Builder {
     if (prepass) drop(st);
   }
   void repeat(const Act& in, const Act& out, int rep) {          // out = cat([in] * rep) along the batch
-    Op o; o.kind = OP_REPEAT; o.a = R(in); o.out = R(out); o.rows = in.bytes; o.c1 = rep;
-    o.bytes = (double)in.bytes * (1 + rep);
+    Op o; o.kind = OP_REPEAT; o.a = R(in); o.out = R(out); o.rows = in.content; o.c1 = rep;     // (stream tensors: never triples)
+    o.bytes = (double)in.content * (1 + rep);
     snprintf(o.label, sizeof(o.label), "k_repeat");
     plan->ops.push_back(o);
   }
@@ -346,6 +424,7 @@ struct Builder {
     Op o; o.kind = OP_ATTN; o.a = q; o.k = k; o.v = v; o.out = out; o.batch = B; o.heads = u->cfg.n_heads;
     o.nq = nq; o.nk = nk; o.hd = C / u->cfg.n_heads; o.ldq = ldq; o.ldk = ldk; o.ldv = ldv; o.ldo = C;
     o.scale = 1.0f / sqrtf((float)o.hd);
+    if (x3t && out.space == SP_WS) { o.tri_out = 1; tri.insert(out.off); }   // its only reader is the to_out projection
     const double f = 4.0 * (double)B * o.heads * (double)nq * (double)nk * (double)o.hd;
     o.flops = f;
     o.bytes = 2.0 * (double)B * C * (2.0 * nq + 2.0 * nk);
@@ -783,6 +862,7 @@ struct Builder {
     plan->tscalar_off = arena.alloc(256);
     Act tsin = act(B, ch0);
     { Op o; o.kind = OP_TEMB; o.batch = B; o.c1 = ch0; o.out = R(tsin); snprintf(o.label, sizeof(o.label), "k_temb"); plan->ops.push_back(o); }
+    x3t_hold = true;                                            // M = batch: the per-sample time-embedding linears
     Act t1 = act(B, tdim);
     gemm(B, tdim, ch0, R(tsin), l1w, l1b, R(t1), SDN_ACT_SILU);
     drop(tsin);
@@ -793,6 +873,7 @@ struct Builder {
     tproj = R(tp);
     gemm(B, total, tdim, R(semb), tpw, tpb, R(tp), SDN_ACT_NONE, Ref(), SDN_OUT_F32);
     drop(semb);
+    x3t_hold = false;
 
     // ---- conv_in ----
     Ref ciw = param("conv_in.weight", SDN_P_CONV3X3, ch0, 9 * c.in_channels), cib = param("conv_in.bias", SDN_P_VEC_F32, ch0, 0);
@@ -1178,6 +1259,7 @@ Plan* get_plan(sdn_unet* u, int batch) {
   Builder b{u, &p};
   b.B = batch;
   b.es = (!u->is_vae && !u->is_mmdit && u->cfg.dtype >= 2) ? 4 : 2;       // fp32 storage: SD-v1.4 UNet and CLIP text encoder plans
+  b.x3t = !u->is_vae && !u->is_mmdit && !u->is_clip && u->cfg.dtype == 3 && u->x3_expand;
   if (u->is_clip) b.build_clip(); else if (u->is_vae_encoder) b.build_vae_encoder(); else if (u->is_vae) b.build_vae(); else if (u->is_mmdit) b.build_mmdit(); else b.build();
   return &p;
 }
@@ -1307,6 +1389,11 @@ int sdn_unet_prepare(sdn_unet* u, void* weights, void* stream) {
   char* W = (char*)weights;
   const int dt = (u->is_mmdit ? u->mcfg.dtype : u->cfg.dtype) == 1 ? 1 : 0;
   for (const auto& j : u->fold_jobs) {
+    if (j.kind == 2) {
+      const int rc2 = sdn_expand3_weights((const float*)(W + j.w), j.rows, j.cols, j.group, W + j.wf, stream);
+      if (rc2 != SDN_OK) return rc2;
+      continue;
+    }
     if (j.kind == 1) {
       const int rc1 = sdn_linear_pair_fold(dt, W + j.w, W + j.gamma, (const float*)(W + j.beta), (const float*)(W + j.bias), j.rows, j.cols,
                                            W + j.wf, (float*)(W + j.c), stream);
@@ -1423,6 +1510,38 @@ int sdn_mmdit_forward(sdn_unet* u, const void* weights, const float* latents, fl
   return run_plan(u, weights, latents, timestep, text, pooled, out, batch, workspace, workspace_bytes, stream);
 }
 
+// A GEMM of the bf16x3 plan on sdn_gemm_bf16 (triple operands, expanded weights).  The LDS-DMA tiles address each operand with
+// 31-bit byte offsets, and a triple is 1.5 x its f32 tensor: the launch is cut into row chunks (whole samples for a conv) that
+// stay below 2 GiB per operand.  Rows are independent, so the chunks are the same arithmetic.
+static int launch_x3t_gemm(const Op& o, const char* a, const char* w, const float* bias, const float* rowbias, const char* residual,
+                           void* out, void* stream) {
+  const sdn_gemm_desc& d = o.gd;
+  const bool conv = d.a_mode == SDN_A_CONV3X3;
+  const long rows_out_unit = conv ? (long)d.Ho * d.Wo : 256;                 // chunk granularity in output rows
+  const long a_bytes_unit = conv ? (long)d.Hs * d.Ws * d.Cin * 2 : 256L * d.K * 2;
+  const long units = conv ? d.M / rows_out_unit : (d.M + 255) / 256;
+  long per = ((1L << 31) - 4096) / a_bytes_unit;                              // units per launch
+  if (per < 1) return SDN_E_INVALID;
+  if (per > units) per = units;
+  const int n_cols = d.x3_out == 2 ? d.N / 2 : d.N;                           // logical output width
+  const long out_row_bytes = d.x3_out == 0 ? 0 : (d.x3_out == 1 ? 4L * n_cols : 6L * n_cols);
+  if (d.x3_out == 0 && per < units) return SDN_E_INVALID;                     // (the NCHW output of conv_out is not chunked: 4 channels)
+  for (long u0 = 0; u0 < units; u0 += per) {
+    const long nu = units - u0 < per ? units - u0 : per;
+    sdn_gemm_desc c = d;
+    const long r0 = u0 * rows_out_unit;
+    long rn = nu * rows_out_unit;
+    if (r0 + rn > d.M) rn = d.M - r0;
+    c.M = (int)rn;
+    const float* rb = rowbias;
+    if (rowbias && d.rows_per_batch > 0) rb = rowbias + (r0 / d.rows_per_batch) * d.ld_rowbias;   // chunks start on sample boundaries when it matters (conv)
+    const int rc = sdn_gemm_bf16(&c, a + u0 * a_bytes_unit, nullptr, w, bias, rb, nullptr,
+                                 residual ? residual + r0 * 4L * n_cols : nullptr, (char*)out + r0 * out_row_bytes, stream);
+    if (rc != SDN_OK) return rc;
+  }
+  return SDN_OK;
+}
+
 // Launches every op of the plan on `stream`.  t_dev != nullptr: the timestep is read from device memory (graph mode).
 static int launch_ops(sdn_unet* u, Plan* p, const char* W, const char* WS, const char* L, const char* T, const char* O,
                       const char* PL, float timestep, const float* t_dev, bool prof, void* stream) {
@@ -1443,22 +1562,28 @@ static int launch_ops(sdn_unet* u, Plan* p, const char* W, const char* WS, const
           rc = sdn_conv_in_f32((const float*)P(o.a), P(o.w), (const float*)P(o.bias), o.batch, o.c1, o.hw, o.hw, o.c2, (void*)P(o.out), stream);
           break;
         case OP_GEMM:
+          if (o.x3t) { rc = launch_x3t_gemm(o, P(o.a), P(o.w), (const float*)P(o.bias), (const float*)P(o.rowbias), P(o.residual), (void*)P(o.out), stream); break; }
           rc = (o.ln || o.gd.split_k > 1) ? SDN_E_INVALID
                : (x3 ? sdn_gemm_x3 : sdn_gemm_f32)(&o.gd, P(o.a), P(o.a2), P(o.w), (const float*)P(o.bias), (const float*)P(o.rowbias),
                                                    (const float*)P(o.rowgate), P(o.residual), (void*)P(o.out), stream);
           break;
+        case OP_SPLIT3:
+          rc = sdn_split3((const float*)P(o.a), (const float*)P(o.a2), o.rows, o.c1, o.c2, (void*)P(o.out), stream);
+          break;
         case OP_GN:
-          rc = sdn_groupnorm_f32(P(o.a), P(o.a2), o.batch, o.hw, o.c1, o.c2, o.groups, o.eps, o.silu, (const float*)P(o.w),
-                                 (const float*)P(o.bias), (void*)P(o.out), (float*)P(o.aux), stream);
+          rc = (o.tri_out ? sdn_groupnorm_f32_triple : sdn_groupnorm_f32)(P(o.a), P(o.a2), o.batch, o.hw, o.c1, o.c2, o.groups, o.eps, o.silu,
+                                                                         (const float*)P(o.w), (const float*)P(o.bias), (void*)P(o.out),
+                                                                         (float*)P(o.aux), stream);
           break;
         case OP_LN:
           rc = o.mod ? SDN_E_INVALID
-                     : sdn_layernorm_f32(P(o.a), o.rows, o.c1, o.eps, (const float*)P(o.w), (const float*)P(o.bias), (void*)P(o.out), stream);
+                     : (o.tri_out ? sdn_layernorm_f32_triple : sdn_layernorm_f32)(P(o.a), o.rows, o.c1, o.eps, (const float*)P(o.w),
+                                                                                  (const float*)P(o.bias), (void*)P(o.out), stream);
           break;
         case OP_ATTN:
           rc = o.n1 > 0 ? SDN_E_INVALID
-                        : (x3 ? sdn_attention_x3 : sdn_attention_f32)(P(o.a), P(o.k), P(o.v), (void*)P(o.out), o.batch, o.heads, o.nq, o.nk,
-                                                                      o.hd, o.ldq, o.ldk, o.ldv, o.ldo, o.scale, stream);
+                        : (o.tri_out ? sdn_attention_x3_triple : (x3 ? sdn_attention_x3 : sdn_attention_f32))(
+                              P(o.a), P(o.k), P(o.v), (void*)P(o.out), o.batch, o.heads, o.nq, o.nk, o.hd, o.ldq, o.ldk, o.ldv, o.ldo, o.scale, stream);
           break;
         case OP_REPEAT:
           rc = sdn_repeat(P(o.a), (size_t)o.rows, o.c1, (void*)P(o.out), stream);
@@ -1662,6 +1787,15 @@ void sdn_unet_set_graph_mode(sdn_unet* u, int32_t on) {
 
 // Undeclared tuning hook (tools/): size threshold of the transformer sub-batching; rebuilds the plans.
 // Undeclared A/B hook: run the BasicTransformerBlock LayerNorms as separate kernels again (the derived regions stay).
+// A/B and tests: dtype-3 plans on the f32-staging k_gemm_x3 everywhere (0) or with triple operands on the LDS-DMA tiles (1, default).
+// The expanded weight regions stay registered either way (the manifest does not change); query the workspace size again.
+extern "C" void sdn_debug_set_x3_expand(sdn_unet* u, int on) {
+  if (!u || u->x3_expand == (on != 0)) return;
+  u->x3_expand = on != 0;
+  drop_graphs(u);
+  u->plans.clear();
+}
+
 extern "C" void sdn_debug_set_ln_fold(sdn_unet* u, int on) {
   if (!u) return;
   u->ln_fold = on != 0;

@@ -151,23 +151,26 @@ class UNet2DConditionModel:
                 sd[name] = (torch.rand(shape, generator=g) * 2 - 1) * bound
         return sd
 
+    def _pack_one(self, p: dict, t: torch.Tensor) -> torch.Tensor:
+        """One state_dict tensor in the engine layout, as raw bytes (uint8, 1-D)."""
+        t = t.detach().float().cpu()
+        k = p["kind"]
+        if k == P_CONV3X3:
+            t = t.permute(0, 2, 3, 1).reshape(p["rows"], p["cols"])
+        elif k in (P_MAT, P_GEGLU_MAT):
+            t = t.reshape(p["rows"], p["cols"])
+        if k in (P_GEGLU_MAT, P_GEGLU_VEC):
+            t = _interleave16(t)
+        if k not in (P_VEC_F32, P_GEGLU_VEC):
+            t = t.to(self.dtype)
+        return t.contiguous().view(torch.uint8).reshape(-1)
+
     def pack_state_dict(self, sd: dict) -> torch.Tensor:
         """CPU uint8 buffer in the engine layout."""
         buf = torch.zeros(self.weight_bytes, dtype=torch.uint8)
         for p in self.manifest:
-            t = sd[p["name"]].detach().float().cpu()
-            k = p["kind"]
-            if k == P_CONV3X3:
-                t = t.permute(0, 2, 3, 1).reshape(p["rows"], p["cols"])
-            elif k in (P_MAT, P_GEGLU_MAT):
-                t = t.reshape(p["rows"], p["cols"])
-            if k in (P_GEGLU_MAT, P_GEGLU_VEC):
-                t = _interleave16(t)
-            if k in (P_VEC_F32, P_GEGLU_VEC):
-                raw = t.contiguous().view(torch.uint8)
-            else:
-                raw = t.to(self.dtype).contiguous().view(torch.uint8).reshape(-1)
-            buf[p["offset"]:p["offset"] + raw.numel()] = raw.reshape(-1)
+            raw = self._pack_one(p, sd[p["name"]])
+            buf[p["offset"]:p["offset"] + raw.numel()] = raw
         return buf
 
     def load_state_dict(self, sd: dict, device="cuda"):
@@ -175,7 +178,13 @@ class UNet2DConditionModel:
         if missing:
             raise KeyError(f"state_dict lacks {len(missing)} keys, e.g. {missing[:3]}")
         _lib.require_gpu()
-        self._weights = self.pack_state_dict(sd).to(device)
+        # tensor by tensor into the device buffer: the engine-derived regions between them (LayerNorm-folded / product weights;
+        # in the bf16x3 plan the expanded bf16 copy of every matrix, 1.5 x the f32 weights) never exist on the host
+        buf = torch.zeros(self.weight_bytes, dtype=torch.uint8, device=device)
+        for p in self.manifest:
+            raw = self._pack_one(p, sd[p["name"]])
+            buf[p["offset"]:p["offset"] + raw.numel()].copy_(raw)
+        self._weights = buf
         return self._prepare()
 
     def load_synthetic_on_device(self, seed: int = 1234, device="cuda"):

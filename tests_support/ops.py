@@ -139,3 +139,62 @@ def ffn_fused(x, w1, gamma, beta, bias1, w_cat, b_cat, residual, col_stats=None,
     _lib.check(sda.lib().sdn_ffn_geglu_fused(code, M, K, p(x), p(stats), p(wf), p(c), p(dv), p(w_cat), p(b_cat), p(residual), p(out),
                                              p(col_stats), _lib.stream_ptr()), "sdn_ffn_geglu_fused")
     return out
+
+
+# ---- bf16x3 by operand expansion (include/sdn.h): triples, expanded weights, sdn_gemm_bf16 with x3_out ------------------------
+def split3(x, x2=None):
+    """f32 [rows, c1] (++ [rows, c2]) -> bf16 triple [rows, 3 (c1 + c2)] = [hi | lo | hi]."""
+    rows, c1 = x.shape
+    c2 = 0 if x2 is None else x2.shape[1]
+    out = torch.empty((rows, 3 * (c1 + c2)), dtype=BF, device=x.device)
+    _lib.check(sda.lib().sdn_split3(x.data_ptr(), None if x2 is None else x2.data_ptr(), rows, c1, c2, out.data_ptr(),
+                                    _lib.stream_ptr()), "sdn_split3")
+    return out
+
+
+def triple_value(t):
+    """What a triple stands for: hi + lo, as float64 [rows, C] (and the check that its two hi planes agree)."""
+    C3 = t.shape[-1]
+    C_ = C3 // 3
+    hi, lo, hi2 = t[..., :C_], t[..., C_:2 * C_], t[..., 2 * C_:]
+    assert torch.equal(hi, hi2)
+    return hi.double() + lo.double()
+
+
+def expand3(w, group=None):
+    """f32 W [N, K] -> bf16 [N, 3K], every `group` columns expanded to [hi | hi | lo]."""
+    N, K = w.shape
+    out = torch.empty((N, 3 * K), dtype=BF, device=w.device)
+    _lib.check(sda.lib().sdn_expand3_weights(w.data_ptr(), N, K, group or K, out.data_ptr(), _lib.stream_ptr()), "sdn_expand3_weights")
+    return out
+
+
+def gemm_x3t(a3, w3, N, K, *, bias=None, rowbias=None, residual=None, conv=None, act=0, x3_out=1, rows_per_batch=0, out_kind=1,
+             n_valid=0):
+    """sdn_gemm_bf16 over a triple A operand [M, 3K] (or an NHWC triple map for conv) and an expanded weight [N, 3K]:
+    K / Cin below are the LOGICAL sizes.  x3_out 1 -> f32 [M, N]; 2 (GEGLU) / 3 -> triple [M, 3 N'] ; 0 -> out_kind as given."""
+    d = _lib.GemmDesc()
+    if conv:
+        B = a3.shape[0]
+        d.a_mode = 1
+        d.Hs, d.Ws, d.Cin, d.Ho, d.Wo = conv["Hs"], conv["Ws"], 3 * conv["Cin"], conv["Ho"], conv["Wo"]
+        d.stride, d.upsample, d.asym_pad = conv.get("stride", 1), conv.get("upsample", 0), conv.get("asym_pad", 0)
+        M = B * d.Ho * d.Wo
+        rows_per_batch = d.Ho * d.Wo
+    else:
+        M = a3.shape[0]
+    d.M, d.N, d.K, d.act, d.out_kind, d.x3_out, d.n_valid = M, N, 3 * K, act, out_kind, x3_out, n_valid
+    d.rows_per_batch = rows_per_batch
+    if rowbias is not None:
+        d.ld_rowbias = rowbias.stride(0)
+    width = N // 2 if act == 2 else N
+    if x3_out == 1:
+        out = torch.empty((M, width), dtype=torch.float32, device=a3.device)
+    elif x3_out in (2, 3):
+        out = torch.empty((M, 3 * width), dtype=BF, device=a3.device)
+    else:
+        out = torch.empty((M // rows_per_batch, n_valid or N, rows_per_batch), dtype=torch.float32, device=a3.device)
+    p = lambda t: None if t is None else t.data_ptr()
+    _lib.check(sda.lib().sdn_gemm_bf16(C.byref(d), p(a3), None, p(w3), p(bias), p(rowbias), None, p(residual), p(out),
+                                       _lib.stream_ptr()), "sdn_gemm_bf16 (x3_out)")
+    return out
