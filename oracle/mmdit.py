@@ -25,7 +25,10 @@ SD3 = dict(in_channels=16, out_channels=16, sample_size=64, patch_size=2, num_la
 
 
 class OracleMMDiT:
-    def __init__(self, state_dict: dict, config: dict | None = None, act_dtype=None):
+    def __init__(self, state_dict: dict, config: dict | None = None, act_dtype=None, device=None):
+        """`device`: evaluate the same torch ops there (the full 2 B-parameter network over a loop is hours on a few host
+        cores); arithmetic unchanged fp32 (callers switch TF32 off)."""
+        self.device = device
         self.cfg = dict(SD3)
         if config:
             self.cfg.update(config)
@@ -35,7 +38,7 @@ class OracleMMDiT:
             v = v.detach().float()
             if act_dtype is not None and v.dim() > 1:
                 v = v.to(act_dtype).float()
-            self.sd[k] = v
+            self.sd[k] = v if device is None else v.to(device)
 
     def q(self, x):
         return x if self.q_dtype is None else x.to(self.q_dtype).float()
@@ -65,8 +68,8 @@ class OracleMMDiT:
         x = self.q(x + pos)
         # conditioning
         half = c["time_dim"] // 2
-        fr = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
-        ang = torch.full((b, 1), float(timestep)) * fr[None]
+        fr = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half).to(hidden_states.device)
+        ang = torch.full((b, 1), float(timestep), device=hidden_states.device) * fr[None]
         tsin = self.q(torch.cat([torch.cos(ang), torch.sin(ang)], -1))
         te = self.q(F.silu(self.lin(tsin, "time_text_embed.timestep_embedder.linear_1")))
         te = self.lin(te, "time_text_embed.timestep_embedder.linear_2")           # f32

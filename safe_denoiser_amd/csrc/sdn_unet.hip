@@ -261,6 +261,7 @@ struct Builder {
     tri.insert(t.off);
     return t;
   }
+  bool triple_out_next = false;   // the next gemm() writes the triple of its result (its only reader is another x3 GEMM)
   bool x3t_on(const Ref& a) const { return x3t && !x3t_hold && a.space == SP_WS; }
 
   // ---- op emitters ------------------------------------------------------------------------------
@@ -275,17 +276,20 @@ struct Builder {
       Op o; o.kind = OP_GEMM; memset(&o.gd, 0, sizeof(o.gd));
       o.x3t = 1;
       o.gd.M = (int)M; o.gd.N = N; o.gd.K = 3 * K; o.gd.a_mode = SDN_A_PLAIN; o.gd.act = act_; o.gd.out_kind = SDN_OUT_F32;
-      o.gd.x3_out = act_ == SDN_ACT_GEGLU ? 2 : 1; o.gd.rows_per_batch = rows_per_batch; o.gd.ld_rowbias = ld_rowbias;
+      const bool tri_o = triple_out_next && act_ == SDN_ACT_NONE;
+      triple_out_next = false;
+      o.gd.x3_out = act_ == SDN_ACT_GEGLU ? 2 : (tri_o ? 3 : 1); o.gd.rows_per_batch = rows_per_batch; o.gd.ld_rowbias = ld_rowbias;
       o.a = au; o.w = x3_weight(w, N, K, K); o.bias = bias; o.rowbias = rowbias; o.residual = residual; o.out = out;
       o.flops = 2.0 * (double)M * (double)N * (double)K;
       o.bytes = 6.0 * ((double)M * K + (double)N * K) + 4.0 * (double)M * (act_ == SDN_ACT_GEGLU ? 0.75 * N : N) +
                 (residual.space != SP_NONE ? 4.0 * (double)M * N : 0.0);
       snprintf(o.label, sizeof(o.label), "k_gemm<%d>x3", sdn_gemm_pick_tile((int)M, N, 3 * K, act_));
       push_gemm(o);
-      if (act_ == SDN_ACT_GEGLU) tri.insert(out.off);
+      if (act_ == SDN_ACT_GEGLU || tri_o) tri.insert(out.off);
       if (tmp.off >= 0) drop(tmp);                            // stream order: the next op may reuse it
       return;
     }
+    triple_out_next = false;
     Op o; o.kind = OP_GEMM; memset(&o.gd, 0, sizeof(o.gd));
     o.gd.M = (int)M; o.gd.N = N; o.gd.K = K; o.gd.a_mode = SDN_A_PLAIN; o.gd.K1 = K1; o.gd.act = act_;
     o.gd.out_kind = out_kind; o.gd.n_valid = n_valid; o.gd.rows_per_batch = rows_per_batch; o.gd.ld_rowbias = ld_rowbias;
@@ -613,6 +617,7 @@ struct Builder {
       return;
     }
     Act h4 = act(rows, C, hw, x.side);
+    triple_out_next = x3t;                                  // (bf16x3 plan: proj_out is its only reader)
     gemm(rows, C, 4 * C, R(ff), f2w, f2b, R(h4), SDN_ACT_NONE, R(h3));
     drop(ff); drop(h3);
     want_stats(out);

@@ -14,7 +14,12 @@ Text encoders (CLIP x2 + T5) are outside the hot path: pass `prom
 output) gives the latents; with a `vae` and `return_latents=False` the call ends like the reference's (:1195-1214) and returns
 `StableDiffusion3PipelineOutput(images=...)` -- `.images` as run_nudity_sdv3.py:351-360 reads it (`return_dict=False`: a tuple;
 `output_type="latent"`: the latents in `.images`).
-The reference draws z from the GLOBAL torch RNG (`randn_like`, :1159); so does this loop unless `noise_fn` is given.
+The reference draws z from the GLOBAL torch RNG (`randn_like`, :1159); so does this loop unless `noise_fn` is given -- the P draws
+of a window step come out of one launch (rng.BatchedNormal.draw_sequence: the same values and the same final generator offset as
+P consecutive `torch.randn` calls on the default CUDA generator).  The projection runs through `conditioning_device` (no host
+synchronisation: the plug-in's dict API reads the score back with .item()), and the loop's tensors are kept across calls.
+(No `latent_repeat` here: the two guidance branches of the MMDiT share nothing but the patch embedding -- their text enters the
+first joint-attention block -- so there is no branch-independent prefix to compute once.)
 Known reference quirk kept out: with `repellency_processor=None` inside the window the reference reads undefined
 names (:1159); here that case simply takes the Euler step.
 """
@@ -41,6 +46,9 @@ class SD3SafeDenoiserPipeline:
         self.transformer, self.scheduler, self.vae = transformer, scheduler, vae
         self.vae_scale_factor = 8
         self.last_stats = {}
+        self._bufs = {}
+        self._rng = {}
+        self.batched_rng = True     # False: one torch.randn per prompt, as the reference's Python loop would draw
 
     @torch.no_grad()
     def __call__(self, prompt=None, height: Optional[int] = None, width: Optional[int] = None,
@@ -113,14 +121,32 @@ class SD3SafeDenoiserPipeline:
         lat = rq(lat).contiguous()
 
         L, st = _lib.lib(), _lib.stream_ptr()
-        x_in = torch.empty((2 * P, C_, s, s), dtype=torch.float32, device=dev)
-        vout = torch.empty_like(x_in)
-        v = torch.empty((P, C_, s, s), dtype=torch.float32, device=dev)
-        x0, x1, z, nxt = (torch.empty_like(v) for _ in range(4))
         D = C_ * s * s
+        key = (P, C_, s, str(dev))
+        if self._bufs.get("key") != key:                                       # persistent across calls (and across steps)
+            f32 = dict(dtype=torch.float32, device=dev)
+            self._bufs = dict(key=key, x_in=torch.empty((2 * P, C_, s, s), **f32), vout=torch.empty((2 * P, C_, s, s), **f32),
+                              **{n: torch.empty((P, C_, s, s), **f32) for n in ("v", "x0", "x1", "z", "a", "b")})
+        bf = self._bufs
+        x_in, vout, v, x0, x1, z = (bf[n] for n in ("x_in", "vout", "v", "x0", "x1", "z"))
+        cur, nxt = bf["a"], bf["b"]
+        cur.copy_(lat)
+        rng = None
+        if noise_fn is None and self.batched_rng:
+            from .rng import BatchedNormal
+            rng = self._rng.get((str(dev), D))
+            if rng is None:
+                rng = self._rng[(str(dev), D)] = BatchedNormal(dev, D)
+        device_proj = hasattr(repellency_processor, "conditioning_device")
+
+        def rq_(x):                                                            # in place: the latents_dtype round trip of a loop buffer
+            if latents_dtype != torch.float32:
+                x.copy_(x.to(latents_dtype))
+            return x
+
         n_win = 0
         for i, t in enumerate(ts):
-            x_in.view(2, P, C_, s, s).copy_(lat)
+            x_in.view(2, P, C_, s, s).copy_(cur)
             tr.forward_into(x_in, t, text, pooled, vout)
             vq = vout if latents_dtype == torch.float32 else vout.to(latents_dtype).float()   # model output is fp16 in the ref
             _lib.check(L.sdn_cfg_combine(vq.data_ptr(), P, 2, D, float(guidance_scale), v.data_ptr(), st), "sdn_cfg_combine")
@@ -128,18 +154,28 @@ class SD3SafeDenoiserPipeline:
                 n_win += 1
                 sigma = t / 1000.0
                 sigma_next = ts[i + 1] / 1000.0 if i + 1 < len(ts) else 0.0
-                _lib.check(L.sdn_flow_endpoints(lat.data_ptr(), v.data_ptr(), lat.numel(), sigma, x0.data_ptr(),
+                _lib.check(L.sdn_flow_endpoints(cur.data_ptr(), v.data_ptr(), cur.numel(), sigma, x0.data_ptr(),
                                                 x1.data_ptr(), st), "sdn_flow_endpoints")
-                x0r = repellency_processor.conditioning(rq(x0), beta_threshold=False)["x_0_hat"].contiguous()
-                for p in range(P):
-                    z[p:p + 1] = draw(p)
-                _lib.check(L.sdn_flow_renoise(x0r.data_ptr(), rq(x1).data_ptr(), z.data_ptr(), lat.numel(), sigma_next,
+                rq_(x0); rq_(x1)
+                if device_proj:                                                # fast_sdv3: x0 <- x0 - scale * neg, in place, no sync
+                    repellency_processor.conditioning_device(x0, beta_threshold=False, want_neg=False)
+                    x0r = x0
+                else:
+                    x0r = repellency_processor.conditioning(x0, beta_threshold=False)["x_0_hat"].float().contiguous()
+                if rng is not None:                                            # the global generator's next P draws, one launch
+                    rng.draw_sequence(torch.cuda.default_generators[dev.index], z, shape1)
+                    rq_(z)                                                     # (randn_like of an fp16 tensor: the f32 normal, rounded)
+                else:
+                    for p in range(P):
+                        z[p:p + 1] = draw(p)
+                _lib.check(L.sdn_flow_renoise(x0r.data_ptr(), x1.data_ptr(), z.data_ptr(), cur.numel(), sigma_next,
                                               nxt.data_ptr(), st), "sdn_flow_renoise")
             else:
-                _lib.check(L.sdn_flow_euler_step(lat.data_ptr(), v.data_ptr(), lat.numel(), sig_step[i], sig_step[i + 1],
+                _lib.check(L.sdn_flow_euler_step(cur.data_ptr(), v.data_ptr(), cur.numel(), sig_step[i], sig_step[i + 1],
                                                  nxt.data_ptr(), st), "sdn_flow_euler_step")
-            lat = rq(nxt).contiguous()
-            nxt = torch.empty_like(lat)
+            rq_(nxt)
+            cur, nxt = nxt, cur
+        lat = cur.clone()                                                       # the loop buffers are reused by the next call
         self.last_stats = {"window_steps": n_win, "prompts": P}
         wrap = (lambda im: StableDiffusion3PipelineOutput(im) if return_dict else (im,))
         if return_latents:

@@ -108,6 +108,24 @@ class BatchedNormal:
         self._gens = None                                                         # the device copy is stale now
         return out
 
+    def draw_sequence(self, generator: torch.Generator, out: torch.Tensor, shape=None):
+        """out[p] <- the p-th of out.shape[0] CONSECUTIVE `torch.randn(shape, generator=generator)` draws (one generator, the
+        draws a Python loop over prompts would make one after the other -- the SD-v3 loop's `randn_like` on the global
+        generator, models/sdv3/safe_denoiser_pipeline.py:1159) in one launch: draw p starts at the generator's offset + p x the
+        per-draw increment."""
+        n = out.shape[0]
+        if not self.ok:
+            shp = shape or (1,) + tuple(out.shape[1:])
+            for p in range(n):
+                out[p:p + 1] = torch.randn(shp, generator=generator, device=self.device, dtype=torch.float32)
+            return out
+        off0 = generator.get_offset()
+        seed = self._signed(generator.initial_seed())
+        self._launch([seed] * n, [off0 + p * self.increment for p in range(n)], None, out)
+        generator.set_offset(off0 + n * self.increment)
+        self._gens = None
+        return out
+
     def skip(self, generators: Sequence[torch.Generator], which: Optional[Sequence[int]] = None):
         """A draw whose values nobody reads (the x0 probe's scheduler.step variance noise): advance the streams only."""
         idx = range(len(generators)) if which is None else which

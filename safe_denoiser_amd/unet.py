@@ -178,6 +178,10 @@ class UNet2DConditionModel:
         if missing:
             raise KeyError(f"state_dict lacks {len(missing)} keys, e.g. {missing[:3]}")
         _lib.require_gpu()
+        if type(self).pack_state_dict is not UNet2DConditionModel.pack_state_dict:
+            # a subclass with its own packing rules (MMDiT position-embedding crop, VAE 1x1 mixers, CLIP key prefixes)
+            self._weights = self.pack_state_dict(sd).to(device)
+            return self._prepare()
         # tensor by tensor into the device buffer: the engine-derived regions between them (LayerNorm-folded / product weights;
         # in the bf16x3 plan the expanded bf16 copy of every matrix, 1.5 x the f32 weights) never exist on the host
         buf = torch.zeros(self.weight_bytes, dtype=torch.uint8, device=device)

@@ -42,6 +42,53 @@ def make_proc(flavour, method, refs, tmpdir, **params):
                                      n_embed=4, proj_ref_path=path, cache_proj_ref=True, **params)
 
 
+def main_sdv3_full():
+    """G8-style FULL-SIZE cases of BASELINE config 4's projection (repellency_methods_fast_sdv3.py:229-271): M = 515 references of
+    the SD-v3 latent shape [16, 64, 64] (D = 65 536: the reference driver's own 512 x 512 default, run_nudity_sdv3.py:357-358).
+    Stored as head / tail / float64 sum / L2 + the largest change, like G8: written to repellency_golden_sdv3_full.npz (the
+    G1-G8 file is left as it is)."""
+    torch.set_num_threads(8)
+    store, meta = {}, []
+
+    def put(name, **arrs):
+        for k, v in arrs.items():
+            if isinstance(v, torch.Tensor):
+                v = v.detach().cpu().numpy()
+            store[f"{name}/{k}"] = np.asarray(v)
+        meta.append(name)
+
+    with tempfile.TemporaryDirectory() as td:
+        m, c, hw = 515, 16, 64
+        refs = chan_norm_refs(m, c, hw, 0)
+        proc = make_proc("fast_sdv3", "kernel_fast", refs, td, scale=0.03)
+        g = torch.Generator().manual_seed(2000)
+        noise = torch.randn(1, c, hw, hw, generator=g)
+        cases = {
+            # an un-normalised query sitting next to reference 7 (after the channel norm its distance is ~1: weights of order 1)
+            "near": 3.0 * (refs[7:8].clone() + 0.0005 * noise),
+            # between two references
+            "between": 2.0 * (0.5 * refs[100:101] + 0.5 * refs[300:301] + 0.0003 * noise),
+            # a random query: every distance ~ 90, every weight underflows against epsilon -> the output is the input
+            "far": noise.clone(),
+            # fp16 input (the SD-v3 pipelines hand over fp16 latents): cast to the references' dtype first
+            "near_f16": (3.0 * (refs[7:8].clone() + 0.0005 * noise)).half(),
+        }
+        for tag, x in cases.items():
+            xin = x.clone()
+            out = proc.conditioning(xin)
+            ox = out["x_0_hat"].reshape(-1)
+            put(f"G8_sdv3_full_{tag}", seed_refs=0, seed_noise=2000, m=m, scale=0.03, epsilon=1e-8,
+                head=ox[:16].float(), tail=ox[-16:].float(), sum64=float(ox.double().sum()), l2_64=float(ox.double().norm()),
+                max_abs_delta=float((out["x_0_hat"].float() - x.float()).abs().max()),
+                delta_l2=float((out["x_0_hat"].double() - x.double()).norm()), out_is_f32=int(out["x_0_hat"].dtype == torch.float32))
+    store["__cases__"] = np.array(meta)
+    out_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "repellency_golden_sdv3_full.npz")
+    np.savez_compressed(out_path, **store)
+    print(f"wrote {out_path}: {meta}")
+    for n in meta:
+        print(n, "max_abs_delta", float(store[n + "/max_abs_delta"]), "delta_l2", float(store[n + "/delta_l2"]))
+
+
 def main():
     torch.set_num_threads(4)
     store = {}
@@ -194,4 +241,7 @@ def main():
 if __name__ == "__main__":
     if not os.path.isdir("/root/reference/repellency"):
         sys.exit("reference not present: golden vectors can only be regenerated in the build container")
-    main()
+    if "--sdv3-full" in sys.argv:
+        main_sdv3_full()
+    else:
+        main()

@@ -246,3 +246,50 @@ def test_g7_goldens_against_product_project(golden, tmp_path):
         assert calls == ([k] if k <= ne else [min(ne, k - i) for i in range(0, k, ne)]), (name, calls)
         n += 1
     assert n == 6
+
+
+@pytest.mark.parametrize("tag", ["near", "between", "far", "near_f16"])
+def test_g8_sdv3_full_size_on_the_hip_path(tmp_path, tag):
+    """BASELINE config 4's projection at full size (M = 515, C = 16, 64 x 64: D = 65 536) through the product's
+    repellency_methods_fast_sdv3 front end vs the goldens captured from the reference's module (make_golden.py --sdv3-full)."""
+    from safe_denoiser_amd.repellency import repellency_methods_fast_sdv3 as sd3rep
+    from tests.test_oracle_repellency import SDV3_FULL, chan_norm_refs, sdv3_full_case
+    z = np.load(SDV3_FULL)
+    c = {k.split("/", 1)[1]: z[k] for k in z.files if k.startswith(f"G8_sdv3_full_{tag}/")}
+    refs = chan_norm_refs(int(c["m"]), 16, 64, int(c["seed_refs"]))
+    x = sdv3_full_case(tag, refs, int(c["seed_noise"]))
+    proc = make_proc(sd3rep, "kernel_fast", refs, tmp_path, scale=float(c["scale"]))
+    out = proc.conditioning(x.clone().cuda())["x_0_hat"]
+    assert out.dtype == torch.float32
+    ox = out.reshape(-1)
+    close(ox[:16], c["head"], rt=2e-5, at=2e-6); close(ox[-16:], c["tail"], rt=2e-5, at=2e-6)
+    close(float(ox.double().sum()), c["sum64"], rt=1e-5, at=5e-3)
+    close(float(ox.double().norm()), c["l2_64"], rt=1e-6)
+    d = float((out.double().cpu() - x.double()).norm())
+    assert abs(d - float(c["delta_l2"])) <= 3e-2 * float(c["delta_l2"]) + 1e-9, (d, float(c["delta_l2"]))
+
+
+def test_fast_sdv3_at_1024_squared_against_the_oracle(tmp_path):
+    """BASELINE config 4 names 1024 x 1024: latents [16, 128, 128], D = 262 144, M = 515 (540 MB of references; the reference's
+    driver runs 512 x 512 and ships no 1024-sized cache).  HIP vs the CPU oracle on a query next to a reference, one
+    between two, a batch of three -- and the size-independent property that a query which IS alpha x reference k (any alpha > 0:
+    the query is channel-normalised) comes back as x - scale (r_k + sum of the others' weighted rows) / (1 + ...)."""
+    from safe_denoiser_amd.repellency import repellency_methods_fast_sdv3 as sd3rep
+    g = torch.Generator().manual_seed(3)
+    refs = orp.channel_normalise(torch.randn(515, 16, 128, 128, generator=g))
+    noise = torch.randn(3, 16, 128, 128, generator=g)
+    x = torch.cat([2.5 * (refs[11:12] + 0.0003 * noise[:1]), 0.7 * (0.5 * refs[1:2] + 0.5 * refs[2:3] + 0.0002 * noise[1:2]), noise[2:3]])
+    proc = make_proc(sd3rep, "kernel_fast", refs, tmp_path, scale=0.03)
+    xg = x.clone().cuda()
+    neg, den, isneg = proc.conditioning_device(xg)
+    for p in range(3):
+        want = orp.kernel_fast_conditioning(x[p:p + 1].clone(), refs, flavour="fast_sdv3", scale=0.03)["x_0_hat"]
+        close(xg[p:p + 1], want, rt=2e-5, at=2e-6)
+    assert float((xg[2].cpu() - x[2]).abs().max()) == 0.0                     # epsilon-dominated: untouched
+    for alpha in (0.1, 7.0):
+        q = (alpha * refs[40:41]).clone().cuda()
+        q0 = q.clone()
+        proc.conditioning_device(q)
+        upd = (q0 - q).cpu() / 0.03                                           # = neg = sum_m w_m r_m / (sum_m w_m + eps)
+        # w_40 = exp(0) = 1; every other reference is ~ sqrt(2) * 128 away: weight exp(-90) -> neg = r_40 / (1 + 1e-8)
+        close(upd, refs[40:41], rt=0, at=1e-6 + 4e-7 * alpha / 0.03)         # (q0 - q is formed in fp32 at the query's magnitude)

@@ -3,6 +3,8 @@
 Tolerance: the oracle uses the same torch CPU ops as the reference, so fp32 results agree to a few ulp;
 rtol=2e-6 / atol=1e-7 is asserted.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -162,3 +164,39 @@ def test_g8_full_size(golden, case):
     close(ox[:16], c["head"], rt=1e-5); close(ox[-16:], c["tail"], rt=1e-5)
     close(float(ox.double().sum()), c["sum64"], rt=1e-6, at=1e-3)
     close(float(ox.double().norm()), c["l2_64"], rt=1e-6)
+
+
+def sdv3_full_case(tag, refs, seed_noise=2000):
+    """Inputs of tests/golden/repellency_golden_sdv3_full.npz (make_golden.py --sdv3-full), rebuilt from their seeds."""
+    noise = torch.randn(1, 16, 64, 64, generator=torch.Generator().manual_seed(seed_noise))
+    if tag in ("near", "near_f16"):
+        x = 3.0 * (refs[7:8].clone() + 0.0005 * noise)
+        return x.half() if tag == "near_f16" else x
+    if tag == "between":
+        return 2.0 * (0.5 * refs[100:101] + 0.5 * refs[300:301] + 0.0003 * noise)
+    return noise.clone()
+
+
+SDV3_FULL = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "repellency_golden_sdv3_full.npz")
+
+
+@pytest.mark.parametrize("tag", ["near", "between", "far", "near_f16"])
+def test_g8_sdv3_full_size(tag):
+    """BASELINE config 4's projection at its real size (M = 515 references of [16, 64, 64], D = 65 536) against the reference's
+    own repellency_methods_fast_sdv3 (VERDICT r3 missing #4): head / tail / float64 sum / L2 of the output and the size of the
+    update.  `near`: weights of order 1; `between`: a 7e-5 update (cancellation-limited: 2 % on its norm); `far`: every weight
+    underflows against epsilon, output = input; `near_f16`: the fp16 latents the SD-v3 pipelines hand over."""
+    z = np.load(SDV3_FULL)
+    c = {k.split("/", 1)[1]: z[k] for k in z.files if k.startswith(f"G8_sdv3_full_{tag}/")}
+    refs = chan_norm_refs(int(c["m"]), 16, 64, int(c["seed_refs"]))
+    x = sdv3_full_case(tag, refs, int(c["seed_noise"]))
+    out = orp.kernel_fast_conditioning(x.clone(), refs, flavour="fast_sdv3", scale=float(c["scale"]), epsilon=float(c["epsilon"]))["x_0_hat"]
+    assert out.dtype == torch.float32 and int(c["out_is_f32"]) == 1
+    ox = out.reshape(-1)
+    close(ox[:16], c["head"], rt=1e-5); close(ox[-16:], c["tail"], rt=1e-5)
+    close(float(ox.double().sum()), c["sum64"], rt=1e-6, at=1e-3)
+    close(float(ox.double().norm()), c["l2_64"], rt=1e-6)
+    d = float((out.double() - x.double()).norm())
+    assert abs(d - float(c["delta_l2"])) <= 2e-2 * float(c["delta_l2"]) + 1e-9
+    if tag == "far":
+        assert d == 0.0
