@@ -513,6 +513,41 @@ k_clip_embed_f32(const int* __restrict__ ids, const float* __restrict__ tok, con
   }
 }
 
+// conv_in, weights in LDS: a workgroup keeps the whole [9 cin][cout] weight (transposed: a thread's 4 output channels are one
+// 16-byte LDS read per tap, conflict-free) and walks `ppb` pixels; thread = (pixel slot, quad of output channels); the 9 cin
+// latent values of a pixel are wave-broadcast global loads.  Same products in the same (tap, channel) order as k_conv_in_f32
+// below, which stays for shapes this form does not take (cout % 4, weights over 64 KB).
+__global__ void __launch_bounds__(256)
+k_conv_in_f32_lds(const float* __restrict__ lat, const float* __restrict__ w, const float* __restrict__ bias, int B, int cin, int H,
+                  int W, int cout, int ppb, float* __restrict__ out) {
+  extern __shared__ float swt[];                                             // [9 cin][cout]
+  const int K = 9 * cin, cq = cout / 4;
+  for (int e = threadIdx.x; e < K * cout; e += 256) { const int co = e / K, k = e - co * K; swt[k * cout + co] = w[e]; }
+  __syncthreads();
+  const int slots = 256 / cq;                                                // pixels in flight per pass
+  const int slot = threadIdx.x / cq, q = threadIdx.x - slot * cq;
+  if (slot >= slots) return;
+  const long npix = (long)B * H * W;
+  const long p0 = (long)blockIdx.x * ppb;
+  const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 4 * q);
+  for (long pix = p0 + slot; pix < p0 + ppb && pix < npix; pix += slots) {
+    const int x = (int)(pix % W), y = (int)((pix / W) % H), b = (int)(pix / ((long)W * H));
+    f32x4 acc = bv;
+    for (int ty = 0; ty < 3; ++ty)
+      for (int tx = 0; tx < 3; ++tx) {
+        const int iy = y + ty - 1, ix = x + tx - 1;
+        if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+        for (int c = 0; c < cin; ++c) {
+          const float v = lat[(((long)b * cin + c) * H + iy) * W + ix];
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(&swt[((ty * 3 + tx) * cin + c) * cout + 4 * q]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] = fmaf(v, wv[e], acc[e]);
+        }
+      }
+    *reinterpret_cast<f32x4*>(out + pix * cout + 4 * q) = acc;
+  }
+}
+
 // conv_in: 3x3, pad 1, fp32 NCHW latent -> NHWC f32; one thread per (pixel, output channel).  w is [Cout][ky][kx][Cin].
 __global__ void __launch_bounds__(256)
 k_conv_in_f32(const float* __restrict__ lat, const float* __restrict__ w, const float* __restrict__ bias, int B, int cin,
@@ -1158,6 +1193,15 @@ extern "C" int sdn_conv_in_f32(const float* latents_nchw, const void* w, const f
                                int32_t h, int32_t wd, int32_t cout, void* out_nhwc, void* stream) {
   if (!latents_nchw || !w || !bias || !out_nhwc || batch < 0 || cin <= 0 || h <= 0 || wd <= 0 || cout <= 0) return SDN_E_INVALID;
   if (batch == 0) return SDN_OK;
+  const size_t wbytes = (size_t)9 * cin * cout * 4;
+  if ((cout & 3) == 0 && cout / 4 <= 256 && wbytes <= 64 * 1024 && (reinterpret_cast<uintptr_t>(out_nhwc) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(bias) & 15) == 0) {
+    const int ppb = 64;
+    const long npix = (long)batch * h * wd;
+    hipLaunchKernelGGL(k_conv_in_f32_lds, dim3((unsigned)((npix + ppb - 1) / ppb)), dim3(256), wbytes, (hipStream_t)stream, latents_nchw,
+                       (const float*)w, bias, batch, cin, h, wd, cout, ppb, (float*)out_nhwc);
+    return sdn_launch_status();
+  }
   const long total = (long)batch * h * wd * cout;
   long grid = (total + 255) / 256;
   if (grid > 8192) grid = 8192;

@@ -100,6 +100,20 @@ def test_conv3x3_f32(B, H, Cin, Cout, stride, ups, asym, mode):
     assert rel_l2(out.reshape(B, Ho, Ho, Cout).permute(0, 3, 1, 2), ref) <= TOL
 
 
+@pytest.mark.parametrize("B,cin,H,cout", [(2, 4, 16, 320), (1, 4, 64, 320), (3, 16, 8, 96), (1, 4, 8, 322)])
+def test_conv_in_f32(B, cin, H, cout):
+    """conv_in of the fp32-storage plans (fp32 NCHW latent -> NHWC f32): the weights-in-LDS kernel (cout % 4 == 0) and the
+    one-thread-per-output form behind it, vs F.conv2d."""
+    import safe_denoiser_amd as sda
+    from safe_denoiser_amd import _lib
+    x, w, bias = rnd(B, cin, H, H, seed=41), rnd(cout, cin, 3, 3, seed=42, scale=(9 * cin) ** -0.5), rnd(cout, seed=43)
+    ref = F.conv2d(x.double(), w.double(), bias.double(), padding=1).permute(0, 2, 3, 1)
+    xg, wg, bg = x.cuda(), w.permute(0, 2, 3, 1).contiguous().cuda(), bias.cuda()
+    out = torch.empty(B, H, H, cout, device="cuda")
+    _lib.check(sda.lib().sdn_conv_in_f32(xg.data_ptr(), wg.data_ptr(), bg.data_ptr(), B, cin, H, H, cout, out.data_ptr(), _lib.stream_ptr()), "conv_in f32")
+    assert rel_l2(out, ref) <= 2e-6
+
+
 def test_norms_f32():
     B, hw, c1, c2 = 2, 256, 320, 640
     x, x2 = rnd(B, hw, c1, seed=20) + 3.0, rnd(B, hw, c2, seed=21, scale=0.1) + 50.0       # |mean| >> std: no cancellation allowed

@@ -12,6 +12,10 @@
 //   mix   : the full mix                          -> the ceiling of ANY schedule of this instruction mix
 //   mfma  : the 28 MFMAs alone                    -> the matrix-pipe bound at the clock the chip holds
 //   valu  : the softmax / pack vector work alone  -> the vector-issue bound
+// Round 4 adds the ALTERNATIVE MIX VERDICT r3 #4 asks to be priced (`alt` rows): the second PV row block holds only dims 32..39 and
+// the ones column, so instead of 4 x v_mfma_f32_32x32x16 (128 cycles, 25 % useful) it runs as 4 x v_mfma_f32_16x16x32_bf16 (2 query
+// halves x 2 key halves, 64 cycles) whose B operands are re-laid-out from the same probabilities with 8 cross-lane swaps
+// (v_permlane16_swap / v_permlane32_swap) per query set and tile: 384 instead of 448 matrix cycles per tile and set.
 // Build + run on the GPU box:  hipcc -O3 --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form tools/attn_ceiling.hip -o /tmp/attn_ceiling && /tmp/attn_ceiling
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -97,6 +101,115 @@ __global__ void __launch_bounds__(256) k_mix(float* out, int tiles) {
   out[(size_t)blockIdx.x * 256 + threadIdx.x] = acc;
 }
 
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// the alternative mix: MODE 0 = full, 1 = MFMAs only, 2 = vector work only
+template <int MODE, int QS>
+__global__ void __launch_bounds__(256) k_alt(float* out, int tiles) {
+  const int lane = threadIdx.x & 63;
+  bf16x8 kf[2][3], qf[QS][3], vf[4], vf16[4];
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 3; ++j) _Pragma("unroll") for (int e = 0; e < 8; ++e) kf[i][j][e] = (__bf16)(0.01f * ((lane * 7 + i * 3 + j * 5 + e) % 13 - 6));
+  _Pragma("unroll") for (int s = 0; s < QS; ++s) _Pragma("unroll") for (int j = 0; j < 3; ++j) _Pragma("unroll") for (int e = 0; e < 8; ++e) qf[s][j][e] = (__bf16)(0.02f * ((lane * 5 + s * 3 + j * 7 + e) % 11 - 5));
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int e = 0; e < 8; ++e) { vf[i][e] = (__bf16)(0.03f * ((lane * 3 + i * 5 + e) % 9 - 4)); vf16[i][e] = (__bf16)(0.02f * ((lane + i * 3 + e) % 7 - 3)); }
+  f32x16 o[QS];
+  f32x4 o16[QS][2];
+  float m_hi[QS];
+  _Pragma("unroll") for (int s = 0; s < QS; ++s) { m_hi[s] = -1e30f; _Pragma("unroll") for (int i = 0; i < 16; ++i) o[s][i] = 0.f; _Pragma("unroll") for (int h = 0; h < 2; ++h) o16[s][h] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  f32x16 st[QS][2];
+  _Pragma("unroll") for (int s = 0; s < QS; ++s) _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) _Pragma("unroll") for (int i = 0; i < 16; ++i) st[s][kb][i] = 0.001f * (lane + i + kb);
+  for (int t = 0; t < tiles; ++t) {
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(kf[i][j]));
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) { asm volatile("" : "+v"(vf[i])); asm volatile("" : "+v"(vf16[i])); }
+    if (MODE != 2) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s = 0; s < QS; ++s) {
+          f32x16 z;
+          _Pragma("unroll") for (int i = 0; i < 16; ++i) z[i] = 0.f;
+#pragma unroll
+          for (int j = 0; j < 3; ++j) z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kb][j], qf[s][j], z, 0, 0, 0);
+          st[s][kb] = z;
+        }
+    }
+    if (MODE != 1) {
+#pragma unroll
+      for (int s = 0; s < QS; ++s) {
+        float mx = fmaxf(st[s][0][0], st[s][1][0]);
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mx = fmaxf(fmaxf(mx, st[s][0][i]), st[s][1][i]);
+        const unsigned u = __float_as_uint(mx);
+        const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        m_hi[s] = fmaxf(m_hi[s], mx);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) st[s][kb][i] = __builtin_amdgcn_exp2f(st[s][kb][i]);
+      }
+    }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s = 0; s < QS; ++s) {
+      u32x4 pw[4];                                            // the 4 k-steps' packed probabilities (as in the shipped mix)
+#pragma unroll
+      for (int item = 0; item < 4; ++item) {
+        const int kb = item >> 1, s2 = item & 1;
+        if (MODE != 1) {
+          pw[item].x = pk(st[s][kb][8 * s2 + 0], st[s][kb][8 * s2 + 1]); pw[item].y = pk(st[s][kb][8 * s2 + 2], st[s][kb][8 * s2 + 3]);
+          pw[item].z = pk(st[s][kb][8 * s2 + 4], st[s][kb][8 * s2 + 5]); pw[item].w = pk(st[s][kb][8 * s2 + 6], st[s][kb][8 * s2 + 7]);
+        } else {
+          pw[item].x = __float_as_uint(st[s][kb][8 * s2]); pw[item].y = __float_as_uint(st[s][kb][8 * s2 + 2]);
+          pw[item].z = __float_as_uint(st[s][kb][8 * s2 + 4]); pw[item].w = __float_as_uint(st[s][kb][8 * s2 + 6]);
+        }
+        if (MODE != 2) o[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[item], *reinterpret_cast<bf16x8*>(&pw[item]), o[s], 0, 0, 0);   // dims 0..31
+        else o[s][0] += __uint_as_float(pw[item].x ^ pw[item].y ^ pw[item].z ^ pw[item].w);
+      }
+      // dims 32..47: 16x16x32 tiles.  Their B operand wants, per lane, 8 consecutive keys of ONE query of a 16-query half; the
+      // packed words above hold 8 keys of one of 32 queries -> two cross-lane swaps per k-step re-deal them (8 per set and tile)
+      u32x4 pb[4];
+#pragma unroll
+      for (int item = 0; item < 4; ++item) {
+        pb[item] = pw[item];
+        if (MODE != 1) {
+          const auto a = __builtin_amdgcn_permlane16_swap(pw[item].x, pw[item].y, false, false);
+          const auto b = __builtin_amdgcn_permlane32_swap(pw[item].z, pw[item].w, false, false);
+          pb[item].x = a[0]; pb[item].y = a[1]; pb[item].z = b[0]; pb[item].w = b[1];
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+          if (MODE != 2) o16[s][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf16[2 * h + kh], *reinterpret_cast<bf16x8*>(&pb[2 * kh + h]), o16[s][h], 0, 0, 0);
+          else o16[s][h][0] += __uint_as_float(pb[2 * kh + h].x ^ pb[2 * kh + h].z);
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+  }
+  float acc = 0.f;
+  _Pragma("unroll") for (int s = 0; s < QS; ++s) { acc += m_hi[s]; _Pragma("unroll") for (int i = 0; i < 16; ++i) acc += o[s][i]; _Pragma("unroll") for (int h = 0; h < 2; ++h) acc += o16[s][h][0] + o16[s][h][1] + o16[s][h][2] + o16[s][h][3]; }
+  out[(size_t)blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
+template <int MODE, int QS>
+static double run_alt(int blocks, int tiles, float* out) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL((k_alt<MODE, QS>), dim3(blocks), dim3(256), 0, 0, out, tiles);
+  hipLaunchKernelGGL((k_alt<MODE, QS>), dim3(blocks), dim3(256), 0, 0, out, tiles);
+  hipDeviceSynchronize();
+  hipEventRecord(e0, 0);
+  for (int r = 0; r < 5; ++r) hipLaunchKernelGGL((k_alt<MODE, QS>), dim3(blocks), dim3(256), 0, 0, out, tiles);
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, e0, e1);
+  ms /= 5;
+  const double flop = (double)blocks * 4 * tiles * (4.0 * 32 * QS * 64 * 40);
+  return flop / (ms * 1e-3) / 1e12;
+}
+
 template <int MODE, int QS>
 static double run(int blocks, int tiles, float* out) {
   hipEvent_t e0, e1;
@@ -133,6 +246,13 @@ int main() {
     const int blocks = cus * per_cu;
     printf(" \"qs1_blocks_per_cu_%d\": {\"mix\": %.1f, \"mfma_only\": %.1f, \"valu_only\": %.1f},\n", per_cu,
            run<0, 1>(blocks, tiles, out), run<1, 1>(blocks, tiles, out), run<2, 1>(blocks, tiles, out));
+  }
+  for (int per_cu = 2; per_cu <= 4; per_cu *= 2) {
+    const int blocks = cus * per_cu;
+    printf(" \"alt_pv16_qs2_blocks_per_cu_%d\": {\"mix\": %.1f, \"mfma_only\": %.1f, \"valu_only\": %.1f},\n", per_cu,
+           run_alt<0, 2>(blocks, tiles, out), run_alt<1, 2>(blocks, tiles, out), run_alt<2, 2>(blocks, tiles, out));
+    printf(" \"alt_pv16_qs1_blocks_per_cu_%d\": {\"mix\": %.1f, \"mfma_only\": %.1f, \"valu_only\": %.1f},\n", per_cu,
+           run_alt<0, 1>(blocks, tiles, out), run_alt<1, 1>(blocks, tiles, out), run_alt<2, 1>(blocks, tiles, out));
   }
   printf(" \"peak_bf16_tflops\": 2500.0, \"target_40pct\": 1000.0}\n");
   hipFree(out);
