@@ -322,7 +322,8 @@ int sdn_timestep_embed_f32(float timestep, int32_t batch, int32_t dim, void* out
  * fly into bf16 hi + lo (16 mantissa bits) and each product runs as hi.hi + hi.lo + lo.hi on the bf16 matrix cores
  * (3 x v_mfma_f32_16x16x32_bf16 per 16x16x32 block, f32 accumulation) instead of 8 f32-input MFMAs.  Norms, softmax,
  * epilogues and storage stay f32.  Distance from the reference's fp32 arithmetic (run_nudity.py:277): ~1.5e-5 per UNet
- * forward, 3.4e-5 over the 10-step loop -- inside the north star's 1e-3, which a single 16-bit rounding of the MFMA
+ * forward (1.9e-5 measured in the engine), 5.3e-5 / 5.5e-5 over the 10- / 50-step loop (engine, profiles/round3_parity.json; the
+ * emulation gave 3.4e-5) -- inside the north star's 1e-3, which a single 16-bit rounding of the MFMA
  * operands cannot meet (2.96e-3 fp16 / 2.3e-2 bf16: profiles/round3_precision_ablation.md). */
 int sdn_gemm_x3(const sdn_gemm_desc* d_host, const void* a, const void* a2, const void* w,
                 const float* bias, const float* rowbias, const float* rowgate, const void* residual, void* out,

@@ -588,7 +588,8 @@ __global__ void k_temb_f32(float t_val, const float* __restrict__ t_dev, int B, 
 // lo.lo term is below 2^-17 relative).  3 MFMAs at the 16-bit rate instead of 8 at the f32-input rate for the same
 // 16 x 16 x 32 block: the precision mode's contraction at ~5x the f32-MFMA throughput, with everything else (storage,
 // norms, softmax, epilogues) unchanged f32.  Measured distance from the pure-fp32 reference: ~1.5e-5 per UNet forward,
-// 3.4e-5 over the 10-step loop (profiles/round3_precision_ablation.md) against the north star's 1e-3.
+// 3.4e-5 over the 10-step loop in the emulation (profiles/round3_precision_ablation.md), 5.3e-5 / 5.5e-5 over 10 / 50 steps in the
+// engine (profiles/round3_parity.json), against the north star's 1e-3.
 // ================================================================================================
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;

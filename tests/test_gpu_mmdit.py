@@ -305,7 +305,7 @@ def test_full_sd3_medium_10_step_loop_with_fast_sdv3_repellency_matches_oracle(t
     driver's 512 x 512 default, guidance 3.5, 10 flow-Euler steps of which the first 5 (t >= 780) take the repellency re-noise
     path against M = 64 references of [16, 64, 64], 2 prompts batched vs the per-prompt oracle loop on the same tapes (the
     oracle's MMDiT evaluated by torch on the GPU, TF32 off).  fp16 storage + fp16 latents: bound = measured + 25 % against the
-    pure-fp32 network, with the fp16-emulating oracle alongside."""
+    pure-fp32 network (1.9e-3 measured), with the fp16-emulating oracle alongside (1.3e-3)."""
     from oracle import repellency as orp
     from oracle import schedulers as osch
     from oracle.mmdit import sd3_denoise_one
@@ -356,4 +356,5 @@ def test_full_sd3_medium_10_step_loop_with_fast_sdv3_repellency_matches_oracle(t
         torch.cuda.empty_cache()
     print(f"full SD3-medium, 10-step loop with fast_sdv3 repellency ({st['window_steps']} window steps): rel L2 vs the pure-fp32 oracle "
           f"{['%.2e' % e for e in res['fp32']]}, vs the fp16-emulating oracle {['%.2e' % e for e in res['fp16_emulating']]}")
-    assert max(res["fp32"]) <= 2e-2 and max(res["fp16_emulating"]) <= 2e-2          # set to measured + 25 % once measured (round 4)
+    # measured on MI355X (round 4): 1.86e-3 / 1.85e-3 vs the pure-fp32 network, 1.28e-3 / 1.30e-3 vs the fp16-emulating one; + 25 %
+    assert max(res["fp32"]) <= 2.4e-3 and max(res["fp16_emulating"]) <= 1.65e-3
