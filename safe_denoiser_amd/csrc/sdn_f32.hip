@@ -1098,12 +1098,62 @@ extern "C" int sdn_groupnorm_f32_triple(const void* x, const void* x2, int32_t b
   return groupnorm_f32_impl(1, x, x2, batch, hw, c1, c2, groups, eps, silu, gamma, beta, out_triple, stats_ws, stream);
 }
 
+// LayerNorm with the row held in registers (C % 4 == 0, C <= 64 * 4 * LN_MAXV): one 16-byte load per lane and quad, the mean and
+// the centred sum of squares from the registers, one 16-byte f32 store or three 8-byte triple stores.  One wave per row.
+constexpr int LN_MAXV = 5;                                                   // C <= 1280
+__global__ void __launch_bounds__(256)
+k_layernorm_f32_regs(const float* __restrict__ x, long rows, int c, float eps, const float* __restrict__ gamma,
+                     const float* __restrict__ beta, float* __restrict__ out, int triple) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63, c4 = c >> 2;
+  const float* xr = x + row * c;
+  f32x4 v[LN_MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    const int q = lane + 64 * j;
+    v[j] = q < c4 ? *reinterpret_cast<const f32x4*>(xr + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+  }
+  const float mean = wave_sum(s) / (float)c;
+  float qs = 0.f;
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    if (lane + 64 * j < c4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = v[j][e] - mean; qs = fmaf(d, d, qs); }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(qs) / (float)c + eps);
+  unsigned short* row3 = reinterpret_cast<unsigned short*>(out) + row * 3 * c;
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    const int q = lane + 64 * j;
+    if (q >= c4) continue;
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + 4 * q), be = *reinterpret_cast<const f32x4*>(beta + 4 * q);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mean) * rstd * ga[e] + be[e];
+    if (triple) {
+      store_triple2(row3, c, 4 * q, o[0], o[1]);
+      store_triple2(row3, c, 4 * q + 2, o[2], o[3]);
+    } else {
+      *reinterpret_cast<f32x4*>(out + row * c + 4 * q) = o;
+    }
+  }
+}
+
 static int layernorm_f32_impl(int triple, const void* x, int64_t rows, int32_t c, float eps, const float* gamma, const float* beta,
                               void* out, void* stream) {
   if (!x || !gamma || !beta || !out || rows < 0 || c <= 0 || (triple && (reinterpret_cast<uintptr_t>(out) & 3))) return SDN_E_INVALID;
   if (rows == 0) return SDN_OK;
-  hipLaunchKernelGGL(k_layernorm_f32, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)x,
-                     (long)rows, c, eps, gamma, beta, (float*)out, triple);
+  if ((c & 3) == 0 && c <= 64 * 4 * LN_MAXV && al16(x) && al16(gamma) && al16(beta) && (reinterpret_cast<uintptr_t>(out) & (triple ? 7 : 15)) == 0)
+    hipLaunchKernelGGL(k_layernorm_f32_regs, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)x,
+                       (long)rows, c, eps, gamma, beta, (float*)out, triple);
+  else
+    hipLaunchKernelGGL(k_layernorm_f32, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)x,
+                       (long)rows, c, eps, gamma, beta, (float*)out, triple);
   return sdn_launch_status();
 }
 extern "C" int sdn_layernorm_f32(const void* x, int64_t rows, int32_t c, float eps, const float* gamma, const float* beta,
