@@ -175,6 +175,7 @@ SIGNATURES = {
     "sdn_masked_attention_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "sdn_unet_prepare": (C.c_int, [_vp, _vp, _vp]),
     "sdn_unet_set_graph_mode": (None, [_vp, _i32]),
+    "sdn_unet_set_text_version": (None, [_vp, C.c_uint64]),
     "sdn_unet_set_split_k": (None, [_vp, _i32]),
     "sdn_unet_profile_next": (None, [_vp]),
     "sdn_unet_profile_read": (C.c_int, [_vp, C.POINTER(ProfileRow), _i32]),

@@ -549,7 +549,15 @@ int sdn_gemm_pick_tile(int M, int N, int K, int act, int epilogue_reads) {
   if (g_gemm_variant == 2) return nrep;                      // debug: heuristics off
   // big tile (256 rows, 8 waves, 1 block/CU) when it still fills the chip: >= ~3/4 of the 256 CUs get a tile
   if (g_gemm_variant != 3) {
-    const int big = (N % 320 == 0) ? 10 : ((N % 256 == 0) ? 8 : 0);
+    int big = (N % 320 == 0) ? 10 : ((N % 256 == 0) ? 8 : 0);
+    // N divisible by both (1280): one workgroup per CU runs whole waves of 256 tiles, so a grid of 192 tiles of 256 x 320 (the
+    // 8x8-level convs at 3 x 64 samples: M = 12288, N = 1280) leaves a quarter of the chip idle for the whole launch, while the
+    // same problem as 240 tiles of 256 x 256 fills 94 % of it with tiles 20 % shorter.  Cost = waves x tile width; ties keep 320.
+    if (big == 10 && N % 256 == 0 && act == SDN_ACT_NONE && g_gemm_variant != 14) {                     // variant 14: rule off (A/B)
+      const long tm = (M + 255) / 256;
+      const long w10 = (tm * (N / 320) + 255) / 256 * 320, w8 = (tm * (N / 256) + 255) / 256 * 256;
+      if (w8 < w10) big = 8;
+    }
     // Round 1 kept short k loops (K = 320 .. 1280) on the 2-blocks-per-CU tile: with one block per CU nothing hides a tile's
     // epilogue, and that epilogue was then as long as the k loop.  After the lean epilogues and the cheaper GELU the picture
     // (tools/bench_gemm.py, round 2, B = 128) is: the big tile WINS 17-30 % on every short-K shape whose epilogue only computes
@@ -584,7 +592,8 @@ static int sdn_gemm_impl(int dtype, const sdn_gemm_desc* d, const void* a, const
   if (x3 && ((x3 == 2) != (d->act == SDN_ACT_GEGLU) || (x3 != 2 && d->act != SDN_ACT_NONE) || (residual && !al16(residual)) || !al16(out)))
     return SDN_E_INVALID;
   // (in the bf16x3 plan the residual rides in the accumulators from the start: it is not an epilogue read)
-  const int nrep = sdn_gemm_pick_tile(d->M, d->N, d->K, d->act, ((residual && !x3) || rowgate) ? 1 : 0);
+  int nrep = sdn_gemm_pick_tile(d->M, d->N, d->K, d->act, ((residual && !x3) || rowgate) ? 1 : 0);
+  if ((ln_c || ln_d) && nrep == 8 && d->N % 320 == 0) nrep = 10;          // (the LayerNorm-folded forms have no 256-wide instantiation)
   if (!al16(a) || !al16(w) || (a2 && !al16(a2)) || (residual && (reinterpret_cast<uintptr_t>(residual) & 7)) ||
       (reinterpret_cast<uintptr_t>(out) & 7) || (bias && !al16(bias)) || (rowbias && !al16(rowbias)))
     return SDN_E_INVALID;

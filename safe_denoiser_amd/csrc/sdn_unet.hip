@@ -34,7 +34,8 @@
 
 namespace {
 
-enum Space { SP_NONE = 0, SP_W = 1, SP_WS = 2, SP_LATENTS = 3, SP_TEXT = 4, SP_OUT = 5, SP_POOLED = 6 };
+enum Space { SP_NONE = 0, SP_W = 1, SP_WS = 2, SP_LATENTS = 3, SP_TEXT = 4, SP_OUT = 5, SP_POOLED = 6,
+             SP_KV = 7 };   // SP_KV: the workspace's persistent tail (text K / V slots: written by one op, read by one op, never recycled)
 struct Ref { int space = SP_NONE; int64_t off = 0; };
 
 enum OpKind { OP_TEMB, OP_CONV_IN, OP_GEMM, OP_GN, OP_LN, OP_ATTN, OP_PATCHIFY, OP_UNPATCHIFY, OP_LATENT_MIX, OP_SOFTMAX,
@@ -48,6 +49,7 @@ struct Op {
   Ref col, cols1, cols2;     // GEMM: column partials to emit; GroupNorm: partials of its input(s) to reduce instead of reading
   Ref ln_c, ln_d, ln_stats;  // GEMM with LayerNorm folded in (sdn_gemm_ln_*); ln_stats unset = statistics inside the kernel
   int ln = 0;
+  int text_kv = 0;           // cross-attention K / V projection of the TEXT operand: skipped while the caller's text version stands
   int x3t = 0;               // bf16x3 plan: this GEMM runs on sdn_gemm_bf16 over triple operands (gd holds the EXPANDED K / Cin)
   int tri_out = 0;           // bf16x3 plan: GroupNorm / LayerNorm / attention write the bf16 hi|lo|hi triple a GEMM will read
   int n1 = 0, mod = 0, ld_mod = 0, patch = 0;
@@ -117,6 +119,7 @@ struct Plan {
   int64_t tscalar_off = -1;          // 256-byte workspace slot holding the step's timestep (graph mode)
   std::vector<Op> ops;
   int64_t ws_bytes = 0;
+  int64_t kv_base = 0;               // byte offset of the persistent tail inside the workspace (= the recycled arena's peak)
   double flops = 0.0, attn_flops = 0.0;
 };
 
@@ -151,6 +154,13 @@ struct sdn_unet {
                                         // contracted into ONE GEMM over [ff | h3] with the product weight (sdn_linear_pair_fold)
   struct FoldJob { int64_t w, gamma, beta, bias, wf, c, d; int rows, cols; int kind = 0; int group = 0; };   // kind 0: LayerNorm fold; 1: linear pair; 2: bf16x3 weight expansion (sdn_expand3_weights)
   std::vector<FoldJob> fold_jobs;       // what sdn_unet_prepare has to compute into the SDN_P_DERIVED regions
+  // Cross-attention K / V of the text (16 projections per forward, M = batch x 77) depend on the text operand alone, which the
+  // denoising loop changes a handful of times in 50 steps: their outputs live in never-recycled workspace slots and the launches
+  // are skipped while the caller-declared text version (sdn_unet_set_text_version; 0 = undeclared) equals the one they were
+  // computed for, on the same batch / weights / text / workspace addresses.  Same bits: the skipped launches would rewrite them.
+  uint64_t text_version = 0, kv_version = 0;
+  int kv_batch = 0;
+  const void *kv_w = nullptr, *kv_text = nullptr, *kv_ws = nullptr;
   bool x3_expand = true;                // dtype 3: GEMM operands as bf16 triples on the LDS-DMA tiles (false: the f32-staging k_gemm_x3 everywhere)
   bool split_k = false;                 // sdn_unet_set_split_k: small-M GEMMs of the plan take the split-K form (off by
                                         // default: it changes fp32 summation order with the batch size, and batch rows are
@@ -261,6 +271,7 @@ struct Builder {
     tri.insert(t.off);
     return t;
   }
+  int64_t kv_top = 0;             // bytes of persistent text K / V slots handed out so far (space SP_KV)
   bool triple_out_next = false;   // the next gemm() writes the triple of its result (its only reader is another x3 GEMM)
   bool x3t_on(const Ref& a) const { return x3t && !x3t_hold && a.space == SP_WS; }
 
@@ -562,10 +573,21 @@ struct Builder {
       if (!fold3) ln = act(rows, C, hw, x.side);
       at = act(rows, C, hw, x.side);
     }
-    Act kvb = act((int64_t)B * T, 2 * C);
-    gemm((int64_t)B * T, 2 * C, X, Ref{SP_TEXT, text_off}, kv2, Ref(), R(kvb));
-    attention(R(qb), R(kvb), Ref{SP_WS, kvb.off + (int64_t)C * es}, R(at), hw, T, C, C, 2 * C, 2 * C);
-    drop(qb); drop(kvb);
+    if (u->subbatch_bytes > 0) {
+      Act kvb = act((int64_t)B * T, 2 * C);
+      gemm((int64_t)B * T, 2 * C, X, Ref{SP_TEXT, text_off}, kv2, Ref(), R(kvb));
+      attention(R(qb), R(kvb), Ref{SP_WS, kvb.off + (int64_t)C * es}, R(at), hw, T, C, C, 2 * C, 2 * C);
+      drop(qb); drop(kvb);
+    } else {
+      // the text's keys / values live in the workspace's persistent tail: no other op ever writes there, so a forward that is
+      // handed the same text version can skip this projection and read the previous forward's output (sdn_unet::text_version)
+      const Ref kvr{SP_KV, kv_top};
+      kv_top += Arena::up((int64_t)B * T * 2 * C * es);
+      gemm((int64_t)B * T, 2 * C, X, Ref{SP_TEXT, text_off}, kv2, Ref(), kvr);
+      plan->ops.back().text_kv = 1;
+      attention(R(qb), kvr, Ref{SP_KV, kvr.off + (int64_t)C * es}, R(at), hw, T, C, C, 2 * C, 2 * C);
+      drop(qb);
+    }
     Act h3 = act(rows, C, hw, x.side);
     gemm(rows, C, C, R(at), o2w, o2b, R(h3), SDN_ACT_NONE, R(h2));
     drop(h2); drop(at);
@@ -984,7 +1006,8 @@ struct Builder {
     drop(cur);
     conv3x3(g, c.out_channels, npad, cow, cob, Ref{SP_OUT, 0}, 1, 0, Ref(), Ref(), 0, SDN_OUT_F32_NCHW, c.out_channels);
     drop(g);
-    plan->ws_bytes = arena.peak;
+    plan->kv_base = Arena::up(arena.peak);
+    plan->ws_bytes = plan->kv_base + kv_top;
   }
 
   // =================================================================================================
@@ -1270,10 +1293,11 @@ Plan* get_plan(sdn_unet* u, int batch) {
 }
 
 inline const char* resolve(const Ref& r, const char* w, const char* ws, const char* lat, const char* text, const char* out,
-                           const char* pooled) {
+                           const char* pooled, const char* kv = nullptr) {
   switch (r.space) {
     case SP_W: return w + r.off;
     case SP_WS: return ws + r.off;
+    case SP_KV: return kv + r.off;
     case SP_LATENTS: return lat + r.off;
     case SP_TEXT: return text + r.off;
     case SP_OUT: return out + r.off;
@@ -1549,14 +1573,16 @@ static int launch_x3t_gemm(const Op& o, const char* a, const char* w, const floa
 
 // Launches every op of the plan on `stream`.  t_dev != nullptr: the timestep is read from device memory (graph mode).
 static int launch_ops(sdn_unet* u, Plan* p, const char* W, const char* WS, const char* L, const char* T, const char* O,
-                      const char* PL, float timestep, const float* t_dev, bool prof, void* stream) {
-  auto P = [&](const Ref& r) { return resolve(r, W, WS, L, T, O, PL); };
+                      const char* PL, float timestep, const float* t_dev, bool prof, void* stream, bool skip_text_kv = false) {
+  const char* KV = WS + p->kv_base;
+  auto P = [&](const Ref& r) { return resolve(r, W, WS, L, T, O, PL, KV); };
   size_t opi = 0;
   const bool f16 = (u->is_mmdit ? u->mcfg.dtype : u->cfg.dtype) == 1;       // (VAE / CLIP creators mirror dtype into cfg)
   const bool f32 = !u->is_mmdit && u->cfg.dtype >= 2;                        // fp32-storage modes (SD-v1.4 UNet plans only)
   const bool x3 = f32 && u->cfg.dtype == 3;                                  // ... with bf16x3 contractions (sdn_gemm_x3 / sdn_attention_x3)
   for (const Op& o : p->ops) {
     int rc = SDN_OK;
+    if (skip_text_kv && o.text_kv) { ++opi; continue; }       // its output of the previous forward stands (same text version)
     if (prof) (void)hipEventRecord(u->ev[2 * opi], (hipStream_t)stream);
     if (f32) {                                                               // same plan, fp32 operators (sdn_f32.hip)
       switch (o.kind) {
@@ -1759,11 +1785,21 @@ static int run_plan(sdn_unet* u, const void* weights, const float* latents, floa
         if (ei != hipSuccess || !exec) return SDN_E_LAUNCH;
         it = u->graphs.emplace(key, exec).first;
       }
+      u->kv_version = 0;                                       // the replay rewrites every K / V slot: nothing to reuse afterwards
       return hipGraphLaunch(it->second, hs) == hipSuccess ? SDN_OK : SDN_E_LAUNCH;
     }
   }
-  return launch_ops(u, p, W, WS, L, T, O, PL, timestep, nullptr, prof, stream);
+  // text K / V reuse (ordinary launches only: a captured graph holds a fixed op list)
+  const bool declared = u->text_version != 0 && !u->is_mmdit && !u->is_vae && !u->is_clip && u->subbatch_bytes == 0;
+  const bool skip = declared && !prof && u->kv_version == u->text_version && u->kv_batch == batch && u->kv_w == weights &&
+                    u->kv_text == text && u->kv_ws == workspace;
+  const int rc_l = launch_ops(u, p, W, WS, L, T, O, PL, timestep, nullptr, prof, stream, skip);
+  if (rc_l == SDN_OK && declared) { u->kv_version = u->text_version; u->kv_batch = batch; u->kv_w = weights; u->kv_text = text; u->kv_ws = workspace; }
+  else if (!declared) u->kv_version = 0;
+  return rc_l;
 }
+
+void sdn_unet_set_text_version(sdn_unet* u, uint64_t version) { if (u) u->text_version = version; }
 
 void sdn_unet_profile_next(sdn_unet* u) { if (u) u->profile_next = true; }
 

@@ -70,6 +70,7 @@ class SafeDenoiserPipeline:
         self.last_stats = {}
         self.last_safree = None
         self._bufs = {}
+        self._text_ver = 0         # contents counter of the loop's text buffers (unet.set_text_version: K / V of an unchanged text are reused)
         self._rngs = {}
         self.batched_rng = True    # False: per-prompt torch.randn calls (the draws are the same bits either way)
         self.batched_safree = True  # False: the SAFREE projection prompt by prompt (safree.prepare), as the reference runs it
@@ -329,6 +330,11 @@ class SafeDenoiserPipeline:
         tb_plain = bf["tb_plain"].copy_(tb_plain)
         if tb_safe is not None:
             tb_safe = bf["tb_safe"].copy_(tb_safe)
+        # every (re)write of a text buffer gets a fresh version: the UNet recomputes the cross-attention K / V of the text only when
+        # the version it is handed changes (plain / projected / per-prompt mix: a handful of changes over the 50 steps)
+        ver_plain, ver_safe, ver_mix, mix_key = self._text_ver + 1, self._text_ver + 2, 0, None
+        self._text_ver += 2
+        has_ver = hasattr(self.unet, "set_text_version")
         x_in, model_out, eps, x0, noise, nxt = bf["x_in"], bf["model_out"], bf["eps"], bf["x0"], bf["noise"], bf["nxt"]
         bf["lat"].copy_(lat)
         lat = bf["lat"]
@@ -351,12 +357,19 @@ class SafeDenoiserPipeline:
             else:
                 safe_p = [sf["re_attn_t"][0] <= i <= sf["re_attn_t"][1]] * P
             if all(safe_p):
-                tb = tb_safe
+                tb, ver = tb_safe, ver_safe
             elif not any(safe_p):
-                tb = tb_plain
+                tb, ver = tb_plain, ver_plain
             else:
-                pick = torch.tensor(safe_p * nb, device=dev)[:, None, None]
-                tb = bf["tb_mix"].copy_(torch.where(pick, tb_safe, tb_plain))
+                if mix_key != tuple(safe_p):                                        # the set of projected prompts changed: rebuild the mix
+                    pick = torch.tensor(safe_p * nb, device=dev)[:, None, None]
+                    bf["tb_mix"].copy_(torch.where(pick, tb_safe, tb_plain))
+                    mix_key = tuple(safe_p)
+                    self._text_ver += 1
+                    ver_mix = self._text_ver
+                tb, ver = bf["tb_mix"], ver_mix
+            if has_ver:
+                self.unet.set_text_version(ver)
             self.unet.forward_into(lat if shared_latents else x_in, float(t), tb, model_out)
             if sld and g_rows is not None:
                 _lib.check(L.sdn_sld_guidance_rows(model_out.data_ptr(), P, D, g_rows.data_ptr(), sld["scale"], sld["thr"],
@@ -411,6 +424,8 @@ class SafeDenoiserPipeline:
             if callback is not None and i % callback_steps == 0:
                 callback(i, t, lat)
 
+        if has_ver:
+            self.unet.set_text_version(0)                              # undeclared again: a direct caller of the UNet gets plain forwards
         lat = lat.clone()                                              # the loop buffers are reused by the next call
         self.last_stats = {"renoise_draws": n_renoise, "window_steps": n_window, "prompts": P, "branches": nb}
         if self.record_den:

@@ -224,6 +224,12 @@ class UNet2DConditionModel:
         _lib.lib().sdn_unet_set_graph_mode(self._h, 1 if on else 0)
         return self
 
+    def set_text_version(self, version: int = 0):
+        """Declare the contents of the text operand of the next forwards (sdn_unet_set_text_version): while the version, the
+        batch and the buffers stay the same, the cross-attention K / V projections of the text are not recomputed.  0 = undeclared."""
+        _lib.lib().sdn_unet_set_text_version(self._h, int(version))
+        return self
+
     def set_split_k(self, on: bool = True):
         """Small-batch option (sdn_unet_set_split_k): under-filled GEMMs run in split-K form.  Rebuilds the plans, so the
         cached workspaces are dropped.  Off by default (keeps outputs bit-identical across batch sizes)."""

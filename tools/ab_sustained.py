@@ -7,16 +7,21 @@ import os, sys, time, torch
 sys.path.insert(0, os.getcwd())
 import safe_denoiser_amd as sda
 from safe_denoiser_amd.unet import UNet2DConditionModel
-B = 128
-u = UNet2DConditionModel(latent_repeat=2)
+B = int(os.environ.get("B", "128"))
+REP = int(os.environ.get("REP", "2"))
+TEXTVER = os.environ.get("TEXTVER") == "1"       # second arm = the same library with the text version declared (K / V of the text reused)
+u = UNet2DConditionModel(latent_repeat=REP)
 u.load_synthetic_on_device(1234)
-x = torch.randn(B // 2, 4, 64, 64, device="cuda")
+x = torch.randn(B // REP, 4, 64, 64, device="cuda")
 e = u.prepare_text(torch.randn(B, 77, 768, device="cuda"))
 y = torch.empty(B, 4, 64, 64, device="cuda")
 N = int(os.environ.get("N", "150"))
 for rnd in range(3):
     for v in (0, int(os.environ.get("VARIANT", "128"))):
-        sda.lib().sdn_debug_set_gemm_variant(v)
+        if TEXTVER:
+            u.set_text_version(5 if v else 0)
+        else:
+            sda.lib().sdn_debug_set_gemm_variant(v)
         u._ws = {}
         u.forward_into(x, 981.0, e, y); torch.cuda.synchronize()
         t0 = time.perf_counter()
