@@ -650,7 +650,7 @@ def main():
             if hit:
                 traffic = sum(r["hbm_bytes_per_launch"] * r["launches"] for r in hit) / sum(r["launches"] for r in hit)
                 traffic_src = (f"profiles/{os.path.basename(cands[-1])} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected; "
-                               f"git {meta.get('git_head', '?')[:10]}, same libsdn.so as this run, batch {meta.get('batch', '?')})")
+                               f"git {(meta.get('git_head') or '?')[:10]}, same libsdn.so as this run, batch {meta.get('batch', '?')})")
             else:
                 traffic_src = f"profiles/{os.path.basename(cands[-1])} has no row for {dom}"
     # matrix-pipe utilisation of the same kernel from the SQ counter passes (tools/pmc_mfma.py), under the same sha rule
