@@ -208,6 +208,9 @@ typedef struct sdn_gemm_desc {
   int32_t asym_pad;         /* CONV3X3, stride 2 only: 1 = zero padding (0,1,0,1) (right/bottom only: the VAE encoder's
                                Downsample2D(padding=0) + F.pad) instead of 1 on every side             */
   int32_t split_k;          /* number of k-loop slices for sdn_gemm_splitk_* (0 / 1 = none); plain sdn_gemm_* rejects > 1 */
+  int32_t res_pre;          /* 1 = add the 16-bit residual into the accumulators BEFORE the k loop instead of in the epilogue
+                               (plain 16-bit output, no gate / activation / split-K): the sum is formed in a different order
+                               (bias + residual first), so the last bit of an output may differ from res_pre = 0           */
   int32_t x3_out;           /* sdn_gemm_bf16 inside the bf16x3 plan (see "bf16x3 by operand expansion" below): 0 = off;
                                1 = out is F32 [M, ldc]; 2 = GEGLU, out is a bf16 triple [M, 3 ldc]; 3 = out is a bf16 triple.
                                With any of them `residual` is F32 [M, ldc] and out_kind is ignored                        */

@@ -35,7 +35,7 @@ class RepelParams(C.Structure):
 class GemmDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("M", "N", "K", "a_mode", "K1", "Hs", "Ws", "Cin", "Ho", "Wo", "stride",
                                          "upsample", "act", "out_kind", "rows_per_batch", "ld_rowbias", "ld_rowgate",
-                                         "residual_bcast", "n_valid", "ldc", "asym_pad", "split_k", "x3_out")]
+                                         "residual_bcast", "n_valid", "ldc", "asym_pad", "split_k", "res_pre", "x3_out")]
 
 
 class UnetConfig(C.Structure):

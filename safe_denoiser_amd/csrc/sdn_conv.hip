@@ -124,6 +124,20 @@ k_conv_slab(const GemmArgs g) {
       for (int i = 0; i < 4; ++i) acc[i][j] += rb;
     }
   }
+  if (g.res_pre) {                                           // 16-bit residual into the accumulators, as k_gemm_dma (sdn_gemm_desc.res_pre)
+    const unsigned short* r16 = reinterpret_cast<const unsigned short*>(g.res_pre);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wm * 64 + i * 16 + fr;
+      const unsigned short* rp = r16 + (long)(m < g.M ? m : 0) * g.ldc + n0 + wn * 16 * NREP + fq * 4;
+#pragma unroll
+      for (int j = 0; j < NREP; ++j) {
+        const uint2 rr = *reinterpret_cast<const uint2*>(rp + j * 16);
+        acc[i][j][0] += T::to_f(rr.x & 0xffff); acc[i][j][1] += T::to_f(rr.x >> 16);
+        acc[i][j][2] += T::to_f(rr.y & 0xffff); acc[i][j][3] += T::to_f(rr.y >> 16);
+      }
+    }
+  }
   if (g.x3_out && g.residual) {                              // bf16x3 plan: f32 residual [M, ldc], in the shadow of the first k-tile's DMA
     const float* resf = reinterpret_cast<const float*>(g.residual);
 #pragma unroll

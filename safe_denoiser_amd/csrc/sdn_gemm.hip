@@ -245,6 +245,20 @@ k_gemm_dma(const GemmArgs g) {
     }
   }
 
+  if (g.res_pre) {                                           // 16-bit residual, same place (8 bytes per lane and fragment)
+    const unsigned short* r16 = reinterpret_cast<const unsigned short*>(g.res_pre);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wm * 64 + i * 16 + fr;
+      const unsigned short* rp = r16 + (long)(m < g.M ? m : 0) * g.ldc + n0 + wn * 16 * NREP + fq * 4;
+#pragma unroll
+      for (int j = 0; j < NREP; ++j) {
+        const uint2 rr = *reinterpret_cast<const uint2*>(rp + j * 16);
+        acc[i][j][0] += T::to_f(rr.x & 0xffff); acc[i][j][1] += T::to_f(rr.x >> 16);
+        acc[i][j][2] += T::to_f(rr.y & 0xffff); acc[i][j][3] += T::to_f(rr.y >> 16);
+      }
+    }
+  }
   if (g.x3_out && g.residual) {                              // bf16x3 plan: f32 residual [M, ldc], in the shadow of the first k-tile's DMA
     const float* resf = reinterpret_cast<const float*>(g.residual);
 #pragma unroll
@@ -592,14 +606,19 @@ static int sdn_gemm_impl(int dtype, const sdn_gemm_desc* d, const void* a, const
   if (x3 && ((x3 == 2) != (d->act == SDN_ACT_GEGLU) || (x3 != 2 && d->act != SDN_ACT_NONE) || (residual && !al16(residual)) || !al16(out)))
     return SDN_E_INVALID;
   // (in the bf16x3 plan the residual rides in the accumulators from the start: it is not an epilogue read)
-  int nrep = sdn_gemm_pick_tile(d->M, d->N, d->K, d->act, ((residual && !x3) || rowgate) ? 1 : 0);
+  // res_pre: the 16-bit residual goes into the accumulators before the k loop (plain k_gemm_dma tiles only: not split-K, not the
+  // LayerNorm-folded or column-sum forms, whole-width 16-bit output)
+  const bool res_pre = d->res_pre && residual && !x3 && !rowgate && !d->residual_bcast && d->split_k <= 1 && !partials && !ln_c &&
+                       d->out_kind == SDN_OUT_BF16 && n_valid == d->N && d->act == SDN_ACT_NONE;
+  int nrep = sdn_gemm_pick_tile(d->M, d->N, d->K, d->act, ((residual && !x3 && !res_pre) || rowgate) ? 1 : 0);
   if ((ln_c || ln_d) && nrep == 8 && d->N % 320 == 0) nrep = 10;          // (the LayerNorm-folded forms have no 256-wide instantiation)
   if (!al16(a) || !al16(w) || (a2 && !al16(a2)) || (residual && (reinterpret_cast<uintptr_t>(residual) & 7)) ||
       (reinterpret_cast<uintptr_t>(out) & 7) || (bias && !al16(bias)) || (rowbias && !al16(rowbias)))
     return SDN_E_INVALID;
   GemmArgs g{};
   g.a = (const __bf16*)a; g.a2 = (const __bf16*)a2; g.w = (const __bf16*)w;
-  g.bias = bias; g.rowbias = rowbias; g.rowgate = rowgate; g.residual = (const __bf16*)residual; g.out = out;
+  g.bias = bias; g.rowbias = rowbias; g.rowgate = rowgate; g.residual = res_pre ? nullptr : (const __bf16*)residual; g.out = out;
+  g.res_pre = res_pre ? (const __bf16*)residual : nullptr;
   g.M = d->M; g.N = d->N; g.K = d->K;
   g.a_mode = d->a_mode;
   if (d->a_mode == SDN_A_PLAIN) {
@@ -636,7 +655,7 @@ static int sdn_gemm_impl(int dtype, const sdn_gemm_desc* d, const void* a, const
   {
     const long res_rows = d->residual_bcast ? (long)d->rows_per_batch : (long)d->M;
     const long res_bytes = res_rows * g.ldc * 2;
-    g.res_lds = !x3 && residual != nullptr && al16(residual) && res_bytes < (1L << 31) && g_gemm_variant != 4;   // variant 4: per-fragment loads (A/B)
+    g.res_lds = !x3 && !res_pre && residual != nullptr && al16(residual) && res_bytes < (1L << 31) && g_gemm_variant != 4;   // variant 4: per-fragment loads (A/B)
     g.res_bytes = g.res_lds ? (unsigned)res_bytes : 0u;
   }
   if (col_stats) {                                              // column statistics ride on the staged 16-bit tile

@@ -26,6 +26,8 @@ struct GemmArgs {
   long split_stride;         // bytes between the partial outputs of consecutive slices
   int res_lds;               // residual goes through the LDS staging slab (16-bit staged output, offsets fit 31 bits)
   unsigned res_bytes;        // buffer size of the residual for the DMA's bounds check
+  const __bf16* res_pre;     // 16-bit residual [M, ldc] added into the ACCUMULATORS before the k loop (sdn_gemm_desc.res_pre): its loads
+                             // ride in the shadow of the first k-tile's DMA and the epilogue is the lean no-residual one
   int x3_out;                // bf16x3 plan (operands = bf16 hi|lo|hi triples, K = 3 x the logical K; sdn_gemm_x3t): the residual is F32
                              // [M, ldc], added into the accumulators before the k loop, and the output goes straight from the
                              // registers to global memory: 1 = f32 [M, ldc]; 2 = GEGLU, triple [M, 3 ldc]; 3 = triple [M, 3 ldc]

@@ -161,6 +161,7 @@ struct sdn_unet {
   uint64_t text_version = 0, kv_version = 0;
   int kv_batch = 0;
   const void *kv_w = nullptr, *kv_text = nullptr, *kv_ws = nullptr;
+  bool res_pre = true;                  // attention output projections: residual into the accumulators before the k loop (sdn_gemm_desc.res_pre)
   bool x3_expand = true;                // dtype 3: GEMM operands as bf16 triples on the LDS-DMA tiles (false: the f32-staging k_gemm_x3 everywhere)
   bool split_k = false;                 // sdn_unet_set_split_k: small-M GEMMs of the plan take the split-K form (off by
                                         // default: it changes fp32 summation order with the batch size, and batch rows are
@@ -272,6 +273,7 @@ struct Builder {
     return t;
   }
   int64_t kv_top = 0;             // bytes of persistent text K / V slots handed out so far (space SP_KV)
+  bool res_pre_next = false;      // the next gemm() adds its residual into the accumulators before the k loop (sdn_gemm_desc.res_pre)
   bool triple_out_next = false;   // the next gemm() writes the triple of its result (its only reader is another x3 GEMM)
   bool x3t_on(const Ref& a) const { return x3t && !x3t_hold && a.space == SP_WS; }
 
@@ -301,7 +303,10 @@ struct Builder {
       return;
     }
     triple_out_next = false;
+    const bool rp = res_pre_next && residual.space != SP_NONE && act_ == SDN_ACT_NONE && out_kind == SDN_OUT_BF16 && n_valid == 0 && es == 2;
+    res_pre_next = false;
     Op o; o.kind = OP_GEMM; memset(&o.gd, 0, sizeof(o.gd));
+    o.gd.res_pre = rp ? 1 : 0;
     o.gd.M = (int)M; o.gd.N = N; o.gd.K = K; o.gd.a_mode = SDN_A_PLAIN; o.gd.K1 = K1; o.gd.act = act_;
     o.gd.out_kind = out_kind; o.gd.n_valid = n_valid; o.gd.rows_per_batch = rows_per_batch; o.gd.ld_rowbias = ld_rowbias;
     o.a = a; o.a2 = a2; o.w = w; o.bias = bias; o.rowbias = rowbias; o.residual = residual; o.out = out;
@@ -309,7 +314,7 @@ struct Builder {
     // algorithmic bytes: A + W + the output, + the residual operand when the epilogue adds one (it is read once, 16 bit)
     o.bytes = 2.0 * ((double)M * K + (double)N * K + (double)M * (act_ == SDN_ACT_GEGLU ? N / 2 : N)) +
               (residual.space != SP_NONE ? 2.0 * (double)M * N : 0.0);
-    snprintf(o.label, sizeof(o.label), "k_gemm<%d>", sdn_gemm_pick_tile((int)M, N, K, act_, residual.space != SP_NONE));
+    snprintf(o.label, sizeof(o.label), "k_gemm<%d>%s", sdn_gemm_pick_tile((int)M, N, K, act_, residual.space != SP_NONE && !rp), rp ? "/rp" : "");
     push_gemm(o);
   }
   // Small-M / long-K GEMMs (one-prompt batches) run in split-K form: the partial buffer lives only for this op.
@@ -357,6 +362,8 @@ struct Builder {
       return;
     }
     Op o; o.kind = OP_GEMM; memset(&o.gd, 0, sizeof(o.gd));
+    o.gd.res_pre = (res_pre_next && residual.space != SP_NONE && out_kind == SDN_OUT_BF16 && n_valid == 0 && es == 2) ? 1 : 0;
+    res_pre_next = false;
     o.gd.M = B * Ho * Ho; o.gd.N = n_pad; o.gd.K = 9 * in.C; o.gd.a_mode = SDN_A_CONV3X3;
     o.gd.Hs = in.side; o.gd.Ws = in.side; o.gd.Cin = in.C; o.gd.Ho = Ho; o.gd.Wo = Ho; o.gd.stride = stride;
     o.gd.upsample = upsample; o.gd.asym_pad = asym_pad; o.gd.out_kind = out_kind; o.gd.n_valid = n_valid; o.gd.rows_per_batch = Ho * Ho;
@@ -474,10 +481,12 @@ struct Builder {
       gemm(rows, cout, cin, R(x), scw, scb, R(sc), SDN_ACT_NONE, Ref(), SDN_OUT_BF16, 0, skip ? R(*skip) : Ref(),
            skip ? x.C : 0);
       want_stats(out);
+      res_pre_next = u->res_pre;
       conv3x3(g2, cout, cout, c2w, c2b, R(out), 1, 0, R(sc), Ref(), 0);
       drop(sc);
     } else {
       want_stats(out);
+      res_pre_next = u->res_pre;
       conv3x3(g2, cout, cout, c2w, c2b, R(out), 1, 0, R(x), Ref(), 0);
     }
     drop(g2);
@@ -552,6 +561,7 @@ struct Builder {
               3 * C, 3 * C, 3 * C);
     drop(qkvb);
     Act h2 = act(rows, C, hw, x.side);
+    res_pre_next = u->res_pre;
     gemm(rows, C, C, R(at), o1w, o1b, R(h2), SDN_ACT_NONE, R(h));
     drop(h);
     // cross-attention
@@ -589,6 +599,7 @@ struct Builder {
       drop(qb);
     }
     Act h3 = act(rows, C, hw, x.side);
+    res_pre_next = u->res_pre;
     gemm(rows, C, C, R(at), o2w, o2b, R(h3), SDN_ACT_NONE, R(h2));
     drop(h2); drop(at);
     // GEGLU feed-forward
@@ -634,6 +645,7 @@ struct Builder {
       Ref wcat = derived(pfx + ".proj_out.weight#ff", (int64_t)C * 5 * C * 2), bcat = derived(pfx + ".proj_out.bias#ff", (int64_t)C * 4);
       if (fresh) { sdn_unet::FoldJob j{f2w.off, pow_.off, f2b.off, pob.off, wcat.off, bcat.off, -1, C, 4 * C}; j.kind = 1; u->fold_jobs.push_back(j); }
       want_stats(out);
+      res_pre_next = u->res_pre && C != 320;       // (C = 320 must keep the bits of the one-launch k_ffn320, which adds it in its epilogue)
       gemm(rows, C, 5 * C, R(ff), wcat, bcat, R(out), SDN_ACT_NONE, R(rep > 1 ? *x_full : x), SDN_OUT_BF16, 0, R(h3), 4 * C);
       drop(ff); drop(h3);
       return;
@@ -1542,6 +1554,9 @@ int sdn_mmdit_forward(sdn_unet* u, const void* weights, const float* latents, fl
 // A GEMM of the bf16x3 plan on sdn_gemm_bf16 (triple operands, expanded weights).  The LDS-DMA tiles address each operand with
 // 31-bit byte offsets, and a triple is 1.5 x its f32 tensor: the launch is cut into row chunks (whole samples for a conv) that
 // stay below 2 GiB per operand.  Rows are independent, so the chunks are the same arithmetic.
+static long g_x3_chunk_limit = (1L << 31) - 4096;      // bytes of A operand per launch (tests lower it: sdn_debug_set_x3_chunk_bytes)
+extern "C" void sdn_debug_set_x3_chunk_bytes(long long bytes) { g_x3_chunk_limit = bytes > 0 ? (long)bytes : (1L << 31) - 4096; }
+
 static int launch_x3t_gemm(const Op& o, const char* a, const char* w, const float* bias, const float* rowbias, const char* residual,
                            void* out, void* stream) {
   const sdn_gemm_desc& d = o.gd;
@@ -1549,7 +1564,7 @@ static int launch_x3t_gemm(const Op& o, const char* a, const char* w, const floa
   const long rows_out_unit = conv ? (long)d.Ho * d.Wo : 256;                 // chunk granularity in output rows
   const long a_bytes_unit = conv ? (long)d.Hs * d.Ws * d.Cin * 2 : 256L * d.K * 2;
   const long units = conv ? d.M / rows_out_unit : (d.M + 255) / 256;
-  long per = ((1L << 31) - 4096) / a_bytes_unit;                              // units per launch
+  long per = g_x3_chunk_limit / a_bytes_unit;                                 // units per launch
   if (per < 1) return SDN_E_INVALID;
   if (per > units) per = units;
   const int n_cols = d.x3_out == 2 ? d.N / 2 : d.N;                           // logical output width
@@ -1833,6 +1848,13 @@ void sdn_unet_set_graph_mode(sdn_unet* u, int32_t on) {
 extern "C" void sdn_debug_set_x3_expand(sdn_unet* u, int on) {
   if (!u || u->x3_expand == (on != 0)) return;
   u->x3_expand = on != 0;
+  drop_graphs(u);
+  u->plans.clear();
+}
+
+extern "C" void sdn_debug_set_res_pre(sdn_unet* u, int on) {
+  if (!u || u->res_pre == (on != 0)) return;
+  u->res_pre = on != 0;
   drop_graphs(u);
   u->plans.clear();
 }

@@ -287,3 +287,21 @@ def test_full_sd14_every_mode_10_and_50_step_loops_against_the_fp32_oracle(tmp_p
     for name in res:
         assert res[name]["loop_10"] <= LOOP10_BOUND[name], (name, res[name])
         assert res[name]["loop_50"] <= LOOP50_BOUND[name], (name, res[name])
+
+
+def test_bf16x3_plan_in_row_chunks_gives_the_unchunked_bits():
+    """The operand-expansion GEMMs address each operand with 31-bit offsets, so a launch whose triple operand reaches 2 GiB (B = 96
+    at the 64 x 64 level: 2.26 GB) is cut into row chunks -- whole samples for a convolution (launch_x3t_gemm).  Rows are
+    independent: with the limit lowered to 4 MiB (convs one to three samples at a time, GEMMs 256 ... 2048 rows at a time) the small
+    UNet's output must be bit-identical to the unchunked forward."""
+    import safe_denoiser_amd as sda
+    u = UNet2DConditionModel(text_len=77, precision="bf16x3", latent_repeat=1, **SMALL)
+    u.load_state_dict(u.synthetic_state_dict(11))
+    x, E = rnd(3, 4, 16, 16, seed=1).cuda(), rnd(3, 77, 768, seed=2).cuda()
+    ref = u(x, 801.0, encoder_hidden_states=E).sample.clone()
+    try:
+        sda.lib().sdn_debug_set_x3_chunk_bytes(1 << 22)
+        out = u(x, 801.0, encoder_hidden_states=E).sample
+    finally:
+        sda.lib().sdn_debug_set_x3_chunk_bytes(0)
+    assert torch.equal(out, ref)

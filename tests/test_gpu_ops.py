@@ -571,3 +571,47 @@ def test_slab_ring_convolution_gives_the_implicit_gemm_bits(dt, B, H, Cin, Cout)
     ref = F.conv2d(x[:2].float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), bias, padding=1).permute(0, 2, 3, 1).reshape(-1, Cout)
     out = ops.gemm(x, w2, bias=bias, conv=conv)[:2 * H * H]
     assert rel_l2(out, ref.cpu()) <= (4e-3 if dt == torch.bfloat16 else 6e-4)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_residual_into_the_accumulators_matches_the_epilogue_residual_and_is_tile_invariant(dt):
+    """sdn_gemm_desc.res_pre (round 4): the 16-bit residual of an attention output projection / conv2 / FeedForward-output GEMM is
+    added into the ACCUMULATORS before the k loop (its loads ride under the first k-tile's DMA; the epilogue is the lean one) instead
+    of through the epilogue's staging slab.  The sum is formed in another order -- equal to the epilogue form to one output rounding,
+    and to the fp32 reference within the 16-bit bound -- and the SAME BITS come out of every tile family / the slab-ring convolution
+    (variant 3 = 128-row tile, 13 = slab off)."""
+    g = torch.Generator().manual_seed(41)
+    tol = 4e-3 if dt == torch.bfloat16 else 6e-4
+    # plain GEMM (attention to_out at C = 320 / 640): big tile vs 128-row tile
+    for M, N, K in ((4096 * 3, 320, 320), (3000, 640, 640)):
+        a = torch.randn(M, K, generator=g).to(dt).cuda(); w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dt).cuda()
+        bias = torch.randn(N, generator=g).cuda(); res = torch.randn(M, N, generator=g).to(dt).cuda()
+        ref = a.float() @ w.float().T + bias + res.float()
+        try:
+            _variant(0); pre = ops.gemm(a, w, bias=bias, residual=res, res_pre=1)
+            _variant(3); pre_small = ops.gemm(a, w, bias=bias, residual=res, res_pre=1)
+        finally:
+            _variant(0)
+        epi = ops.gemm(a, w, bias=bias, residual=res)
+        assert torch.equal(pre.view(torch.int16), pre_small.view(torch.int16))
+        assert rel_l2(pre, ref.cpu()) <= tol and rel_l2(epi, ref.cpu()) <= tol
+        # at most one output rounding apart at the magnitude of the summands (~1): where an output is a near-cancellation the two
+        # fp32 sums differ by the accumulation noise of the larger terms, a few of the small result's own ulps
+        ulp = (pre.float() - epi.float()).abs() / epi.float().abs().clamp_min(1.0)
+        assert float(ulp.max()) <= (2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10) * 1.01
+    # conv2 of a resnet (+ GroupNorm column sums): slab-ring kernel vs implicit GEMM
+    B, H, C_ = 48, 32, 320
+    x = torch.randn(B, H, H, C_, generator=g).to(dt).cuda()
+    w2 = (torch.randn(C_, 9 * C_, generator=g) * (9 * C_) ** -0.5).to(dt).cuda()
+    bias = torch.randn(C_, generator=g).cuda(); res = torch.randn(B * H * H, C_, generator=g).to(dt).cuda()
+    conv = dict(Hs=H, Ws=H, Cin=C_, Ho=H, Wo=H)
+    nblk = (B * H * H + 127) // 128
+    cs_a = torch.zeros(nblk, C_, 2, device="cuda"); cs_b = torch.zeros_like(cs_a)
+    try:
+        _variant(13); want = ops.gemm(x, w2, bias=bias, residual=res, conv=conv, col_stats=cs_a, res_pre=1)
+        _variant(0); got = ops.gemm(x, w2, bias=bias, residual=res, conv=conv, col_stats=cs_b, res_pre=1)
+    finally:
+        _variant(0)
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16)) and torch.equal(cs_a, cs_b)
+    epi = ops.gemm(x, w2, bias=bias, residual=res, conv=conv)
+    assert float((got.float() - epi.float()).abs().max()) <= float(epi.float().abs().max()) * (2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10)

@@ -21,7 +21,7 @@ def _fn(base: str, t: torch.Tensor):
 
 
 def gemm(a, w, *, bias=None, rowbias=None, residual=None, a2=None, conv=None, act=0, out_kind=0, n_valid=0,
-         rows_per_batch=0, rowgate=None, residual_bcast=0, split_k=0, col_stats=None):
+         rows_per_batch=0, rowgate=None, residual_bcast=0, split_k=0, col_stats=None, res_pre=0):
     """a [M,K] bf16 (or NHWC map for conv=dict(Hs,Ws,Cin,Ho,Wo,stride,upsample)), w [N,K] bf16."""
     N, K = w.shape
     d = _lib.GemmDesc()
@@ -38,6 +38,7 @@ def gemm(a, w, *, bias=None, rowbias=None, residual=None, a2=None, conv=None, ac
         d.K1 = a.shape[1] if a2 is not None else 0
     d.M, d.N, d.K, d.act, d.out_kind, d.n_valid = M, N, K, act, out_kind, n_valid
     d.rows_per_batch = rows_per_batch
+    d.res_pre = res_pre
     if rowbias is not None:
         d.ld_rowbias = rowbias.stride(0)
     if rowgate is not None:

@@ -18,7 +18,10 @@ y = torch.empty(B, 4, 64, 64, device="cuda")
 N = int(os.environ.get("N", "150"))
 for rnd in range(3):
     for v in (0, int(os.environ.get("VARIANT", "128"))):
-        if TEXTVER:
+        if os.environ.get("RESPRE") == "1":                      # second arm = attention output projections with the epilogue residual (res_pre off)
+            import ctypes as C
+            sda.lib().sdn_debug_set_res_pre(C.c_void_p(u._h.value), 0 if v else 1)
+        elif TEXTVER:
             u.set_text_version(5 if v else 0)
         else:
             sda.lib().sdn_debug_set_gemm_variant(v)
