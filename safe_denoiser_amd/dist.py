@@ -33,6 +33,14 @@ def heartbeat(msg: str, rank: Optional[int] = None):
 _T0 = time.perf_counter()
 
 
+def _single() -> bool:
+    """No collective needed: no process group, or a world of one -- unless SDN_DIST_FORCE_COLLECTIVES=1 (tests: RCCL on the one
+    GPU a box has runs as a one-rank group, and the point is to execute the collectives)."""
+    if not dist.is_initialized():
+        return True
+    return dist.get_world_size() == 1 and os.environ.get("SDN_DIST_FORCE_COLLECTIVES") != "1"
+
+
 def check_device_count(world: int, local: int, share: bool = False):
     """Fail fast, before any rendezvous, when this node cannot give every local rank its own GPU."""
     if not torch.cuda.is_available() or share:
@@ -117,7 +125,7 @@ def valid_case_numbers(n_items: int, rank: int, world: int):
 def warm_up_communicator(device) -> float:
     """RCCL builds its communicator (rings over xGMI, IPC handles) lazily inside the FIRST collective; running a 1-element
     all-reduce here keeps that one-off cost (seconds) out of whatever is timed next.  Returns its wall time in ms."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single():
         return 0.0
     t0 = time.perf_counter()
     t = torch.ones(1, dtype=torch.float32, device=_comm_device(device))
@@ -137,7 +145,7 @@ def _comm_device(device):
 def broadcast_proj_ref(refs: Optional[torch.Tensor], device, src: int = 0) -> torch.Tensor:
     """Rank `src` holds refs [M,C,H,W] fp32; everyone returns the same tensor on `device`.  Verifies the payload
     with an fp64 checksum all-reduced MIN/MAX (cheap, once per run)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single():
         return refs.to(device)
     rank = dist.get_rank()
     cdev = _comm_device(device)
@@ -158,7 +166,7 @@ def broadcast_proj_ref(refs: Optional[torch.Tensor], device, src: int = 0) -> to
 
 
 def broadcast_scalar(value: float, device, src: int = 0) -> float:
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single():
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=_comm_device(device))
     dist.broadcast(t, src=src)
@@ -166,12 +174,12 @@ def broadcast_scalar(value: float, device, src: int = 0) -> float:
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if not _single():
         dist.barrier()
 
 
 def max_over_ranks(value: float, device) -> float:
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single():
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=_comm_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -179,7 +187,7 @@ def max_over_ranks(value: float, device) -> float:
 
 
 def sum_over_ranks(value: float, device) -> float:
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single():
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=_comm_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -188,7 +196,7 @@ def sum_over_ranks(value: float, device) -> float:
 
 def gather_over_ranks(value: float, device) -> list:
     """Every rank's `value`, in rank order, on every rank (end-of-run per-rank counters; never inside the step loop)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single():
         return [float(value)]
     t = torch.tensor([float(value)], dtype=torch.float64, device=_comm_device(device))
     out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
