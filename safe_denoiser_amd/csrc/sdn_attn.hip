@@ -17,6 +17,8 @@
 // K/V tiles are double-buffered in LDS through registers: the global loads of tile t+1 are issued before the
 // MFMAs of tile t and written after them (one barrier per tile).  Head dim is zero-padded inside LDS only; HBM
 // tensors stay packed [B, N, heads*d], i.e. the NHWC token matrix the projections write.
+#include <type_traits>
+
 #include "sdn_common.h"
 #include "sdn_ops.h"
 
@@ -72,6 +74,7 @@ struct AttnArgs {
   int n1, ldq2, ldk2, ldv2, ldo2;
   int head_inner;                    // block order for short key sets, see the block-index decode
   int causal; const int* kmask;      // MASK instantiation only: key <= query; kmask [B, nk] (0 = padded key), nullable
+  int nomax;                         // bf16: first pass without the per-tile running maximum (see "optimistic pass"); 0 = guarded pass only
 };
 
 // Row `row` of sample b in a (possibly two-segment) [B, n, ld] tensor.
@@ -119,7 +122,7 @@ k_attn(const AttnArgs a) {
   constexpr int STAGE = KV * KSTR + KV * VSTR;
   constexpr int ZOFF = 2 * STAGE;             // static block: [1,0,0,0 | 0,0,0,0 | 0 x 8] (16-bit), DMA mode only
   constexpr int NLOAD = (2 * KV * CH + THREADS - 1) / THREADS;   // staged chunks per thread per tile (register staging)
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE + 32];
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE + 48];          // + static block (32 B) + the re-run flag
 
   // K/V tile DMA of the next tile: at the top of the iteration, or (d = 40: +1.5-3 %; d = 80 / 160 lose 3-6 %) after the QK^T MFMAs
   constexpr bool kLateDma = HD == 40;
@@ -159,6 +162,7 @@ k_attn(const AttnArgs a) {
   for (int qs = 0; qs < QS; ++qs) qvalid[qs] = q0 + 32 * qs + r < a.nq;
 
   // ---- one-time LDS init: zero the padding columns, plant the ones column (both stages) ----
+  if (tid == 8) *reinterpret_cast<unsigned*>(smem + ZOFF + 32) = 0u;          // re-run flag of the optimistic pass
   if constexpr (DMA) {
     if (tid < 8) *reinterpret_cast<unsigned*>(smem + ZOFF + tid * 4) = tid == 0 ? (T::pack2(1.0f, 0.0f) & 0xffffu) : 0u;
   } else {
@@ -282,7 +286,20 @@ k_attn(const AttnArgs a) {
     }
   };
 
+  // Optimistic pass (bf16 only).  bf16 and fp32 share an exponent range, so p = 2^s needs no maximum at all as long as the
+  // scores of a query stay inside the range -- and the per-tile maximum (16 v_max3 + a cross-half swap + two ballots per query
+  // set and tile) is ~1/4 of the softmax's vector work in a loop that is bound by vector + matrix issue together.  The first
+  // pass therefore runs WITHOUT it; the row sum (which the MFMA delivers anyway) tells afterwards whether that was sound:
+  // 2^-64 <= sum_k p <= 2^64 bounds every p by 2^64 and puts the largest one above 2^-64 / nk, so nothing overflowed and no
+  // term that matters underflowed (the same window as kGuard below).  Any query of the workgroup outside the window -- or a
+  // NaN -- re-runs the block with the guarded loop (running maximum, re-centring).  SD / CLIP scores sit within +-30.
+  // The two passes are two INSTANCES of the loop (compile-time flag): with one loop and a run-time flag the register
+  // allocator carries both forms' live ranges at once (d = 40: 127 -> 166 VGPRs, one wave per SIMD fewer).
+  SDN_ATS_DECL
   f32x16 o[QS][NDB];
+  float l_tot[QS];
+  auto run_pass = [&](auto safe_c) __attribute__((always_inline)) {
+  constexpr bool safe = decltype(safe_c)::value;
   float m_run[QS], l_run[QS];                              // bf16: per-query exponent offset (0 = none); fp16: running max
   float m_hi[QS];                                          // bf16: running max of the scores (decides re-centring)
 #pragma unroll
@@ -307,7 +324,6 @@ k_attn(const AttnArgs a) {
   }
   __syncthreads();
 
-  SDN_ATS_DECL
   SDN_ATS_MARK(-1)
   SDN_ATS_PRO
   for (int t = 0; t < ntiles; ++t) {
@@ -391,13 +407,16 @@ k_attn(const AttnArgs a) {
     SDN_ATS_MARK(0)                               // DMA issue + K reads + S MFMAs issued
 #pragma unroll
     for (int qs = 0; qs < QS; ++qs) {
-    float mx = fmaxf(st[qs][0][0], st[qs][1][0]);
+    [[maybe_unused]] float mx = 0.f;
+    if constexpr (safe) {
+    mx = fmaxf(st[qs][0][0], st[qs][1][0]);
 #pragma unroll
     for (int i = 1; i < 16; ++i) mx = fmaxf(fmaxf(mx, st[qs][0][i]), st[qs][1][i]);
     {
       const unsigned u = __float_as_uint(mx);
       const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // both halves of the same query
       mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
     }
     if constexpr (OFFSET_FREE) {
     // Offset-free softmax: p = 2^(s - off) with a per-query offset that stays 0 while the tile maxima stay inside
@@ -407,7 +426,7 @@ k_attn(const AttnArgs a) {
     constexpr float kGuard = 64.f;
     m_hi[qs] = fmaxf(m_hi[qs], mx);                                    // running maximum of the scores seen so far
     const float drift = m_hi[qs] - m_run[qs];                          // m_run[qs] holds the current offset (0 until re-centred)
-    if (__builtin_amdgcn_ballot_w64(fabsf(drift) > kGuard) != 0) {       // wave-uniform, rare
+    if (safe && __builtin_amdgcn_ballot_w64(fabsf(drift) > kGuard) != 0) {       // wave-uniform, rare (safe: compile-time)
       // upward: the old sums shrink by 2^-(>64).  Downward can only happen on the first tile (m_hi[qs] never decreases),
       // when the sums are still zero -- the exponent is clamped so that 0 * alpha stays 0 instead of 0 * inf.
       const float m_new = fabsf(drift) > kGuard ? m_hi[qs] : m_run[qs];
@@ -419,7 +438,7 @@ k_attn(const AttnArgs a) {
         for (int i = 0; i < 16; ++i) o[qs][d][i] *= alpha;
       m_run[qs] = m_new;
     }
-    if (__builtin_amdgcn_ballot_w64(m_run[qs] != 0.f) != 0) {                 // some query of this wave has an offset
+    if (safe && __builtin_amdgcn_ballot_w64(m_run[qs] != 0.f) != 0) {                 // some query of this wave has an offset
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -552,19 +571,36 @@ k_attn(const AttnArgs a) {
     __syncthreads();
     SDN_ATS_MARK(4)                               // barrier
   }
+  // ---- row sums; was the optimistic pass sound? ----
+  bool bad = false;
+#pragma unroll
+  for (int qs = 0; qs < QS; ++qs) {
+    if (ONES) {
+      constexpr int row = HD % 32;                  // row of the last O^T block that accumulated sum_k p
+      constexpr int ri = (row >> 3) * 4 + (row & 3);
+      static_assert(((row >> 2) & 1) == 0, "ones row must live in lane half 0");
+      l_tot[qs] = __shfl(o[qs][NDB - 1][ri], r, 64);      // lane r (half 0) holds it for query r
+    } else {
+      l_tot[qs] = l_run[qs] + __shfl_xor(l_run[qs], 32, 64);  // both halves hold partial sums of the same query
+    }
+    bad |= !(l_tot[qs] >= 0x1p-64f && l_tot[qs] <= 0x1p64f);
+  }
+  return bad;
+  };   // run_pass
+  bool rerun = true;
+  if constexpr (OFFSET_FREE) {
+    if (a.nomax) {
+      const bool bad = run_pass(std::false_type{});
+      if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) *reinterpret_cast<volatile unsigned*>(smem + ZOFF + 32) = 1u;
+      __syncthreads();
+      rerun = *reinterpret_cast<volatile unsigned*>(smem + ZOFF + 32) != 0u;
+    }
+  }
+  if (rerun) run_pass(std::true_type{});
   // ---- epilogue: normalise by the row sum ----
 #pragma unroll
   for (int qs = 0; qs < QS; ++qs) {
-  float l_tot;
-  if (ONES) {
-    constexpr int row = HD % 32;                  // row of the last O^T block that accumulated sum_k p
-    constexpr int ri = (row >> 3) * 4 + (row & 3);
-    static_assert(((row >> 2) & 1) == 0, "ones row must live in lane half 0");
-    l_tot = __shfl(o[qs][NDB - 1][ri], r, 64);        // lane r (half 0) holds it for query r
-  } else {
-    l_tot = l_run[qs] + __shfl_xor(l_run[qs], 32, 64);    // both halves hold partial sums of the same query
-  }
-  const float inv = 1.f / l_tot;
+  const float inv = 1.f / l_tot[qs];
   if (qvalid[qs]) {
     unsigned short* orow = const_cast<unsigned short*>(row_ptr<SEG>(a.out, a.out2, a.ldo, a.ldo2, a.n1, a.nq, b, q0 + 32 * qs + r)) + head * HD;
 #pragma unroll
@@ -586,7 +622,268 @@ k_attn(const AttnArgs a) {
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// bf16x3 self-attention on PRE-SPLIT operands (the precision mode's 64 x 64 / 32 x 32 levels).
+//
+// The bf16x3 plan's first attention kernel (k_attention_x3, sdn_f32.hip) takes f32 Q / K / V and splits every K / V tile
+// into bf16 hi + lo on its way into LDS -- per workgroup, i.e. 32 times per tensor at N = 4096, through registers and
+// 2-byte LDS scatter writes (151-184 TFLOP/s).  Here the qkv projection writes its output as hi | lo PAIR rows
+// (sdn_gemm_desc.x3_out = 4: row = [hi(3C) | lo(3C)], the same 4 bytes per element as f32), and this kernel is k_attn's
+// LDS-DMA design run three times per product:
+//   S^T  = Kl Qh^T + Kh Ql^T + Kh Qh^T          (32x32x16 bf16 MFMAs, small terms first; K planes by LDS-DMA, Q in registers)
+//   O^T += Vl^T Ph^T + Vh^T Pl^T + Vh^T Ph^T    (P split in registers: ph = bf16(p), pl = bf16(p - ph); V^T by tr reads)
+// Scores stay unscaled (scaling a pre-split hi / lo pair would re-round it): p = 2^(s c - m c) with c = scale log2 e.
+// The row sum rides in the ones column of the V-hi padding (sum ph + sum pl).  Running maximum, wave-uniform rescale.
+struct AttnPArgs {
+  const unsigned short* q; const unsigned short* k; const unsigned short* v;   // hi planes; the lo plane of a row lies `lo` elements on
+  void* out;
+  int nq, nk, ldq, ldk, ldv, ldo, lo;
+  float c;
+  int heads, nqb, npairs, triple;
+};
+
+template <int HD, int QS>
+__global__ void __launch_bounds__(THREADS)
+k_attn_x3p(const AttnPArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef SdnBF16 T;
+  constexpr int KQ = (HD + 15) / 16, NDB = (HD + 31) / 32, CH = HD / 8;
+  static_assert(HD % 32 != 0, "row sums come from the ones column of the padding");
+  constexpr int KCH = HD == 40 ? 5 : CH + 1, VCH = HD == 40 ? 5 : 12;
+  constexpr int KSTR = KCH * 16, VSTR = VCH * 16;
+  constexpr int OFF_KL = KV * KSTR, OFF_VH = 2 * KV * KSTR, OFF_VL = OFF_VH + KV * VSTR;
+  constexpr int STAGE = 2 * KV * (KSTR + VSTR);
+  constexpr int ZOFF = 2 * STAGE;
+  constexpr int NP = 2 * (KCH + VCH), NPIECE = (NP + 3) / 4;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE + 32];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  int pair, qblk;
+  {
+    const int nqb = a.nqb, id = blockIdx.x;
+    if ((a.npairs & 7) == 0) { const int x = id & 7, j = id >> 3; pair = (j / nqb) * 8 + x; qblk = j - (j / nqb) * nqb; }
+    else { pair = id / nqb; qblk = id - pair * nqb; }
+  }
+  const int head = pair % a.heads, b = pair / a.heads;
+  const int q0 = qblk * (QB * QS) + wid * (32 * QS);
+  bool qvalid[QS];
+#pragma unroll
+  for (int qs = 0; qs < QS; ++qs) qvalid[qs] = q0 + 32 * qs + r < a.nq;
+  if (tid < 8) *reinterpret_cast<unsigned*>(smem + ZOFF + tid * 4) = tid == 0 ? (T::pack2(1.0f, 0.0f) & 0xffffu) : 0u;
+
+  // Q fragments, hi and lo (B operand: lane (r, h) holds Q[q0 + r][16 s + 8 h .. + 8))
+  typename T::v8 qh[QS][KQ], ql[QS][KQ];
+#pragma unroll
+  for (int qs = 0; qs < QS; ++qs)
+#pragma unroll
+    for (int s = 0; s < KQ; ++s) {
+      const int dc = 16 * s + 8 * h;
+      u32x4 vh = (u32x4){0u, 0u, 0u, 0u}, vl = vh;
+      if (qvalid[qs] && dc < HD) {
+        const unsigned short* qp = a.q + ((long)b * a.nq + q0 + 32 * qs + r) * a.ldq + head * HD + dc;
+        vh = *reinterpret_cast<const u32x4*>(qp); vl = *reinterpret_cast<const u32x4*>(qp + a.lo);
+      }
+      qh[qs][s] = *reinterpret_cast<typename T::v8*>(&vh); ql[qs][s] = *reinterpret_cast<typename T::v8*>(&vl);
+    }
+
+  // tile images in a stage: [K hi | K lo | V hi | V lo]; piece p = 64 chunks of one image (as k_attn's DMA mode)
+  unsigned dma_off[NPIECE];
+#pragma unroll
+  for (int i = 0; i < NPIECE; ++i) {
+    const int p = wid + 4 * i;                                   // wave-uniform
+    const bool isv = p >= 2 * KCH;
+    const int pi = isv ? (p - 2 * KCH) % VCH : p % KCH;          // piece inside its image
+    const int e = pi * 64 + lane;
+    const int rowc = isv ? VCH : KCH;
+    const int row = e / rowc, ch = e - row * rowc;
+    dma_off[i] = ch < CH ? (unsigned)(((long)row * (isv ? a.ldv : a.ldk) + head * HD + ch * 8) * 2) : 0x80000000u;
+  }
+  auto dma_issue = [&](int buf, int t) {
+    const long k0 = (long)t * KV;
+    const unsigned short* kb_ = a.k + ((long)b * a.nk + k0) * a.ldk;
+    const unsigned short* vb_ = a.v + ((long)b * a.nk + k0) * a.ldv;
+    const long rk = ((a.nk - k0 - 1) * a.ldk + a.heads * HD) * 2, rv = ((a.nk - k0 - 1) * a.ldv + a.heads * HD) * 2;
+    const __amdgpu_buffer_rsrc_t rs_kh = make_rsrc(kb_, (unsigned)(rk > 0 ? rk : 0));
+    const __amdgpu_buffer_rsrc_t rs_kl = make_rsrc(kb_ + a.lo, (unsigned)(rk > 0 ? rk : 0));
+    const __amdgpu_buffer_rsrc_t rs_vh = make_rsrc(vb_, (unsigned)(rv > 0 ? rv : 0));
+    const __amdgpu_buffer_rsrc_t rs_vl = make_rsrc(vb_ + a.lo, (unsigned)(rv > 0 ? rv : 0));
+    unsigned char* st = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) {
+      const int p = wid + 4 * i;
+      if (p < KCH) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_kh, (lds_ptr_t)(st + p * 1024), 16, dma_off[i], 0, 0, 0);
+      else if (p < 2 * KCH) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_kl, (lds_ptr_t)(st + OFF_KL + (p - KCH) * 1024), 16, dma_off[i], 0, 0, 0);
+      else if (p < 2 * KCH + VCH) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_vh, (lds_ptr_t)(st + OFF_VH + (p - 2 * KCH) * 1024), 16, dma_off[i], 0, 0, 0);
+      else if (p < NP) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_vl, (lds_ptr_t)(st + OFF_VL + (p - 2 * KCH - VCH) * 1024), 16, dma_off[i], 0, 0, 0);
+    }
+  };
+
+  f32x16 o[QS][NDB];
+  float m_run[QS];
+#pragma unroll
+  for (int qs = 0; qs < QS; ++qs) {
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[qs][d][i] = 0.f;
+    m_run[qs] = -1e30f;
+  }
+  const int gi = lane & 15, gq = gi >> 2, gp = gi & 3, gcol = 16 * ((lane >> 4) & 1);
+  const int ntiles = (a.nk + KV - 1) / KV;
+  dma_issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    const unsigned char* sKh = smem + buf * STAGE;
+    const unsigned char* sVh = sKh + OFF_VH;
+    // ---- S^T = K Q^T, three products per k-step ----
+    f32x16 st[QS][2];
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int qs = 0; qs < QS; ++qs)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st[qs][kb][i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < KQ; ++s) {
+        const unsigned char* kp = sKh + (32 * kb + r) * KSTR + (16 * s + 8 * h) * 2;
+        const unsigned char* kq = kp + OFF_KL;
+        if (16 * s + 16 > HD) { if (16 * s + 8 * h >= HD) kp = kq = smem + ZOFF + 16; }   // zero padding of d
+        const typename T::v8 kfh = *reinterpret_cast<const typename T::v8*>(kp), kfl = *reinterpret_cast<const typename T::v8*>(kq);
+#pragma unroll
+        for (int qs = 0; qs < QS; ++qs) st[qs][kb] = T::mfma32(kfl, qh[qs][s], st[qs][kb]);
+#pragma unroll
+        for (int qs = 0; qs < QS; ++qs) st[qs][kb] = T::mfma32(kfh, ql[qs][s], st[qs][kb]);
+#pragma unroll
+        for (int qs = 0; qs < QS; ++qs) st[qs][kb] = T::mfma32(kfh, qh[qs][s], st[qs][kb]);
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if (t + 1 < ntiles) dma_issue(buf ^ 1, t + 1);            // behind the QK^T MFMAs already in the pipe; lands under softmax + PV
+    if ((t + 1) * KV > a.nk) {                                // ragged last tile
+      const int k0 = t * KV;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int key = k0 + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
+          if (key >= a.nk) {
+#pragma unroll
+            for (int qs = 0; qs < QS; ++qs) st[qs][kb][i] = -1e30f;
+          }
+        }
+    }
+    // ---- online softmax (running maximum, wave-uniform rescale) ----
+#pragma unroll
+    for (int qs = 0; qs < QS; ++qs) {
+      float mx = fmaxf(st[qs][0][0], st[qs][1][0]);
+#pragma unroll
+      for (int i = 1; i < 16; ++i) mx = fmaxf(fmaxf(mx, st[qs][0][i]), st[qs][1][i]);
+      {
+        const unsigned u = __float_as_uint(mx);
+        const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+      }
+      const float m_new = fmaxf(m_run[qs], mx);
+      const float mc = m_new * a.c;
+      if (__builtin_amdgcn_ballot_w64(m_new != m_run[qs]) != 0) {
+        const float alpha = __builtin_amdgcn_exp2f((m_run[qs] - m_new) * a.c);
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) o[qs][d][i] *= alpha;
+        m_run[qs] = m_new;
+      }
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st[qs][kb][i] = __builtin_amdgcn_exp2f(fmaf(st[qs][kb][i], a.c, -mc));
+    }
+    // ---- O^T += V^T P^T, three products per (16-key step, 32-dim block) ----
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        typename T::v8 ph[QS], pl[QS];
+#pragma unroll
+        for (int qs = 0; qs < QS; ++qs) {
+          u32x4 wh, wl;
+          const float* pv = reinterpret_cast<const float*>(&st[qs][kb]) + 8 * s2;
+          unsigned hh[4], ll[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            hh[e] = T::pack2(pv[2 * e], pv[2 * e + 1]);
+            ll[e] = T::pack2(pv[2 * e] - T::to_f(hh[e] & 0xffff), pv[2 * e + 1] - T::to_f(hh[e] >> 16));
+          }
+          wh.x = hh[0]; wh.y = hh[1]; wh.z = hh[2]; wh.w = hh[3];
+          wl.x = ll[0]; wl.y = ll[1]; wl.z = ll[2]; wl.w = ll[3];
+          ph[qs] = *reinterpret_cast<typename T::v8*>(&wh); pl[qs] = *reinterpret_cast<typename T::v8*>(&wl);
+        }
+        const int keyb = 32 * kb + 16 * s2 + 4 * h + gq;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d) {
+          const unsigned char* pa = sVh + keyb * VSTR + (32 * d + gcol + 4 * gp) * 2;
+          const unsigned char* pb = pa + 8 * VSTR;
+          const unsigned char* la = pa + (OFF_VL - OFF_VH);
+          const unsigned char* lb = pb + (OFF_VL - OFF_VH);
+          if (32 * d + 32 > HD) {                               // columns past HD: V hi = the ones column, then zeros; V lo = zeros
+            const int col = 32 * d + gcol + 4 * gp;
+            if (col >= HD) { pa = pb = smem + ZOFF + (col == HD ? 0 : 8); la = lb = smem + ZOFF + 8; }
+          }
+          union { s16x4 hlf[2]; typename T::v8 full; } vfh, vfl;
+          vfh.hlf[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pa));
+          vfh.hlf[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pb));
+          vfl.hlf[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(la));
+          vfl.hlf[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lb));
+#pragma unroll
+          for (int qs = 0; qs < QS; ++qs) o[qs][d] = T::mfma32(vfl.full, ph[qs], o[qs][d]);
+#pragma unroll
+          for (int qs = 0; qs < QS; ++qs) o[qs][d] = T::mfma32(vfh.full, pl[qs], o[qs][d]);
+#pragma unroll
+          for (int qs = 0; qs < QS; ++qs) o[qs][d] = T::mfma32(vfh.full, ph[qs], o[qs][d]);
+        }
+      }
+    __builtin_amdgcn_s_setprio(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  // ---- epilogue: normalise by the row sum, write f32 rows or [hi | lo | hi] triples ----
+#pragma unroll
+  for (int qs = 0; qs < QS; ++qs) {
+    constexpr int row = HD % 32, ri = (row >> 3) * 4 + (row & 3);
+    static_assert(((row >> 2) & 1) == 0, "ones row must live in lane half 0");
+    const float inv = 1.f / __shfl(o[qs][NDB - 1][ri], r, 64);
+    if (!qvalid[qs]) continue;
+    const long qrow = (long)b * a.nq + q0 + 32 * qs + r;
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+      for (int tq = 0; tq < 4; ++tq) {
+        const int dc = 32 * d + 8 * tq + 4 * h;
+        if (dc < HD) {
+          const float v0 = o[qs][d][4 * tq + 0] * inv, v1 = o[qs][d][4 * tq + 1] * inv, v2 = o[qs][d][4 * tq + 2] * inv, v3 = o[qs][d][4 * tq + 3] * inv;
+          if (a.triple) {
+            unsigned short* o3 = reinterpret_cast<unsigned short*>(a.out) + qrow * 3 * a.ldo + head * HD + dc;
+            uint2 hi, lo;
+            hi.x = T::pack2(v0, v1); hi.y = T::pack2(v2, v3);
+            lo.x = T::pack2(v0 - T::to_f(hi.x & 0xffff), v1 - T::to_f(hi.x >> 16));
+            lo.y = T::pack2(v2 - T::to_f(hi.y & 0xffff), v3 - T::to_f(hi.y >> 16));
+            *reinterpret_cast<uint2*>(o3) = hi; *reinterpret_cast<uint2*>(o3 + a.ldo) = lo; *reinterpret_cast<uint2*>(o3 + 2 * a.ldo) = hi;
+          } else {
+            *reinterpret_cast<sdn_f32x4*>(reinterpret_cast<float*>(a.out) + qrow * a.ldo + head * HD + dc) = (sdn_f32x4){v0, v1, v2, v3};
+          }
+        }
+      }
+  }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
 static int g_attn_qs2 = 1;           // debug A/B switch (sdn_debug_set_attn_qs2)
+static int g_attn_nomax = 1;         // debug A/B switch (sdn_debug_set_attn_nomax): 0 = guarded pass only
 
 template <typename T, int HD>
 int launch(const AttnArgs& a, int batch, int heads, hipStream_t st) {
@@ -637,7 +934,7 @@ int run(const void* q, const void* k, const void* v, void* out, int32_t batch, i
   if (batch == 0) return SDN_OK;
   AttnArgs a{(const unsigned short*)q, (const unsigned short*)k, (const unsigned short*)v, (unsigned short*)out,
              nq, nk, ldq, ldk, ldv, ldo, scale * 1.4426950408889634f, heads, (nq + QB - 1) / QB, batch * heads,
-             nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, causal, kmask};
+             nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, causal, kmask, g_attn_nomax};
   if (!s2 && nk <= 2 * KV && (batch & 7) == 0 && g_attn_head_inner) a.head_inner = 1;
   if (causal && nq != nk) return SDN_E_INVALID;
   if (s2) {                                                  // joint attention over two token streams (nq == nk)
@@ -666,6 +963,7 @@ extern "C" int sdn_debug_set_attn_stamps(void* p) {
 }
 #endif
 extern "C" void sdn_debug_set_attn_qs2(int on) { sdn_attn_detail::g_attn_qs2 = on; }
+extern "C" void sdn_debug_set_attn_nomax(int on) { sdn_attn_detail::g_attn_nomax = on; }
 extern "C" int sdn_attention_bf16(const void* q, const void* k, const void* v, void* out, int32_t batch,
                                   int32_t heads, int32_t nq, int32_t nk, int32_t head_dim, int32_t ldq,
                                   int32_t ldk, int32_t ldv, int32_t ldo, float scale, void* stream) {
@@ -701,3 +999,33 @@ extern "C" int sdn_masked_attention(int32_t dtype, const void* q, const void* k,
 }
 
 extern "C" void sdn_debug_set_attn_head_inner(int on) { sdn_attn_detail::g_attn_head_inner = on; }
+
+// bf16x3 self-attention on hi | lo pair rows (sdn.h).  q / k / v point at the hi planes; the lo plane of every row lies `lo_offset`
+// elements on (the qkv projection's pair output: ld = 6 C, lo_offset = 3 C).  triple = 0: out f32 [B, nq, ldo]; 1: [hi | lo | hi] rows.
+extern "C" int sdn_attention_x3_pairs(const void* q, const void* k, const void* v, int32_t lo_offset, void* out, int32_t batch,
+                                      int32_t heads, int32_t nq, int32_t nk, int32_t head_dim, int32_t ldq, int32_t ldk, int32_t ldv,
+                                      int32_t ldo, float scale, int32_t triple, void* stream) {
+  using namespace sdn_attn_detail;
+  if (!q || !k || !v || !out || batch < 0 || heads <= 0 || nq <= 0 || nk <= 0 || lo_offset <= 0) return SDN_E_INVALID;
+  if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (lo_offset & 7) || (ldo & 3) || nk > 65535) return SDN_E_INVALID;
+  if (lo_offset < heads * head_dim || ldq < lo_offset + heads * head_dim || ldk < lo_offset + heads * head_dim ||
+      ldv < lo_offset + heads * head_dim || ldo < heads * head_dim)
+    return SDN_E_INVALID;
+  auto al = [](const void* p, int n) { return (reinterpret_cast<uintptr_t>(p) & (n - 1)) == 0; };
+  if (!al(q, 16) || !al(k, 16) || !al(v, 16) || !al(out, 16)) return SDN_E_INVALID;
+  if (head_dim != 40 && head_dim != 80) return SDN_E_INVALID;
+  if ((long)nk * ldk * 2 >= (1L << 31) || (long)nk * ldv * 2 >= (1L << 31)) return SDN_E_INVALID;     // 31-bit DMA offsets per sample
+  if (batch == 0) return SDN_OK;
+  const int qs = (head_dim == 40 && nq >= 2 * QB) ? 2 : 1;
+  AttnPArgs a{(const unsigned short*)q, (const unsigned short*)k, (const unsigned short*)v, out, nq, nk, ldq, ldk, ldv, ldo, lo_offset,
+              scale * 1.4426950408889634f, heads, (nq + QB * qs - 1) / (QB * qs), batch * heads, triple ? 1 : 0};
+  const unsigned grid = (unsigned)(a.nqb * a.npairs);
+  hipStream_t st = (hipStream_t)stream;
+  if (head_dim == 40) {
+    if (qs == 2) hipLaunchKernelGGL((k_attn_x3p<40, 2>), dim3(grid), dim3(THREADS), 0, st, a);
+    else hipLaunchKernelGGL((k_attn_x3p<40, 1>), dim3(grid), dim3(THREADS), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((k_attn_x3p<80, 1>), dim3(grid), dim3(THREADS), 0, st, a);
+  }
+  return sdn_launch_status();
+}

@@ -77,7 +77,21 @@ k_gemm_dma(const GemmArgs g) {
     const int q = nt >> 3, r = nt & 7, x = vid & 7;
     tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (vid >> 3);
   }
-  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+  int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+  if (g.panel) {
+    // wide N (GEGLU / qkv projections: 6 ... 32 n-tiles): in row-major order the 32 workgroups an XCD runs at a time span 1-5
+    // tile rows and EVERY n-tile, i.e. each wave of tiles streams the whole weight matrix (6.5 ... 26 MB) through a 4 MiB L2.
+    // Panel order: blocks of 8 tile rows, inside a block panels of g.panel n-tiles, rows fastest -- a wave of 32 tiles is
+    // 8 A row-tiles x 4 W column-tiles (2.6 + 1.6 MB at K = 640), and the next wave re-reads the same 8 A row-tiles from L2.
+    const int per_blk = 8 * g.tiles_n;
+    const int blk = tile / per_blk, rem = tile - blk * per_blk;
+    const int rows = min(8, g.tiles_m - blk * 8);
+    const int full = rows * g.panel;
+    const int p = rem / full, r2 = rem - p * full;
+    const int w = min(g.panel, g.tiles_n - p * g.panel);
+    const int tl = r2 / w;
+    tm = blk * 8 + tl; tn = p * g.panel + (r2 - tl * w);
+  }
   const int m0 = tm * BM, n0 = tn * BN;
   const int lchunk = (lane & 7) ^ lrow;                      // logical 16-B chunk this lane fetches
 
@@ -309,7 +323,7 @@ k_gemm_dma(const GemmArgs g) {
 #ifdef SDN_NO_FRAG_PIPE
     constexpr bool kFragPipe = false;                          // A/B build: the compiler's own fragment schedule
 #else
-    constexpr bool kFragPipe = WGM == 4 && NREP == 10 && LNF != 1;
+    constexpr bool kFragPipe = WGM == 4 && (NREP == 10 || NREP == 8) && LNF != 1;
 #endif
     if constexpr (kFragPipe) {
       // 256 x 320 tile: the W fragments of a k-step are consumed in 5 groups of 2 (8 MFMAs = 128 matrix-pipe cycles each),
@@ -321,11 +335,12 @@ k_gemm_dma(const GemmArgs g) {
       for (int i = 0; i < 4; ++i) fa[0][i] = *reinterpret_cast<const typename T::v8*>(sa + lds_off(i * 16 + fr, fq));
 #pragma unroll
       for (int j = 0; j < 2; ++j) fw[0][j] = *reinterpret_cast<const typename T::v8*>(sw + lds_off(j * 16 + fr, fq));
+      constexpr int G = NREP / 2;                                // fragment groups per k-step (5 at 320 columns, 4 at 256)
 #pragma unroll
-      for (int gi = 0; gi < 10; ++gi) {
-        const int ks = gi / 5, g = gi % 5;
-        if (gi + 1 < 10) {
-          const int ks1 = (gi + 1) / 5, g1 = (gi + 1) % 5;
+      for (int gi = 0; gi < 2 * G; ++gi) {
+        const int ks = gi / G, g = gi % G;
+        if (gi + 1 < 2 * G) {
+          const int ks1 = (gi + 1) / G, g1 = (gi + 1) % G;
 #pragma unroll
           for (int j = 0; j < 2; ++j)
             fw[(gi + 1) & 1][j] = *reinterpret_cast<const typename T::v8*>(sw + lds_off((2 * g1 + j) * 16 + fr, ks1 * 4 + fq));
@@ -341,7 +356,7 @@ k_gemm_dma(const GemmArgs g) {
           for (int j = 0; j < 2; ++j) acc[i][2 * g + j] = T::mfma16(fw[gi & 1][j], fa[ks][i], acc[i][2 * g + j]);
         __builtin_amdgcn_s_setprio(0);
         if (gi == 2 && more) { if (ipos == 1) issue((kt + 1) & 1); else if (ipos == 4) issue_aw((kt + 1) & 1, false); }
-        if (gi == 4 && more) { if (ipos == 2) issue((kt + 1) & 1); else if (ipos == 4) issue_w_only((kt + 1) & 1); }
+        if (gi == G - 1 && more) { if (ipos == 2) issue((kt + 1) & 1); else if (ipos == 4) issue_w_only((kt + 1) & 1); }
       }
     } else {
 #pragma unroll
@@ -672,6 +687,7 @@ static int sdn_gemm_impl(int dtype, const sdn_gemm_desc* d, const void* a, const
       return SDN_E_INVALID;
     g.ln_c = ln_c; g.ln_d = ln_d; g.ln_eps = ln_eps; g.ln_stats = ln_stats;
   }
+  g.panel = (g.tiles_n > 4 && g_gemm_variant != 15) ? 4 : 0;                // variant 15: row-major tile order (A/B)
   g.dbg = g_gemm_variant >= 16 ? (g_gemm_variant >> 4) : 0;
   g.stamps = g_gemm_stamps;
   hipStream_t st = (hipStream_t)stream;

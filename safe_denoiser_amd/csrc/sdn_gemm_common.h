@@ -19,6 +19,7 @@ struct GemmArgs {
   int a_mode, Hs, Ws, Cin, Ho, Wo, stride, upsample, conv_off;
   int act, out_kind, rows_per_batch, ld_rowbias, ld_rowgate, residual_bcast, n_valid, ldc;
   int tiles_m, tiles_n;
+  int panel;                 // tile order inside an XCD's share: 0 = row-major, else n-tiles per panel (see k_gemm_dma)
   const float* ln_c; const float* ln_d; float ln_eps; const float* ln_stats;
   float* col_stats;          // per 128-row block and output column: (sum, sum of squares) of the stored 16-bit values, for the
                              // GroupNorm that consumes this tensor (sdn_gemm_stats_* / sdn_groupnorm_cols_*); nullptr = off   // LNF kernels: LayerNorm folded into this GEMM (see k_gemm_dma)

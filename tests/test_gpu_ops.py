@@ -344,6 +344,45 @@ def test_attention_offset_recentering_branches(kind):
         assert rel_l2(out[0, row, sl], ref[0, row, sl]) <= 2e-2
 
 
+@pytest.mark.parametrize("kind", ["plain", "spike_up_late", "all_far_down", "window_edge"])
+@pytest.mark.parametrize("N,Nk,d", [(512, 512, 40), (256, 256, 80), (128, 128, 160), (256, 77, 40)])
+def test_attention_optimistic_pass_gives_the_guarded_pass_bits(kind, N, Nk, d):
+    """bf16 attention first runs WITHOUT the per-tile running maximum and checks the row sums afterwards (2^-64 <= sum <= 2^64);
+    a workgroup with a query outside that window re-runs its block with the guarded loop.  Ordinary inputs: one pass, and
+    the same bits as the guarded loop alone (sdn_debug_set_attn_nomax(0)); inputs that overflow / underflow 2^s: the re-run
+    must give exactly what the guarded loop alone gives; logits at the edge of the window (2^+-40) stay on the fast pass and
+    must still match the reference."""
+    B, H = 1, 8
+    C_ = H * d
+    g = torch.Generator().manual_seed(41)
+    q = torch.randn(B, N, C_, generator=g) * 0.5
+    k = torch.randn(B, Nk, C_, generator=g) * 0.5
+    v = torch.randn(B, Nk, C_, generator=g)
+    s = d ** 0.5
+    if kind == "spike_up_late":
+        q[0, 7, :d] = 6.0 * (40 / d) ** 0.25; k[0, Nk - 30, :d] = 6.0 * (40 / d) ** 0.25      # ~228 nats: 2^s overflows
+    if kind == "all_far_down":
+        q[0, 9, d:2 * d] = 8.0 * (40 / d) ** 0.25
+        k[0, :, d:2 * d] = (-3.0 + 0.05 * torch.randn(Nk, d, generator=g)) * (40 / d) ** 0.25     # all ~ -150 nats: every 2^s is 0
+    if kind == "window_edge":
+        q[0, 7, :d] = 2.0 * (40 / d) ** 0.25; k[0, Nk - 30, :d] = 2.1 * (40 / d) ** 0.25      # ~ +27 nats = 2^38
+        q[0, 9, d:2 * d] = 2.0 * (40 / d) ** 0.25; k[0, :, d:2 * d] = -2.0 * (40 / d) ** 0.25  # all ~ -25 nats = 2^-36
+    q, k, v = q.to(BF), k.to(BF), v.to(BF)
+    sp = lambda t, n: t.float().reshape(B, n, H, d).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(sp(q, N), sp(k, Nk), sp(v, Nk)).transpose(1, 2).reshape(B, N, C_)
+    lib = sda.lib()
+    try:
+        lib.sdn_debug_set_attn_nomax(0)
+        guarded = ops.attention(q.cuda(), k.cuda(), v.cuda(), H)
+        torch.cuda.synchronize()
+    finally:
+        lib.sdn_debug_set_attn_nomax(1)
+    out = ops.attention(q.cuda(), k.cuda(), v.cuda(), H)
+    assert torch.isfinite(out).all()
+    assert torch.equal(out, guarded)
+    assert rel_l2(out, ref) <= 8e-3, rel_l2(out, ref)
+
+
 # ------------------------------------------------------------------------------------------ conv_in / temb
 def test_conv_in_and_timestep_embedding():
     B, H = 2, 64

@@ -13,6 +13,8 @@ import safe_denoiser_amd as sda  # noqa: E402
 B = int(os.environ.get("B", "32"))
 if os.environ.get("QS2") is not None:
     sda.lib().sdn_debug_set_attn_qs2(int(os.environ["QS2"]))
+if os.environ.get("NOMAX") is not None:
+    sda.lib().sdn_debug_set_attn_nomax(int(os.environ["NOMAX"]))
 if os.environ.get("HEAD_INNER") is not None:
     sda.lib().sdn_debug_set_attn_head_inner(int(os.environ["HEAD_INNER"]))
 for name, nq, nk, d in [("self 64x64 d40", 4096, 4096, 40), ("self 32x32 d80", 1024, 1024, 80),

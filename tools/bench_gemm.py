@@ -25,10 +25,14 @@ SHAPES = [  # name, M, N, K, conv(H, Cin) or None, act
     ("ff1 geglu 640 @32", B * 1024, 5120, 640, None, 2),
     ("ff2 640 @32", B * 1024, 640, 2560, None, 0),
     ("ff1 geglu 1280 @16", B * 256, 10240, 1280, None, 2),
+    ("qkv 640 @32", B * 1024, 1920, 640, None, 0),
+    ("qkv 1280 @16", B * 256, 3840, 1280, None, 0),
     ("mmdit qkv 1536", B * 1024, 4608, 1536, None, 0),
     ("mmdit ff1 1536", B * 1024, 6144, 1536, None, 3),
 ]
 VARIANTS = [int(v) for v in os.environ.get("VARIANTS", "0,1").split(",")]
+if os.environ.get("ONLY"):                                   # comma-separated substrings of the shape names to keep
+    SHAPES = [s for s in SHAPES if any(k in s[0] for k in os.environ["ONLY"].split(","))]
 
 
 def main():
