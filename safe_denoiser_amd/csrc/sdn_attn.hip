@@ -17,6 +17,8 @@
 // K/V tiles are double-buffered in LDS through registers: the global loads of tile t+1 are issued before the
 // MFMAs of tile t and written after them (one barrier per tile).  Head dim is zero-padded inside LDS only; HBM
 // tensors stay packed [B, N, heads*d], i.e. the NHWC token matrix the projections write.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "sdn_common.h"
@@ -642,8 +644,9 @@ struct AttnPArgs {
   int heads, nqb, npairs, triple;
 };
 
-template <int HD, int QS>
-__global__ void __launch_bounds__(THREADS)
+// NW = waves per workgroup (4 or 8: d = 80 holds 94 KB of K / V stages, one workgroup per CU -- eight waves share them)
+template <int HD, int QS, int NW>
+__global__ void __launch_bounds__(64 * NW)
 k_attn_x3p(const AttnPArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef SdnBF16 T;
@@ -654,7 +657,7 @@ k_attn_x3p(const AttnPArgs a) {
   constexpr int OFF_KL = KV * KSTR, OFF_VH = 2 * KV * KSTR, OFF_VL = OFF_VH + KV * VSTR;
   constexpr int STAGE = 2 * KV * (KSTR + VSTR);
   constexpr int ZOFF = 2 * STAGE;
-  constexpr int NP = 2 * (KCH + VCH), NPIECE = (NP + 3) / 4;
+  constexpr int NP = 2 * (KCH + VCH), NPIECE = (NP + NW - 1) / NW;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE + 32];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -666,7 +669,7 @@ k_attn_x3p(const AttnPArgs a) {
     else { pair = id / nqb; qblk = id - pair * nqb; }
   }
   const int head = pair % a.heads, b = pair / a.heads;
-  const int q0 = qblk * (QB * QS) + wid * (32 * QS);
+  const int q0 = qblk * (32 * NW * QS) + wid * (32 * QS);
   bool qvalid[QS];
 #pragma unroll
   for (int qs = 0; qs < QS; ++qs) qvalid[qs] = q0 + 32 * qs + r < a.nq;
@@ -691,7 +694,7 @@ k_attn_x3p(const AttnPArgs a) {
   unsigned dma_off[NPIECE];
 #pragma unroll
   for (int i = 0; i < NPIECE; ++i) {
-    const int p = wid + 4 * i;                                   // wave-uniform
+    const int p = wid + NW * i;                                   // wave-uniform
     const bool isv = p >= 2 * KCH;
     const int pi = isv ? (p - 2 * KCH) % VCH : p % KCH;          // piece inside its image
     const int e = pi * 64 + lane;
@@ -711,7 +714,7 @@ k_attn_x3p(const AttnPArgs a) {
     unsigned char* st = smem + buf * STAGE;
 #pragma unroll
     for (int i = 0; i < NPIECE; ++i) {
-      const int p = wid + 4 * i;
+      const int p = wid + NW * i;
       if (p < KCH) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_kh, (lds_ptr_t)(st + p * 1024), 16, dma_off[i], 0, 0, 0);
       else if (p < 2 * KCH) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_kl, (lds_ptr_t)(st + OFF_KL + (p - KCH) * 1024), 16, dma_off[i], 0, 0, 0);
       else if (p < 2 * KCH + VCH) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_vh, (lds_ptr_t)(st + OFF_VH + (p - 2 * KCH) * 1024), 16, dma_off[i], 0, 0, 0);
@@ -1016,16 +1019,26 @@ extern "C" int sdn_attention_x3_pairs(const void* q, const void* k, const void* 
   if (head_dim != 40 && head_dim != 80) return SDN_E_INVALID;
   if ((long)nk * ldk * 2 >= (1L << 31) || (long)nk * ldv * 2 >= (1L << 31)) return SDN_E_INVALID;     // 31-bit DMA offsets per sample
   if (batch == 0) return SDN_OK;
-  const int qs = (head_dim == 40 && nq >= 2 * QB) ? 2 : 1;
+  static const int qs_env = getenv("SDN_X3P_QS") ? atoi(getenv("SDN_X3P_QS")) : 0;      /* tuning knobs (tools/profile_x3.py) */
+  static const int nw_env = getenv("SDN_X3P_NW") ? atoi(getenv("SDN_X3P_NW")) : 0;
+  int qs = (head_dim == 40 && nq >= 2 * QB) ? 2 : 1;
+  int nw = head_dim == 80 && nq >= 2 * QB ? 8 : 4;
+  if (head_dim == 40 && qs_env) qs = qs_env == 2 ? 2 : 1;
+  if (nw_env) nw = nw_env == 8 ? 8 : 4;
+  if (head_dim == 80) qs = 1;
+  if (head_dim == 40 && qs == 2) nw = 4;
+  const int qper = 32 * nw * qs;
   AttnPArgs a{(const unsigned short*)q, (const unsigned short*)k, (const unsigned short*)v, out, nq, nk, ldq, ldk, ldv, ldo, lo_offset,
-              scale * 1.4426950408889634f, heads, (nq + QB * qs - 1) / (QB * qs), batch * heads, triple ? 1 : 0};
+              scale * 1.4426950408889634f, heads, (nq + qper - 1) / qper, batch * heads, triple ? 1 : 0};
   const unsigned grid = (unsigned)(a.nqb * a.npairs);
   hipStream_t st = (hipStream_t)stream;
   if (head_dim == 40) {
-    if (qs == 2) hipLaunchKernelGGL((k_attn_x3p<40, 2>), dim3(grid), dim3(THREADS), 0, st, a);
-    else hipLaunchKernelGGL((k_attn_x3p<40, 1>), dim3(grid), dim3(THREADS), 0, st, a);
+    if (qs == 2) hipLaunchKernelGGL((k_attn_x3p<40, 2, 4>), dim3(grid), dim3(256), 0, st, a);
+    else if (nw == 8) hipLaunchKernelGGL((k_attn_x3p<40, 1, 8>), dim3(grid), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((k_attn_x3p<40, 1, 4>), dim3(grid), dim3(256), 0, st, a);
   } else {
-    hipLaunchKernelGGL((k_attn_x3p<80, 1>), dim3(grid), dim3(THREADS), 0, st, a);
+    if (nw == 8) hipLaunchKernelGGL((k_attn_x3p<80, 1, 8>), dim3(grid), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((k_attn_x3p<80, 1, 4>), dim3(grid), dim3(256), 0, st, a);
   }
   return sdn_launch_status();
 }

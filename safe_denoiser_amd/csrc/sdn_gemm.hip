@@ -616,7 +616,7 @@ static int sdn_gemm_impl(int dtype, const sdn_gemm_desc* d, const void* a, const
   if (n_valid > d->N) return SDN_E_INVALID;
   if (sdn_gemm_pick_nrep(d->N, d->act) == 0) return SDN_E_INVALID;
   const int x3 = d->x3_out;
-  if (x3 < 0 || x3 > 3 || (x3 && (dtype != 0 || rowgate || d->split_k > 1 || partials || ln_c || col_stats || n_valid != d->N)))
+  if (x3 < 0 || x3 > 4 || (x3 && (dtype != 0 || rowgate || d->split_k > 1 || partials || ln_c || col_stats || n_valid != d->N)))
     return SDN_E_INVALID;
   if (x3 && ((x3 == 2) != (d->act == SDN_ACT_GEGLU) || (x3 != 2 && d->act != SDN_ACT_NONE) || (residual && !al16(residual)) || !al16(out)))
     return SDN_E_INVALID;

@@ -51,6 +51,7 @@ struct Op {
   int ln = 0;
   int text_kv = 0;           // cross-attention K / V projection of the TEXT operand: skipped while the caller's text version stands
   int x3t = 0;               // bf16x3 plan: this GEMM runs on sdn_gemm_bf16 over triple operands (gd holds the EXPANDED K / Cin)
+  int pair_in = 0;           // bf16x3 plan: attention whose q / k / v are column blocks of ONE hi | lo pair-row buffer (sdn_attention_x3_pairs)
   int tri_out = 0;           // bf16x3 plan: GroupNorm / LayerNorm / attention write the bf16 hi|lo|hi triple a GEMM will read
   int n1 = 0, mod = 0, ld_mod = 0, patch = 0;
   // GN / LN / conv_in / attention scalars
@@ -161,6 +162,7 @@ struct sdn_unet {
   uint64_t text_version = 0, kv_version = 0;
   int kv_batch = 0;
   const void *kv_w = nullptr, *kv_text = nullptr, *kv_ws = nullptr;
+  bool x3_pairs = true;                 // bf16x3 plan: self-attention on pre-split operands (qkv projection writes hi | lo pair rows)
   bool res_pre = true;                  // attention output projections: residual into the accumulators before the k loop (sdn_gemm_desc.res_pre)
   bool x3_expand = true;                // dtype 3: GEMM operands as bf16 triples on the LDS-DMA tiles (false: the f32-staging k_gemm_x3 everywhere)
   bool split_k = false;                 // sdn_unet_set_split_k: small-M GEMMs of the plan take the split-K form (off by
@@ -247,7 +249,7 @@ struct Builder {
   Ref pending_cols;                    // set by want_stats() for the NEXT emitted GEMM
   void want_stats(const Act& out) { pending_cols = out.st_off >= 0 ? Ref{SP_WS, out.st_off} : Ref(); }
   void drop(Act& t) {
-    if (t.off >= 0) { arena.release(t.off, t.bytes); tri.erase(t.off); }
+    if (t.off >= 0) { arena.release(t.off, t.bytes); tri.erase(t.off); pairs.erase(t.off); }
     if (t.st_off >= 0) arena.release(t.st_off, t.st_bytes);
     t.off = -1; t.st_off = -1;
   }
@@ -275,6 +277,8 @@ struct Builder {
   int64_t kv_top = 0;             // bytes of persistent text K / V slots handed out so far (space SP_KV)
   bool res_pre_next = false;      // the next gemm() adds its residual into the accumulators before the k loop (sdn_gemm_desc.res_pre)
   bool triple_out_next = false;   // the next gemm() writes the triple of its result (its only reader is another x3 GEMM)
+  bool pair_out_next = false;     // the next gemm() writes hi | lo pair rows (the qkv projection of a self-attention: sdn_attention_x3_pairs)
+  std::set<int64_t> pairs;        // workspace offsets that hold pair rows
   bool x3t_on(const Ref& a) const { return x3t && !x3t_hold && a.space == SP_WS; }
 
   // ---- op emitters ------------------------------------------------------------------------------
@@ -290,8 +294,10 @@ struct Builder {
       o.x3t = 1;
       o.gd.M = (int)M; o.gd.N = N; o.gd.K = 3 * K; o.gd.a_mode = SDN_A_PLAIN; o.gd.act = act_; o.gd.out_kind = SDN_OUT_F32;
       const bool tri_o = triple_out_next && act_ == SDN_ACT_NONE;
-      triple_out_next = false;
-      o.gd.x3_out = act_ == SDN_ACT_GEGLU ? 2 : (tri_o ? 3 : 1); o.gd.rows_per_batch = rows_per_batch; o.gd.ld_rowbias = ld_rowbias;
+      const bool pair_o = pair_out_next && act_ == SDN_ACT_NONE && !tri_o && residual.space == SP_NONE;
+      triple_out_next = false; pair_out_next = false;
+      o.gd.x3_out = act_ == SDN_ACT_GEGLU ? 2 : (tri_o ? 3 : (pair_o ? 4 : 1)); o.gd.rows_per_batch = rows_per_batch; o.gd.ld_rowbias = ld_rowbias;
+      if (pair_o) pairs.insert(out.off);
       o.a = au; o.w = x3_weight(w, N, K, K); o.bias = bias; o.rowbias = rowbias; o.residual = residual; o.out = out;
       o.flops = 2.0 * (double)M * (double)N * (double)K;
       o.bytes = 6.0 * ((double)M * K + (double)N * K) + 4.0 * (double)M * (act_ == SDN_ACT_GEGLU ? 0.75 * N : N) +
@@ -302,7 +308,7 @@ struct Builder {
       if (tmp.off >= 0) drop(tmp);                            // stream order: the next op may reuse it
       return;
     }
-    triple_out_next = false;
+    triple_out_next = false; pair_out_next = false;
     const bool rp = res_pre_next && residual.space != SP_NONE && act_ == SDN_ACT_NONE && out_kind == SDN_OUT_BF16 && n_valid == 0 && es == 2;
     res_pre_next = false;
     Op o; o.kind = OP_GEMM; memset(&o.gd, 0, sizeof(o.gd));
@@ -447,6 +453,7 @@ struct Builder {
     o.nq = nq; o.nk = nk; o.hd = C / u->cfg.n_heads; o.ldq = ldq; o.ldk = ldk; o.ldv = ldv; o.ldo = C;
     o.scale = 1.0f / sqrtf((float)o.hd);
     if (x3t && out.space == SP_WS) { o.tri_out = 1; tri.insert(out.off); }   // its only reader is the to_out projection
+    if (q.space == SP_WS && pairs.count(q.off)) { o.pair_in = 1; pairs.erase(q.off); }   // q / k / v = column blocks of one pair-row buffer
     const double f = 4.0 * (double)B * o.heads * (double)nq * (double)nk * (double)o.hd;
     o.flops = f;
     o.bytes = 2.0 * (double)B * C * (2.0 * nq + 2.0 * nk);
@@ -554,6 +561,8 @@ struct Builder {
       gemm_ln(h, rows, 3 * C, C, tb + ".attn1.to_q.weight", qkv, l1g, l1b, Ref(), R(qkvb), SDN_ACT_NONE, 3 * C > 960 || u->ln_prepass_all);
     } else {
       layernorm(h, l1g, l1b, ln);
+      const int hd1 = C / u->cfg.n_heads;
+      if (x3t && u->x3_pairs && (hd1 == 40 || hd1 == 80) && (int64_t)hw * 6 * C * 2 < (1LL << 31)) pair_out_next = true;
       gemm(rows, 3 * C, C, R(ln), qkv, Ref(), R(qkvb));
     }
     Act at = act(rows, C, hw, x.side);
@@ -1568,7 +1577,7 @@ static int launch_x3t_gemm(const Op& o, const char* a, const char* w, const floa
   if (per < 1) return SDN_E_INVALID;
   if (per > units) per = units;
   const int n_cols = d.x3_out == 2 ? d.N / 2 : d.N;                           // logical output width
-  const long out_row_bytes = d.x3_out == 0 ? 0 : (d.x3_out == 1 ? 4L * n_cols : 6L * n_cols);
+  const long out_row_bytes = d.x3_out == 0 ? 0 : ((d.x3_out == 1 || d.x3_out == 4) ? 4L * n_cols : 6L * n_cols);
   if (d.x3_out == 0 && per < units) return SDN_E_INVALID;                     // (the NCHW output of conv_out is not chunked: 4 channels)
   for (long u0 = 0; u0 < units; u0 += per) {
     const long nu = units - u0 < per ? units - u0 : per;
@@ -1627,6 +1636,11 @@ static int launch_ops(sdn_unet* u, Plan* p, const char* W, const char* WS, const
                                                                                   (const float*)P(o.bias), (void*)P(o.out), stream);
           break;
         case OP_ATTN:
+          if (o.pair_in) {                             // ld = 2 x (qkv width) bf16 elements, lo plane = one width on
+            rc = sdn_attention_x3_pairs(P(o.a), P(o.a) + (size_t)o.ldo * 2, P(o.a) + (size_t)o.ldo * 4, o.ldq, (void*)P(o.out), o.batch, o.heads, o.nq,
+                                        o.nk, o.hd, 2 * o.ldq, 2 * o.ldk, 2 * o.ldv, o.ldo, o.scale, o.tri_out, stream);
+            break;
+          }
           rc = o.n1 > 0 ? SDN_E_INVALID
                         : (o.tri_out ? sdn_attention_x3_triple : (x3 ? sdn_attention_x3 : sdn_attention_f32))(
                               P(o.a), P(o.k), P(o.v), (void*)P(o.out), o.batch, o.heads, o.nq, o.nk, o.hd, o.ldq, o.ldk, o.ldv, o.ldo, o.scale, stream);
@@ -1882,6 +1896,13 @@ extern "C" void sdn_debug_set_ffn_fuse(sdn_unet* u, int on) {   // one-launch GE
 extern "C" void sdn_debug_set_ff_fuse(sdn_unet* u, int on) {
   if (!u) return;
   u->ff_fuse = on != 0;
+  drop_graphs(u);
+  u->plans.clear();
+}
+
+extern "C" void sdn_debug_set_x3_pairs(sdn_unet* u, int on) {
+  if (!u) return;
+  u->x3_pairs = on != 0;
   drop_graphs(u);
   u->plans.clear();
 }

@@ -305,3 +305,28 @@ def test_bf16x3_plan_in_row_chunks_gives_the_unchunked_bits():
     finally:
         sda.lib().sdn_debug_set_x3_chunk_bytes(0)
     assert torch.equal(out, ref)
+
+
+def test_bf16x3_plan_presplit_self_attention_against_the_first_kernel():
+    """The bf16x3 plan's self-attention at d = 40 / 80 reads hi | lo pair rows written by the qkv projection (sdn_attention_x3_pairs);
+    sdn_debug_set_x3_pairs(0) restores the f32 qkv tensor + sdn_attention_x3.  Same three-term products either way: the two
+    forwards agree to the mode's own accuracy, are NOT bit-identical (the switch really changes the path), and both sit at the
+    mode's distance from the pure-fp32 oracle."""
+    import ctypes as C
+    import safe_denoiser_amd as sda
+    u = UNet2DConditionModel(text_len=77, precision="bf16x3", latent_repeat=1, **SMALL)
+    sd = u.synthetic_state_dict(11)
+    u.load_state_dict(sd)
+    x, E = rnd(3, 4, 16, 16, seed=1), rnd(3, 77, 768, seed=2)
+    new = u(x.cuda(), 801.0, encoder_hidden_states=E.cuda()).sample.clone()
+    try:
+        sda.lib().sdn_debug_set_x3_pairs(C.c_void_p(u._h.value), 0)
+        u._ws = {}
+        old = u(x.cuda(), 801.0, encoder_hidden_states=E.cuda()).sample.clone()
+    finally:
+        sda.lib().sdn_debug_set_x3_pairs(C.c_void_p(u._h.value), 1)
+    ref = OracleUNet(sd, SMALL_O, act_dtype=None)(x, 801.0, E)
+    r_new, r_old, r_between = rel_l2(new, ref), rel_l2(old, ref), rel_l2(new, old)
+    print(f"bf16x3 small UNet vs fp32 oracle: pre-split attention {r_new:.2e}, first kernel {r_old:.2e}; between them {r_between:.2e}")
+    assert not torch.equal(new, old)
+    assert r_new <= 1e-4 and r_old <= 1e-4 and r_between <= 5e-5

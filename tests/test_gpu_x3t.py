@@ -142,3 +142,43 @@ def test_norms_and_attention_write_the_triple_of_their_f32_result():
         _lib.check(L.sdn_attention_x3_triple(q.data_ptr(), kv.data_ptr(), kv.data_ptr() + 4 * H * d, t.data_ptr(), B, H, nq, nk, d, H * d,
                                              2 * H * d, 2 * H * d, H * d, d ** -0.5, _lib.stream_ptr()), "attention triple")
         assert torch.equal(t.reshape(B * nq, -1), ops.split3(f.reshape(B * nq, H * d))), (nq, nk, d)
+
+
+def test_x3t_gemm_pair_rows_are_the_split_of_the_f32_result():
+    M, N, K = 1000, 960, 320
+    a, w, bias = rnd(M, K, seed=41), rnd(N, K, seed=42, scale=K ** -0.5), rnd(N, seed=43)
+    a3, w3 = ops.split3(a.cuda()), ops.expand3(w.cuda())
+    f = ops.gemm_x3t(a3, w3, N, K, bias=bias.cuda())
+    pr = ops.gemm_x3t(a3, w3, N, K, bias=bias.cuda(), x3_out=4)
+    assert pr.shape == (M, 2 * N)
+    hi = f.bfloat16()
+    assert torch.equal(pr[:, :N], hi)
+    assert torch.equal(pr[:, N:], (f - hi.float()).bfloat16())
+
+
+@pytest.mark.parametrize("B,N,d", [(2, 256, 40), (1, 300, 40), (1, 4096, 40), (2, 1024, 80), (1, 100, 80), (8, 128, 40)])
+def test_attention_on_presplit_pairs_against_float64(B, N, d):
+    """sdn_attention_x3_pairs (K / V planes by LDS-DMA, three bf16 products per term) vs float64 softmax attention on the values the
+    pairs carry, and vs the first bf16x3 kernel (sdn_attention_x3 on the f32 tensor); triple output = split of the f32 output."""
+    H = 8
+    C_ = H * d
+    qkv = rnd(B, N, 3 * C_, seed=44)
+    qkv[0, 5, :d] *= 4.0                                                         # a sharp row (running-maximum rescale after tile 0)
+    qkv[0, min(N - 1, 200), C_:C_ + d] = qkv[0, 5, :d] * 1.5
+    g = qkv.cuda()
+    hi = g.bfloat16()
+    pairs = torch.cat([hi, (g - hi.float()).bfloat16()], -1).contiguous()
+    val = (pairs[..., :3 * C_].double() + pairs[..., 3 * C_:].double()).cpu()    # what the kernel is given
+    sp = lambda t: t.reshape(B, N, H, d).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(sp(val[..., :C_]), sp(val[..., C_:2 * C_]), sp(val[..., 2 * C_:])).transpose(1, 2).reshape(B, N, C_)
+    out = ops.attention_x3_pairs(pairs, H)
+    assert torch.isfinite(out).all()
+    assert rel_l2(out, ref) <= TOL, rel_l2(out, ref)
+    ops.X3 = True
+    try:
+        old = ops.attention(g[..., :C_], g[..., C_:2 * C_], g[..., 2 * C_:], H)
+    finally:
+        ops.X3 = False
+    assert rel_l2(out, old) <= 2 * TOL
+    tri = ops.attention_x3_pairs(pairs, H, triple=True)
+    assert torch.equal(tri.reshape(B * N, -1), ops.split3(out.reshape(B * N, C_)))

@@ -193,9 +193,26 @@ def gemm_x3t(a3, w3, N, K, *, bias=None, rowbias=None, residual=None, conv=None,
         out = torch.empty((M, width), dtype=torch.float32, device=a3.device)
     elif x3_out in (2, 3):
         out = torch.empty((M, 3 * width), dtype=BF, device=a3.device)
+    elif x3_out == 4:
+        out = torch.empty((M, 2 * width), dtype=BF, device=a3.device)
     else:
         out = torch.empty((M // rows_per_batch, n_valid or N, rows_per_batch), dtype=torch.float32, device=a3.device)
     p = lambda t: None if t is None else t.data_ptr()
     _lib.check(sda.lib().sdn_gemm_bf16(C.byref(d), p(a3), None, p(w3), p(bias), p(rowbias), None, p(residual), p(out),
                                        _lib.stream_ptr()), "sdn_gemm_bf16 (x3_out)")
+    return out
+
+
+def attention_x3_pairs(qkv_pairs, heads, triple=False, scale=None):
+    """qkv_pairs [B, N, 2 * 3C] bf16: rows [hi(q | k | v) | lo(q | k | v)] (sdn_gemm_bf16 with x3_out = 4) -> f32 [B, N, C]
+    or the triple [B, N, 3C]."""
+    B, n, w = qkv_pairs.shape
+    c = w // 6
+    d = c // heads
+    out = torch.empty((B, n, 3 * c), dtype=BF, device=qkv_pairs.device) if triple else \
+        torch.empty((B, n, c), dtype=torch.float32, device=qkv_pairs.device)
+    scale = scale if scale is not None else d ** -0.5
+    base = qkv_pairs.data_ptr()
+    _lib.check(sda.lib().sdn_attention_x3_pairs(base, base + 2 * c, base + 4 * c, 3 * c, out.data_ptr(), B, heads, n, n, d, w, w, w, c,
+                                                scale, 1 if triple else 0, _lib.stream_ptr()), "sdn_attention_x3_pairs")
     return out

@@ -13,6 +13,10 @@ B = int(os.environ.get("BATCH", "96"))
 rep = int(os.environ.get("REP", "3"))
 u = UNet2DConditionModel(latent_repeat=rep, precision=prec)
 u.load_synthetic_on_device(1234)
+if os.environ.get("PAIRS") == "0":                 # A/B: f32 qkv tensor + sdn_attention_x3 instead of the pre-split self-attention
+    import ctypes as C
+    import safe_denoiser_amd as sda
+    sda.lib().sdn_debug_set_x3_pairs(C.c_void_p(u._h.value), 0)
 x = torch.randn(B // rep, 4, 64, 64, device="cuda")
 tb = u.prepare_text(torch.randn(B, 77, 768, device="cuda"))
 y = torch.empty(B, 4, 64, 64, device="cuda")
