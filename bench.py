@@ -757,7 +757,7 @@ def main():
             line["precision_mode_bf16x3"]["relative_to_16bit_engine_same_workload"] = \
                 line["precision_mode_bf16x3"]["value"] / line["latent_b2"]["value"]
         # the headline call itself in the mode that meets the tolerance from token ids (VERDICT r3 next #1c)
-        line["e2e_bf16x3"] = measure_e2e_precision(args, dev, proc, min(P, 32), mine)
+        line["e2e_bf16x3"] = measure_e2e_precision(args, dev, proc, min(P, 64), mine)      # (B = 192 samples per forward: 3.3 % per image over 96)
         line["value_at_north_star_tolerance"] = line["e2e_bf16x3"]["value"]
         line["e2e_bf16x3"]["relative_to_headline"] = line["e2e_bf16x3"]["value"] / value
         line["parity"] = measure_parity(args, dev)
