@@ -356,14 +356,16 @@ int sdn_layernorm_f32_triple(const void* x, int64_t rows, int32_t c, float eps, 
 int sdn_attention_x3_triple(const void* q, const void* k, const void* v, void* out_triple, int32_t batch, int32_t heads, int32_t nq,
                             int32_t nk, int32_t head_dim, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo, float scale,
                             void* stream);
-/* Self-attention of the bf16x3 plan on PRE-SPLIT operands (replaces Attention.forward's softmax(Q K^T) V of
- * models/transformer_2d.py at the 64 x 64 / 32 x 32 levels in that mode): q / k / v point at the hi planes of hi | lo pair rows
- * (the qkv projection run with x3_out = 4: row = [hi(3C) | lo(3C)], ld = 6 C, lo_offset = 3 C elements); every product is the
- * three-term bf16 sum of sdn_attention_x3, but K / V reach LDS by LDS-DMA instead of being split per tile per workgroup.
- * head_dim 40 or 80.  triple_out = 0: out is F32 [batch, nq, ldo]; 1: out is the bf16 triple [batch, nq, 3 ldo]. */
-int sdn_attention_x3_pairs(const void* q, const void* k, const void* v, int32_t lo_offset, void* out, int32_t batch, int32_t heads,
-                           int32_t nq, int32_t nk, int32_t head_dim, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo, float scale,
-                           int32_t triple_out, void* stream);
+/* Attention of the bf16x3 plan on PRE-SPLIT operands (replaces Attention.forward's softmax(Q K^T) V of models/transformer_2d.py
+ * in that mode, self- and cross-attention): q / k / v point at the hi planes of hi | lo PAIR rows written by a projection run with
+ * x3_out = 4; the lo plane of a Q row lies lo_offset_q elements on, that of a K / V row lo_offset_kv elements on
+ * (self-attention over the qkv projection [hi(3C) | lo(3C)]: ld = 6 C, both offsets 3 C; cross-attention: q from [hi(C) | lo(C)],
+ * k / v from the text projection [hi(2C) | lo(2C)]).  Every product is the three-term bf16 sum of sdn_attention_x3, but K / V
+ * reach LDS by LDS-DMA instead of being split per tile per workgroup.  head_dim 40, 80 or 160.
+ * triple_out = 0: out is F32 [batch, nq, ldo]; 1: out is the bf16 triple [batch, nq, 3 ldo]. */
+int sdn_attention_x3_pairs(const void* q, const void* k, const void* v, int32_t lo_offset_q, int32_t lo_offset_kv, void* out,
+                           int32_t batch, int32_t heads, int32_t nq, int32_t nk, int32_t head_dim, int32_t ldq, int32_t ldk,
+                           int32_t ldv, int32_t ldo, float scale, int32_t triple_out, void* stream);
 
 /* ---- random draws (row S2): P per-prompt generators in one launch ------------------------------------------------
  * Replaces the per-prompt `torch.randn(latents_shape, generator=gen)` calls behind prepare_latents / scheduler.step /

@@ -171,7 +171,7 @@ SIGNATURES = {
     "sdn_groupnorm_f32_triple": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "sdn_layernorm_f32_triple": (C.c_int, [_vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp]),
     "sdn_attention_x3_triple": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
-    "sdn_attention_x3_pairs": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "sdn_attention_x3_pairs": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
     "sdn_clip_embed_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "sdn_masked_attention_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "sdn_unet_prepare": (C.c_int, [_vp, _vp, _vp]),

@@ -639,25 +639,27 @@ k_attn(const AttnArgs a) {
 struct AttnPArgs {
   const unsigned short* q; const unsigned short* k; const unsigned short* v;   // hi planes; the lo plane of a row lies `lo` elements on
   void* out;
-  int nq, nk, ldq, ldk, ldv, ldo, lo;
+  int nq, nk, ldq, ldk, ldv, ldo, lo_q, lo_kv;                                 // lo plane of a Q row / of a K or V row: that many elements on
   float c;
   int heads, nqb, npairs, triple;
 };
 
 // NW = waves per workgroup (4 or 8: d = 80 holds 94 KB of K / V stages, one workgroup per CU -- eight waves share them)
-template <int HD, int QS, int NW>
+// KVT = keys per tile (64; 32 at d = 160, whose four plane images of 64 keys would not leave room for two stages)
+template <int HD, int QS, int NW, int KVT>
 __global__ void __launch_bounds__(64 * NW)
 k_attn_x3p(const AttnPArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef SdnBF16 T;
   constexpr int KQ = (HD + 15) / 16, NDB = (HD + 31) / 32, CH = HD / 8;
-  static_assert(HD % 32 != 0, "row sums come from the ones column of the padding");
-  constexpr int KCH = HD == 40 ? 5 : CH + 1, VCH = HD == 40 ? 5 : 12;
-  constexpr int KSTR = KCH * 16, VSTR = VCH * 16;
-  constexpr int OFF_KL = KV * KSTR, OFF_VH = 2 * KV * KSTR, OFF_VL = OFF_VH + KV * VSTR;
-  constexpr int STAGE = 2 * KV * (KSTR + VSTR);
+  constexpr bool ONES = HD % 32 != 0;                           // row sums from the ones column of the padding (else summed on the vector side)
+  constexpr int KCH = HD == 40 ? 5 : CH + 1, VCH = HD == 40 ? 5 : (HD == 160 ? 20 : 12);
+  constexpr int KSTR = KCH * 16, VSTR = VCH * 16, NKB = KVT / 32;
+  constexpr int KP = (KVT * KCH + 63) / 64, VP = (KVT * VCH + 63) / 64;      // 1-KiB DMA pieces per K / V plane image
+  constexpr int OFF_KL = KP * 1024, OFF_VH = 2 * KP * 1024, OFF_VL = OFF_VH + VP * 1024;
+  constexpr int STAGE = 2 * (KP + VP) * 1024;
   constexpr int ZOFF = 2 * STAGE;
-  constexpr int NP = 2 * (KCH + VCH), NPIECE = (NP + NW - 1) / NW;
+  constexpr int NP = 2 * (KP + VP), NPIECE = (NP + NW - 1) / NW;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE + 32];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -685,7 +687,7 @@ k_attn_x3p(const AttnPArgs a) {
       u32x4 vh = (u32x4){0u, 0u, 0u, 0u}, vl = vh;
       if (qvalid[qs] && dc < HD) {
         const unsigned short* qp = a.q + ((long)b * a.nq + q0 + 32 * qs + r) * a.ldq + head * HD + dc;
-        vh = *reinterpret_cast<const u32x4*>(qp); vl = *reinterpret_cast<const u32x4*>(qp + a.lo);
+        vh = *reinterpret_cast<const u32x4*>(qp); vl = *reinterpret_cast<const u32x4*>(qp + a.lo_q);
       }
       qh[qs][s] = *reinterpret_cast<typename T::v8*>(&vh); ql[qs][s] = *reinterpret_cast<typename T::v8*>(&vl);
     }
@@ -695,45 +697,46 @@ k_attn_x3p(const AttnPArgs a) {
 #pragma unroll
   for (int i = 0; i < NPIECE; ++i) {
     const int p = wid + NW * i;                                   // wave-uniform
-    const bool isv = p >= 2 * KCH;
-    const int pi = isv ? (p - 2 * KCH) % VCH : p % KCH;          // piece inside its image
+    const bool isv = p >= 2 * KP;
+    const int pi = isv ? (p - 2 * KP) % VP : p % KP;             // piece inside its image
     const int e = pi * 64 + lane;
     const int rowc = isv ? VCH : KCH;
     const int row = e / rowc, ch = e - row * rowc;
-    dma_off[i] = ch < CH ? (unsigned)(((long)row * (isv ? a.ldv : a.ldk) + head * HD + ch * 8) * 2) : 0x80000000u;
+    dma_off[i] = (ch < CH && row < KVT) ? (unsigned)(((long)row * (isv ? a.ldv : a.ldk) + head * HD + ch * 8) * 2) : 0x80000000u;
   }
   auto dma_issue = [&](int buf, int t) {
-    const long k0 = (long)t * KV;
+    const long k0 = (long)t * KVT;
     const unsigned short* kb_ = a.k + ((long)b * a.nk + k0) * a.ldk;
     const unsigned short* vb_ = a.v + ((long)b * a.nk + k0) * a.ldv;
     const long rk = ((a.nk - k0 - 1) * a.ldk + a.heads * HD) * 2, rv = ((a.nk - k0 - 1) * a.ldv + a.heads * HD) * 2;
     const __amdgpu_buffer_rsrc_t rs_kh = make_rsrc(kb_, (unsigned)(rk > 0 ? rk : 0));
-    const __amdgpu_buffer_rsrc_t rs_kl = make_rsrc(kb_ + a.lo, (unsigned)(rk > 0 ? rk : 0));
+    const __amdgpu_buffer_rsrc_t rs_kl = make_rsrc(kb_ + a.lo_kv, (unsigned)(rk > 0 ? rk : 0));
     const __amdgpu_buffer_rsrc_t rs_vh = make_rsrc(vb_, (unsigned)(rv > 0 ? rv : 0));
-    const __amdgpu_buffer_rsrc_t rs_vl = make_rsrc(vb_ + a.lo, (unsigned)(rv > 0 ? rv : 0));
+    const __amdgpu_buffer_rsrc_t rs_vl = make_rsrc(vb_ + a.lo_kv, (unsigned)(rv > 0 ? rv : 0));
     unsigned char* st = smem + buf * STAGE;
 #pragma unroll
     for (int i = 0; i < NPIECE; ++i) {
       const int p = wid + NW * i;
-      if (p < KCH) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_kh, (lds_ptr_t)(st + p * 1024), 16, dma_off[i], 0, 0, 0);
-      else if (p < 2 * KCH) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_kl, (lds_ptr_t)(st + OFF_KL + (p - KCH) * 1024), 16, dma_off[i], 0, 0, 0);
-      else if (p < 2 * KCH + VCH) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_vh, (lds_ptr_t)(st + OFF_VH + (p - 2 * KCH) * 1024), 16, dma_off[i], 0, 0, 0);
-      else if (p < NP) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_vl, (lds_ptr_t)(st + OFF_VL + (p - 2 * KCH - VCH) * 1024), 16, dma_off[i], 0, 0, 0);
+      if (p < KP) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_kh, (lds_ptr_t)(st + p * 1024), 16, dma_off[i], 0, 0, 0);
+      else if (p < 2 * KP) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_kl, (lds_ptr_t)(st + OFF_KL + (p - KP) * 1024), 16, dma_off[i], 0, 0, 0);
+      else if (p < 2 * KP + VP) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_vh, (lds_ptr_t)(st + OFF_VH + (p - 2 * KP) * 1024), 16, dma_off[i], 0, 0, 0);
+      else if (p < NP) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_vl, (lds_ptr_t)(st + OFF_VL + (p - 2 * KP - VP) * 1024), 16, dma_off[i], 0, 0, 0);
     }
   };
 
   f32x16 o[QS][NDB];
   float m_run[QS];
+  [[maybe_unused]] float l_run[QS];
 #pragma unroll
   for (int qs = 0; qs < QS; ++qs) {
 #pragma unroll
     for (int d = 0; d < NDB; ++d)
 #pragma unroll
       for (int i = 0; i < 16; ++i) o[qs][d][i] = 0.f;
-    m_run[qs] = -1e30f;
+    m_run[qs] = -1e30f; l_run[qs] = 0.f;
   }
   const int gi = lane & 15, gq = gi >> 2, gp = gi & 3, gcol = 16 * ((lane >> 4) & 1);
-  const int ntiles = (a.nk + KV - 1) / KV;
+  const int ntiles = (a.nk + KVT - 1) / KVT;
   dma_issue(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -742,10 +745,10 @@ k_attn_x3p(const AttnPArgs a) {
     const unsigned char* sKh = smem + buf * STAGE;
     const unsigned char* sVh = sKh + OFF_VH;
     // ---- S^T = K Q^T, three products per k-step ----
-    f32x16 st[QS][2];
+    f32x16 st[QS][NKB];
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
       for (int qs = 0; qs < QS; ++qs)
 #pragma unroll
@@ -766,10 +769,10 @@ k_attn_x3p(const AttnPArgs a) {
     }
     __builtin_amdgcn_s_setprio(0);
     if (t + 1 < ntiles) dma_issue(buf ^ 1, t + 1);            // behind the QK^T MFMAs already in the pipe; lands under softmax + PV
-    if ((t + 1) * KV > a.nk) {                                // ragged last tile
-      const int k0 = t * KV;
+    if ((t + 1) * KVT > a.nk) {                               // ragged last tile
+      const int k0 = t * KVT;
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int key = k0 + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
@@ -782,9 +785,11 @@ k_attn_x3p(const AttnPArgs a) {
     // ---- online softmax (running maximum, wave-uniform rescale) ----
 #pragma unroll
     for (int qs = 0; qs < QS; ++qs) {
-      float mx = fmaxf(st[qs][0][0], st[qs][1][0]);
+      float mx = st[qs][0][0];
 #pragma unroll
-      for (int i = 1; i < 16; ++i) mx = fmaxf(fmaxf(mx, st[qs][0][i]), st[qs][1][i]);
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, st[qs][kb][i]);
       {
         const unsigned u = __float_as_uint(mx);
         const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
@@ -794,6 +799,7 @@ k_attn_x3p(const AttnPArgs a) {
       const float mc = m_new * a.c;
       if (__builtin_amdgcn_ballot_w64(m_new != m_run[qs]) != 0) {
         const float alpha = __builtin_amdgcn_exp2f((m_run[qs] - m_new) * a.c);
+        if (!ONES) l_run[qs] *= alpha;
 #pragma unroll
         for (int d = 0; d < NDB; ++d)
 #pragma unroll
@@ -801,14 +807,22 @@ k_attn_x3p(const AttnPArgs a) {
         m_run[qs] = m_new;
       }
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
         for (int i = 0; i < 16; ++i) st[qs][kb][i] = __builtin_amdgcn_exp2f(fmaf(st[qs][kb][i], a.c, -mc));
+      if (!ONES) {
+        float ps = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) ps += st[qs][kb][i];
+        l_run[qs] += ps;
+      }
     }
     // ---- O^T += V^T P^T, three products per (16-key step, 32-dim block) ----
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+    for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         typename T::v8 ph[QS], pl[QS];
@@ -835,7 +849,7 @@ k_attn_x3p(const AttnPArgs a) {
           const unsigned char* lb = pb + (OFF_VL - OFF_VH);
           if (32 * d + 32 > HD) {                               // columns past HD: V hi = the ones column, then zeros; V lo = zeros
             const int col = 32 * d + gcol + 4 * gp;
-            if (col >= HD) { pa = pb = smem + ZOFF + (col == HD ? 0 : 8); la = lb = smem + ZOFF + 8; }
+            if (col >= HD) { pa = pb = smem + ZOFF + ((ONES && col == HD) ? 0 : 8); la = lb = smem + ZOFF + 8; }
           }
           union { s16x4 hlf[2]; typename T::v8 full; } vfh, vfl;
           vfh.hlf[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pa));
@@ -857,9 +871,15 @@ k_attn_x3p(const AttnPArgs a) {
   // ---- epilogue: normalise by the row sum, write f32 rows or [hi | lo | hi] triples ----
 #pragma unroll
   for (int qs = 0; qs < QS; ++qs) {
-    constexpr int row = HD % 32, ri = (row >> 3) * 4 + (row & 3);
-    static_assert(((row >> 2) & 1) == 0, "ones row must live in lane half 0");
-    const float inv = 1.f / __shfl(o[qs][NDB - 1][ri], r, 64);
+    float l_tot;
+    if constexpr (ONES) {
+      constexpr int row = HD % 32, ri = (row >> 3) * 4 + (row & 3);
+      static_assert(((row >> 2) & 1) == 0, "ones row must live in lane half 0");
+      l_tot = __shfl(o[qs][NDB - 1][ri], r, 64);
+    } else {
+      l_tot = l_run[qs] + __shfl_xor(l_run[qs], 32, 64);      // both halves hold partial sums of the same query
+    }
+    const float inv = 1.f / l_tot;
     if (!qvalid[qs]) continue;
     const long qrow = (long)b * a.nq + q0 + 32 * qs + r;
 #pragma unroll
@@ -1005,40 +1025,43 @@ extern "C" void sdn_debug_set_attn_head_inner(int on) { sdn_attn_detail::g_attn_
 
 // bf16x3 self-attention on hi | lo pair rows (sdn.h).  q / k / v point at the hi planes; the lo plane of every row lies `lo_offset`
 // elements on (the qkv projection's pair output: ld = 6 C, lo_offset = 3 C).  triple = 0: out f32 [B, nq, ldo]; 1: [hi | lo | hi] rows.
-extern "C" int sdn_attention_x3_pairs(const void* q, const void* k, const void* v, int32_t lo_offset, void* out, int32_t batch,
+extern "C" int sdn_attention_x3_pairs(const void* q, const void* k, const void* v, int32_t lo_offset_q, int32_t lo_offset_kv, void* out, int32_t batch,
                                       int32_t heads, int32_t nq, int32_t nk, int32_t head_dim, int32_t ldq, int32_t ldk, int32_t ldv,
                                       int32_t ldo, float scale, int32_t triple, void* stream) {
   using namespace sdn_attn_detail;
-  if (!q || !k || !v || !out || batch < 0 || heads <= 0 || nq <= 0 || nk <= 0 || lo_offset <= 0) return SDN_E_INVALID;
-  if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (lo_offset & 7) || (ldo & 3) || nk > 65535) return SDN_E_INVALID;
-  if (lo_offset < heads * head_dim || ldq < lo_offset + heads * head_dim || ldk < lo_offset + heads * head_dim ||
-      ldv < lo_offset + heads * head_dim || ldo < heads * head_dim)
+  if (!q || !k || !v || !out || batch < 0 || heads <= 0 || nq <= 0 || nk <= 0 || lo_offset_q <= 0 || lo_offset_kv <= 0) return SDN_E_INVALID;
+  if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (lo_offset_q & 7) || (lo_offset_kv & 7) || (ldo & 3) || nk > 65535) return SDN_E_INVALID;
+  if (lo_offset_q < heads * head_dim || lo_offset_kv < heads * head_dim || ldq < lo_offset_q + heads * head_dim ||
+      ldk < lo_offset_kv + heads * head_dim || ldv < lo_offset_kv + heads * head_dim || ldo < heads * head_dim)
     return SDN_E_INVALID;
   auto al = [](const void* p, int n) { return (reinterpret_cast<uintptr_t>(p) & (n - 1)) == 0; };
   if (!al(q, 16) || !al(k, 16) || !al(v, 16) || !al(out, 16)) return SDN_E_INVALID;
-  if (head_dim != 40 && head_dim != 80) return SDN_E_INVALID;
+  if (head_dim != 40 && head_dim != 80 && head_dim != 160) return SDN_E_INVALID;
   if ((long)nk * ldk * 2 >= (1L << 31) || (long)nk * ldv * 2 >= (1L << 31)) return SDN_E_INVALID;     // 31-bit DMA offsets per sample
   if (batch == 0) return SDN_OK;
   static const int qs_env = getenv("SDN_X3P_QS") ? atoi(getenv("SDN_X3P_QS")) : 0;      /* tuning knobs (tools/profile_x3.py) */
   static const int nw_env = getenv("SDN_X3P_NW") ? atoi(getenv("SDN_X3P_NW")) : 0;
   int qs = (head_dim == 40 && nq >= 2 * QB) ? 2 : 1;
-  int nw = head_dim == 80 && nq >= 2 * QB ? 8 : 4;
+  int nw = (head_dim == 80 || head_dim == 160) && nq >= 2 * QB ? 8 : 4;
   if (head_dim == 40 && qs_env) qs = qs_env == 2 ? 2 : 1;
   if (nw_env) nw = nw_env == 8 ? 8 : 4;
-  if (head_dim == 80) qs = 1;
+  if (head_dim != 40) qs = 1;
   if (head_dim == 40 && qs == 2) nw = 4;
   const int qper = 32 * nw * qs;
-  AttnPArgs a{(const unsigned short*)q, (const unsigned short*)k, (const unsigned short*)v, out, nq, nk, ldq, ldk, ldv, ldo, lo_offset,
+  AttnPArgs a{(const unsigned short*)q, (const unsigned short*)k, (const unsigned short*)v, out, nq, nk, ldq, ldk, ldv, ldo, lo_offset_q, lo_offset_kv,
               scale * 1.4426950408889634f, heads, (nq + qper - 1) / qper, batch * heads, triple ? 1 : 0};
   const unsigned grid = (unsigned)(a.nqb * a.npairs);
   hipStream_t st = (hipStream_t)stream;
   if (head_dim == 40) {
-    if (qs == 2) hipLaunchKernelGGL((k_attn_x3p<40, 2, 4>), dim3(grid), dim3(256), 0, st, a);
-    else if (nw == 8) hipLaunchKernelGGL((k_attn_x3p<40, 1, 8>), dim3(grid), dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((k_attn_x3p<40, 1, 4>), dim3(grid), dim3(256), 0, st, a);
+    if (qs == 2) hipLaunchKernelGGL((k_attn_x3p<40, 2, 4, 64>), dim3(grid), dim3(256), 0, st, a);
+    else if (nw == 8) hipLaunchKernelGGL((k_attn_x3p<40, 1, 8, 64>), dim3(grid), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((k_attn_x3p<40, 1, 4, 64>), dim3(grid), dim3(256), 0, st, a);
+  } else if (head_dim == 80) {
+    if (nw == 8) hipLaunchKernelGGL((k_attn_x3p<80, 1, 8, 64>), dim3(grid), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((k_attn_x3p<80, 1, 4, 64>), dim3(grid), dim3(256), 0, st, a);
   } else {
-    if (nw == 8) hipLaunchKernelGGL((k_attn_x3p<80, 1, 8>), dim3(grid), dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((k_attn_x3p<80, 1, 4>), dim3(grid), dim3(256), 0, st, a);
+    if (nw == 8) hipLaunchKernelGGL((k_attn_x3p<160, 1, 8, 32>), dim3(grid), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((k_attn_x3p<160, 1, 4, 32>), dim3(grid), dim3(256), 0, st, a);
   }
   return sdn_launch_status();
 }

@@ -277,7 +277,9 @@ struct Builder {
   int64_t kv_top = 0;             // bytes of persistent text K / V slots handed out so far (space SP_KV)
   bool res_pre_next = false;      // the next gemm() adds its residual into the accumulators before the k loop (sdn_gemm_desc.res_pre)
   bool triple_out_next = false;   // the next gemm() writes the triple of its result (its only reader is another x3 GEMM)
-  bool pair_out_next = false;     // the next gemm() writes hi | lo pair rows (the qkv projection of a self-attention: sdn_attention_x3_pairs)
+  bool pair_out_next = false;     // the next gemm() writes hi | lo pair rows (a projection whose only reader is sdn_attention_x3_pairs)
+  bool plan_bad = false;          // an emitter met an inconsistency: the finished plan gets ws_bytes = -1
+  bool force_x3t_next = false;    // the next gemm() takes the operand-expansion form although its A operand is not a workspace tensor (text states)
   std::set<int64_t> pairs;        // workspace offsets that hold pair rows
   bool x3t_on(const Ref& a) const { return x3t && !x3t_hold && a.space == SP_WS; }
 
@@ -285,11 +287,13 @@ struct Builder {
   void gemm(int64_t M, int N, int K, Ref a, Ref w, Ref bias, Ref out, int act_ = SDN_ACT_NONE, Ref residual = Ref(),
             int out_kind = SDN_OUT_BF16, int n_valid = 0, Ref a2 = Ref(), int K1 = 0, Ref rowbias = Ref(),
             int rows_per_batch = 0, int ld_rowbias = 0) {
-    if (x3t_on(a) && (act_ == SDN_ACT_NONE || act_ == SDN_ACT_GEGLU) && out_kind != SDN_OUT_F32_NCHW && n_valid == 0) {
+    const bool forced = force_x3t_next && x3t && !x3t_hold;
+    force_x3t_next = false;
+    if ((x3t_on(a) || forced) && (act_ == SDN_ACT_NONE || act_ == SDN_ACT_GEGLU) && out_kind != SDN_OUT_F32_NCHW && n_valid == 0) {
       // A' = [hi | lo | hi] (written by the producing GroupNorm / LayerNorm / attention / GEGLU epilogue, or by a split pass),
       // W' = [hi | hi | lo]: one bf16 GEMM with three times the k loop; F32 residual, F32 (or, for GEGLU, triple) output
       Act tmp; Ref au = a;
-      if (!tri.count(a.off)) { tmp = split3(a, a2, M, a2.space != SP_NONE ? K1 : K, a2.space != SP_NONE ? K - K1 : 0); au = R(tmp); }
+      if (a.space != SP_WS || !tri.count(a.off)) { tmp = split3(a, a2, M, a2.space != SP_NONE ? K1 : K, a2.space != SP_NONE ? K - K1 : 0); au = R(tmp); }
       Op o; o.kind = OP_GEMM; memset(&o.gd, 0, sizeof(o.gd));
       o.x3t = 1;
       o.gd.M = (int)M; o.gd.N = N; o.gd.K = 3 * K; o.gd.a_mode = SDN_A_PLAIN; o.gd.act = act_; o.gd.out_kind = SDN_OUT_F32;
@@ -297,14 +301,14 @@ struct Builder {
       const bool pair_o = pair_out_next && act_ == SDN_ACT_NONE && !tri_o && residual.space == SP_NONE;
       triple_out_next = false; pair_out_next = false;
       o.gd.x3_out = act_ == SDN_ACT_GEGLU ? 2 : (tri_o ? 3 : (pair_o ? 4 : 1)); o.gd.rows_per_batch = rows_per_batch; o.gd.ld_rowbias = ld_rowbias;
-      if (pair_o) pairs.insert(out.off);
+      if (pair_o && out.space == SP_WS) pairs.insert(out.off);
       o.a = au; o.w = x3_weight(w, N, K, K); o.bias = bias; o.rowbias = rowbias; o.residual = residual; o.out = out;
       o.flops = 2.0 * (double)M * (double)N * (double)K;
       o.bytes = 6.0 * ((double)M * K + (double)N * K) + 4.0 * (double)M * (act_ == SDN_ACT_GEGLU ? 0.75 * N : N) +
                 (residual.space != SP_NONE ? 4.0 * (double)M * N : 0.0);
       snprintf(o.label, sizeof(o.label), "k_gemm<%d>x3", sdn_gemm_pick_tile((int)M, N, 3 * K, act_));
       push_gemm(o);
-      if (act_ == SDN_ACT_GEGLU || tri_o) tri.insert(out.off);
+      if ((act_ == SDN_ACT_GEGLU || tri_o) && out.space == SP_WS) tri.insert(out.off);
       if (tmp.off >= 0) drop(tmp);                            // stream order: the next op may reuse it
       return;
     }
@@ -448,12 +452,16 @@ struct Builder {
     snprintf(o.label, sizeof(o.label), "k_repeat");
     plan->ops.push_back(o);
   }
-  void attention(Ref q, Ref k, Ref v, Ref out, int nq, int nk, int C, int ldq, int ldk, int ldv) {
+  void attention(Ref q, Ref k, Ref v, Ref out, int nq, int nk, int C, int ldq, int ldk, int ldv, bool kv_pairs = false) {
     Op o; o.kind = OP_ATTN; o.a = q; o.k = k; o.v = v; o.out = out; o.batch = B; o.heads = u->cfg.n_heads;
     o.nq = nq; o.nk = nk; o.hd = C / u->cfg.n_heads; o.ldq = ldq; o.ldk = ldk; o.ldv = ldv; o.ldo = C;
     o.scale = 1.0f / sqrtf((float)o.hd);
     if (x3t && out.space == SP_WS) { o.tri_out = 1; tri.insert(out.off); }   // its only reader is the to_out projection
-    if (q.space == SP_WS && pairs.count(q.off)) { o.pair_in = 1; pairs.erase(q.off); }   // q / k / v = column blocks of one pair-row buffer
+    if (q.space == SP_WS && pairs.count(q.off)) {               // 1: q / k / v = column blocks of ONE pair-row buffer (self-attention);
+      o.pair_in = kv_pairs ? 2 : 1; pairs.erase(q.off);         // 2: q = [hi(C) | lo(C)], k / v = column blocks of the text projection's pair rows
+    } else if (kv_pairs) {
+      plan_bad = true;                                          // K / V were written as pairs but Q was not: refuse the plan (forward rejects it)
+    }
     const double f = 4.0 * (double)B * o.heads * (double)nq * (double)nk * (double)o.hd;
     o.flops = f;
     o.bytes = 2.0 * (double)B * C * (2.0 * nq + 2.0 * nk);
@@ -553,6 +561,8 @@ struct Builder {
     // attention projections (statistics inside the kernel while N <= 960, from a read-only pre-pass above) and at
     // C = 320 for the GEGLU projection; the wide, MFMA-bound projections of the lower levels keep the LayerNorm kernel.
     const bool fold12 = u->ln_fold && C <= 640, fold3 = u->ln_fold && C == 320;
+    const int hdx = C / u->cfg.n_heads;
+    const bool x3p_cross = x3t && u->x3_pairs && u->subbatch_bytes == 0 && (hdx == 40 || hdx == 80 || hdx == 160);   // sdn_attention_x3_pairs on the cross-attention too
     // self-attention
     Act ln;
     if (!fold12 || !fold3) ln = act(rows, C, hw, x.side);
@@ -562,7 +572,7 @@ struct Builder {
     } else {
       layernorm(h, l1g, l1b, ln);
       const int hd1 = C / u->cfg.n_heads;
-      if (x3t && u->x3_pairs && (hd1 == 40 || hd1 == 80) && (int64_t)hw * 6 * C * 2 < (1LL << 31)) pair_out_next = true;
+      if (x3t && u->x3_pairs && (hd1 == 40 || hd1 == 80 || hd1 == 160) && (int64_t)hw * 6 * C * 2 < (1LL << 31)) pair_out_next = true;
       gemm(rows, 3 * C, C, R(ln), qkv, Ref(), R(qkvb));
     }
     Act at = act(rows, C, hw, x.side);
@@ -579,6 +589,7 @@ struct Builder {
       gemm_ln(h2, rows, C, C, tb + ".attn2.to_q.weight", q2w, l2g, l2b, Ref(), R(qb), SDN_ACT_NONE, u->ln_prepass_all != 0);
     } else {
       layernorm(h2, l2g, l2b, ln);
+      if (x3p_cross) pair_out_next = true;
       gemm(rows, C, C, R(ln), q2w, Ref(), R(qb));
     }
     if (rep > 1) {                                 // from here on the branches differ (their text does)
@@ -587,8 +598,10 @@ struct Builder {
       B = Bfull; rows = (int64_t)B * hw;
       Act h2f = act(rows, C, hw, x.side), qbf = act(rows, C, hw, x.side);
       repeat(h2, h2f, rep); repeat(qb, qbf, rep);
+      const bool q_is_pairs = pairs.count(qb.off) > 0;         // (a byte-wise copy: pair rows stay pair rows)
       drop(h2); drop(qb);
       h2 = h2f; qb = qbf;
+      if (q_is_pairs) pairs.insert(qb.off);
       if (!fold3) ln = act(rows, C, hw, x.side);
       at = act(rows, C, hw, x.side);
     }
@@ -602,9 +615,10 @@ struct Builder {
       // handed the same text version can skip this projection and read the previous forward's output (sdn_unet::text_version)
       const Ref kvr{SP_KV, kv_top};
       kv_top += Arena::up((int64_t)B * T * 2 * C * es);
+      if (x3p_cross) { force_x3t_next = true; pair_out_next = true; }       // text K / V as pair rows [hi(2C) | lo(2C)] (same bytes as f32)
       gemm((int64_t)B * T, 2 * C, X, Ref{SP_TEXT, text_off}, kv2, Ref(), kvr);
       plan->ops.back().text_kv = 1;
-      attention(R(qb), kvr, Ref{SP_KV, kvr.off + (int64_t)C * es}, R(at), hw, T, C, C, 2 * C, 2 * C);
+      attention(R(qb), kvr, Ref{SP_KV, kvr.off + (int64_t)C * es}, R(at), hw, T, C, C, 2 * C, 2 * C, x3p_cross);
       drop(qb);
     }
     Act h3 = act(rows, C, hw, x.side);
@@ -1028,7 +1042,7 @@ struct Builder {
     conv3x3(g, c.out_channels, npad, cow, cob, Ref{SP_OUT, 0}, 1, 0, Ref(), Ref(), 0, SDN_OUT_F32_NCHW, c.out_channels);
     drop(g);
     plan->kv_base = Arena::up(arena.peak);
-    plan->ws_bytes = plan->kv_base + kv_top;
+    plan->ws_bytes = plan_bad ? -1 : plan->kv_base + kv_top;
   }
 
   // =================================================================================================
@@ -1636,9 +1650,14 @@ static int launch_ops(sdn_unet* u, Plan* p, const char* W, const char* WS, const
                                                                                   (const float*)P(o.bias), (void*)P(o.out), stream);
           break;
         case OP_ATTN:
-          if (o.pair_in) {                             // ld = 2 x (qkv width) bf16 elements, lo plane = one width on
-            rc = sdn_attention_x3_pairs(P(o.a), P(o.a) + (size_t)o.ldo * 2, P(o.a) + (size_t)o.ldo * 4, o.ldq, (void*)P(o.out), o.batch, o.heads, o.nq,
-                                        o.nk, o.hd, 2 * o.ldq, 2 * o.ldk, 2 * o.ldv, o.ldo, o.scale, o.tri_out, stream);
+          if (o.pair_in == 1) {                        // ld = 2 x (qkv width) bf16 elements, lo plane = one width on
+            rc = sdn_attention_x3_pairs(P(o.a), P(o.a) + (size_t)o.ldo * 2, P(o.a) + (size_t)o.ldo * 4, o.ldq, o.ldq, (void*)P(o.out), o.batch, o.heads,
+                                        o.nq, o.nk, o.hd, 2 * o.ldq, 2 * o.ldk, 2 * o.ldv, o.ldo, o.scale, o.tri_out, stream);
+            break;
+          }
+          if (o.pair_in == 2) {                        // q rows [hi(C) | lo(C)]; k / v = column blocks 0 / C of the rows [hi(2C) | lo(2C)]
+            rc = sdn_attention_x3_pairs(P(o.a), P(o.k), P(o.k) + (size_t)o.ldo * 2, o.ldq, o.ldk, (void*)P(o.out), o.batch, o.heads,
+                                        o.nq, o.nk, o.hd, 2 * o.ldq, 2 * o.ldk, 2 * o.ldv, o.ldo, o.scale, o.tri_out, stream);
             break;
           }
           rc = o.n1 > 0 ? SDN_E_INVALID

@@ -156,7 +156,8 @@ def test_x3t_gemm_pair_rows_are_the_split_of_the_f32_result():
     assert torch.equal(pr[:, N:], (f - hi.float()).bfloat16())
 
 
-@pytest.mark.parametrize("B,N,d", [(2, 256, 40), (1, 300, 40), (1, 4096, 40), (2, 1024, 80), (1, 100, 80), (8, 128, 40)])
+@pytest.mark.parametrize("B,N,d", [(2, 256, 40), (1, 300, 40), (1, 4096, 40), (2, 1024, 80), (1, 100, 80), (8, 128, 40),
+                                   (2, 256, 160), (1, 64, 160), (1, 300, 160)])
 def test_attention_on_presplit_pairs_against_float64(B, N, d):
     """sdn_attention_x3_pairs (K / V planes by LDS-DMA, three bf16 products per term) vs float64 softmax attention on the values the
     pairs carry, and vs the first bf16x3 kernel (sdn_attention_x3 on the f32 tensor); triple output = split of the f32 output."""
@@ -182,3 +183,21 @@ def test_attention_on_presplit_pairs_against_float64(B, N, d):
     assert rel_l2(out, old) <= 2 * TOL
     tri = ops.attention_x3_pairs(pairs, H, triple=True)
     assert torch.equal(tri.reshape(B * N, -1), ops.split3(out.reshape(B * N, C_)))
+
+
+@pytest.mark.parametrize("B,Nq,Nk,d", [(2, 256, 77, 40), (1, 4096, 77, 40), (2, 1024, 77, 80), (1, 100, 77, 160), (8, 256, 77, 160), (1, 64, 200, 40)])
+def test_cross_attention_on_presplit_pairs_against_float64(B, Nq, Nk, d):
+    """Cross-attention form of sdn_attention_x3_pairs: queries from a [hi | lo] projection of width C, keys / values from the text
+    projection's pair rows [hi(k | v) | lo(k | v)] (different row strides and lo offsets); ragged key tail (77 keys)."""
+    H = 8
+    C_ = H * d
+    q, kv = rnd(B, Nq, C_, seed=51).cuda(), rnd(B, Nk, 2 * C_, seed=52).cuda()
+    pair = lambda t: torch.cat([t.bfloat16(), (t - t.bfloat16().float()).bfloat16()], -1).contiguous()
+    qp, kvp = pair(q), pair(kv)
+    qv = (qp[..., :C_].double() + qp[..., C_:].double()).cpu()
+    kvv = (kvp[..., :2 * C_].double() + kvp[..., 2 * C_:].double()).cpu()
+    sp = lambda t, n: t.reshape(B, n, H, d).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(sp(qv, Nq), sp(kvv[..., :C_], Nk), sp(kvv[..., C_:], Nk)).transpose(1, 2).reshape(B, Nq, C_)
+    out = ops.cross_attention_x3_pairs(qp, kvp, H)
+    assert torch.isfinite(out).all()
+    assert rel_l2(out, ref) <= TOL, rel_l2(out, ref)

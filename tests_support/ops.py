@@ -213,6 +213,19 @@ def attention_x3_pairs(qkv_pairs, heads, triple=False, scale=None):
         torch.empty((B, n, c), dtype=torch.float32, device=qkv_pairs.device)
     scale = scale if scale is not None else d ** -0.5
     base = qkv_pairs.data_ptr()
-    _lib.check(sda.lib().sdn_attention_x3_pairs(base, base + 2 * c, base + 4 * c, 3 * c, out.data_ptr(), B, heads, n, n, d, w, w, w, c,
+    _lib.check(sda.lib().sdn_attention_x3_pairs(base, base + 2 * c, base + 4 * c, 3 * c, 3 * c, out.data_ptr(), B, heads, n, n, d, w, w, w, c,
                                                 scale, 1 if triple else 0, _lib.stream_ptr()), "sdn_attention_x3_pairs")
+    return out
+
+
+def cross_attention_x3_pairs(q_pairs, kv_pairs, heads, scale=None):
+    """q_pairs [B, Nq, 2C] = [hi(q) | lo(q)], kv_pairs [B, Nk, 4C] = [hi(k | v) | lo(k | v)] -> f32 [B, Nq, C]."""
+    B, nq, w = q_pairs.shape
+    c = w // 2
+    nk, d = kv_pairs.shape[1], c // heads
+    out = torch.empty((B, nq, c), dtype=torch.float32, device=q_pairs.device)
+    scale = scale if scale is not None else d ** -0.5
+    kb = kv_pairs.data_ptr()
+    _lib.check(sda.lib().sdn_attention_x3_pairs(q_pairs.data_ptr(), kb, kb + 2 * c, c, 2 * c, out.data_ptr(), B, heads, nq, nk, d, 2 * c,
+                                                4 * c, 4 * c, c, scale, 0, _lib.stream_ptr()), "sdn_attention_x3_pairs (cross)")
     return out
