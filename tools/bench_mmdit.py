@@ -24,5 +24,5 @@ fl, at = m.flops(B)
 print(f"SD3-medium side {SIDE} B={B}: {t:.2f} ms per forward ({t / B:.2f} ms per sample), {fl / t / 1e9:.1f} TFLOP/s, attention share {at / fl:.2f}")
 m.profile_next(); m(x, timestep=900.0, encoder_hidden_states=e, pooled_projections=pl)
 rows = sorted(m.profile_read(), key=lambda r: -r["ms"]); tot = sum(r["ms"] for r in rows)
-for r in rows[:8]:
+for r in rows[:12]:
     print(f"  {r['kernel']:18s} x{r['launches']:4d} {r['ms']:8.3f} ms {100 * r['ms'] / tot:5.1f} %  {(r['flops'] / r['ms'] / 1e9) if r['flops'] else 0:7.1f} TF/s")
