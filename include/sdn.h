@@ -483,11 +483,13 @@ int sdn_row_stats_f16(const void* x, int64_t rows, int32_t c, float eps, float* 
 /* GEGLU feed-forward of a BasicTransformerBlock contracted with the block's proj_out, in ONE launch (models/transformer_2d.py:
  * 335-355 norm3 -> ff -> residual, then :845-858 proj_out + the Transformer2DModel residual):
  *   out = residual + [ GEGLU(LayerNorm(x) W1^T + b1) | x ] . w_cat^T + b_cat
- * x [M, C] 16-bit (the block's hidden state after cross-attention), row_stats [M][2] from sdn_row_stats_*, w1_folded [8C, C] /
+ * x [M, C] 16-bit (the block's hidden state after cross-attention), row_stats [M][2] from sdn_row_stats_* -- or NULL: the kernel
+ * then takes the statistics from the operand fragments of its first chunk (the arithmetic of sdn_gemm_ln_* with row_stats = NULL,
+ * eps = 1e-5) and no pass over x is needed --, w1_folded [8C, C] /
  * c1 / d1 [8C] from sdn_ln_fold over the value / gate-interleaved GEGLU weight, w_cat [C, 5C] = [Wpo W2 | Wpo] and
  * b_cat [C] = Wpo b2 + bpo (formed once per weight set by sdn_unet_prepare), residual / out [M, C] 16-bit; col_stats nullable,
  * [ceil(M / 128)][C][2] as sdn_gemm_stats_*.  The [M, 4C] hidden activation stays in LDS.  Bit-identical to sdn_gemm_ln_*
- * (act GEGLU) followed by the two-source sdn_gemm_* it replaces.  dtype 0 = bf16, 1 = fp16; only C == 320 is instantiated
+ * (act GEGLU, the same row_stats argument) followed by the two-source sdn_gemm_* it replaces.  dtype 0 = bf16, 1 = fp16; only C == 320 is instantiated
  * (SDN_E_INVALID otherwise: the caller keeps the two-launch form). */
 int sdn_ffn_geglu_fused(int32_t dtype, int64_t M, int32_t C, const void* x, const float* row_stats, const void* w1_folded,
                         const float* c1, const float* d1, const void* w_cat, const float* b_cat, const void* residual, void* out,

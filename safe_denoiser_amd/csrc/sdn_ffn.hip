@@ -58,7 +58,8 @@ __device__ unsigned long long* g_ffn_stamps = nullptr;
 
 struct FfnArgs {
   const void* x;            // h3 [M, C] 16 bit
-  const float* stats;       // [M][2] (mean, rstd) of the rows of x (sdn_row_stats_*)
+  const float* stats;       // [M][2] (mean, rstd) of the rows of x (sdn_row_stats_*); nullptr = taken from the A fragments of the
+                            // first chunk's projection (k_gemm_dma's LNF = 1 arithmetic, eps = 1e-5: no pre-pass over x)
   const void* w1;           // [8C, C] 16 bit: value/gate rows interleaved in groups of 16, LayerNorm gamma folded in
   const float* c1; const float* d1;   // [8C] fold coefficients (sdn_ln_fold)
   const void* w2;           // [C, 5C] 16 bit: [Wpo W2 | Wpo]
@@ -161,13 +162,17 @@ k_ffn320(const FfnArgs a) {
 #pragma unroll
       for (int j = 0; j < NREP; ++j) acc[i][j] = bv[j];
   }
-  float ln_mu[4], ln_rs[4];
+  float ln_mu[4] = {0.f, 0.f, 0.f, 0.f}, ln_rs[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool own_stats = a.stats == nullptr;                    // wave-uniform
+  if (!own_stats) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + fr;
-    const float2 st2 = *reinterpret_cast<const float2*>(a.stats + 2 * (long)(m < a.M ? m : 0));
-    ln_mu[i] = st2.x; ln_rs[i] = st2.y;
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wm * 64 + i * 16 + fr;
+      const float2 st2 = *reinterpret_cast<const float2*>(a.stats + 2 * (long)(m < a.M ? m : 0));
+      ln_mu[i] = st2.x; ln_rs[i] = st2.y;
+    }
   }
+  float ln_s1[4] = {0.f, 0.f, 0.f, 0.f}, ln_s2[4] = {0.f, 0.f, 0.f, 0.f};   // own_stats: per-row sum / sum of squares (chunk 0 only)
   // fold coefficients of this wave's value / gate fragment pair
   f32x4 cv[2], dv[2];
   auto load_cd = [&](int jc) {
@@ -203,6 +208,10 @@ k_ffn320(const FfnArgs a) {
         for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const typename T::v8*>(sa + lds_off(i * 16 + fr, ks * 4 + fq));
 #pragma unroll
         for (int j = 0; j < 2; ++j) fw[j] = *reinterpret_cast<const typename T::v8*>(sw + lds_off(j * 16 + fr, ks * 4 + fq));
+        if (own_stats && jc == 0) {                              // the first chunk's k loop passes every column of this wave's rows
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { ln_s1[i] = T::dot_ones(fa[i], ln_s1[i]); ln_s2[i] = T::dot_self(fa[i], ln_s2[i]); }
+        }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -218,6 +227,18 @@ k_ffn320(const FfnArgs a) {
       SDN_FTS_MARK(2)                                                        // ... wait for the next k-tile
       __builtin_amdgcn_s_barrier();
       SDN_FTS_MARK(3)                                                        // ... barrier
+    }
+    if (own_stats && jc == 0) {                                  // as k_gemm_dma (LNF = 1): the other three lane groups hold the rest of a row
+      const float invk = 1.0f / (float)C;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float a1 = ln_s1[i], a2 = ln_s2[i];
+        a1 += __shfl_xor(a1, 16, 64); a2 += __shfl_xor(a2, 16, 64);
+        a1 += __shfl_xor(a1, 32, 64); a2 += __shfl_xor(a2, 32, 64);
+        const float mu = a1 * invk;
+        const float var = fmaxf(a2 * invk - mu * mu, 0.f);
+        ln_mu[i] = mu; ln_rs[i] = __builtin_amdgcn_rsqf(var + 1e-5f);
+      }
     }
     // ---- GEGLU: LayerNorm fold, value * gelu(gate), 16 bit -> H (a k-tile image in the stage read last) ----
     unsigned char* sh = smem + OFF_RING + ((jc * KT1 + KT1 - 1) & 1) * XIMG;
@@ -326,7 +347,7 @@ extern "C" int sdn_ffn_geglu_fused(int32_t dtype, int64_t M, int32_t C, const vo
                         const float* d1, const void* w_cat, const float* b_cat, const void* residual, void* out, float* col_stats,
                         void* stream) {
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-  if (dtype < 0 || dtype > 1 || C != 320 || M < 0 || !x || !row_stats || !w1_folded || !c1 || !d1 || !w_cat || !b_cat || !residual || !out)
+  if (dtype < 0 || dtype > 1 || C != 320 || M < 0 || !x || !w1_folded || !c1 || !d1 || !w_cat || !b_cat || !residual || !out)
     return SDN_E_INVALID;
   if (!al16(x) || !al16(w1_folded) || !al16(c1) || !al16(d1) || !al16(w_cat) || !al16(b_cat) || !al16(residual) || !al16(out) ||
       (reinterpret_cast<uintptr_t>(row_stats) & 7) || (reinterpret_cast<uintptr_t>(col_stats) & 7))

@@ -151,6 +151,7 @@ struct sdn_unet {
   bool ln_fold = true;                  // BasicTransformerBlock LayerNorms folded into their consumer GEMMs where it pays
   int ln_prepass_all = 0;               // debug A/B: 1 = every folded LayerNorm takes its row statistics from the pre-pass
   bool ff_fuse = true;                  // FeedForward's output linear and the block's proj_out (no nonlinearity between them)
+  bool ffn_own_stats = true;            // k_ffn320 takes norm3's row statistics from its own operand fragments (no sdn_row_stats pass)
   bool ffn_fuse = true;                 // ... and the GEGLU projection in front of them: one launch, hidden activation in LDS (C = 320)
                                         // contracted into ONE GEMM over [ff | h3] with the product weight (sdn_linear_pair_fold)
   struct FoldJob { int64_t w, gamma, beta, bias, wf, c, d; int rows, cols; int kind = 0; int group = 0; };   // kind 0: LayerNorm fold; 1: linear pair; 2: bf16x3 weight expansion (sdn_expand3_weights)
@@ -637,11 +638,15 @@ struct Builder {
       const bool fresh2 = u->param_index.find(pfx + ".proj_out.weight#ff") == u->param_index.end();
       Ref wcat = derived(pfx + ".proj_out.weight#ff", (int64_t)C * 5 * C * 2), bcat = derived(pfx + ".proj_out.bias#ff", (int64_t)C * 4);
       if (fresh2) { sdn_unet::FoldJob j{f2w.off, pow_.off, f2b.off, pob.off, wcat.off, bcat.off, -1, C, 4 * C}; j.kind = 1; u->fold_jobs.push_back(j); }
-      Act st = act(rows, 2, 0, 0, 4);
-      { Op o; o.kind = OP_ROWSTATS; o.a = R(h3); o.rows = rows; o.c1 = C; o.eps = 1e-5f; o.out = R(st);
-        o.bytes = 2.0 * rows * C; snprintf(o.label, sizeof(o.label), "k_row_stats"); plan->ops.push_back(o); }
+      // norm3's row statistics: from the operand fragments inside k_ffn320 (ffn_own_stats), or by a read-only pre-pass over h3
+      Act st;
+      if (!u->ffn_own_stats) {
+        st = act(rows, 2, 0, 0, 4);
+        Op o; o.kind = OP_ROWSTATS; o.a = R(h3); o.rows = rows; o.c1 = C; o.eps = 1e-5f; o.out = R(st);
+        o.bytes = 2.0 * rows * C; snprintf(o.label, sizeof(o.label), "k_row_stats"); plan->ops.push_back(o);
+      }
       want_stats(out);
-      Op o; o.kind = OP_FFN; o.a = R(h3); o.ln_stats = R(st); o.w = wf; o.ln_c = c1; o.ln_d = d1; o.a2 = wcat; o.bias = bcat;
+      Op o; o.kind = OP_FFN; o.a = R(h3); if (st.off >= 0) o.ln_stats = R(st); o.w = wf; o.ln_c = c1; o.ln_d = d1; o.a2 = wcat; o.bias = bcat;
       o.residual = R(rep > 1 ? *x_full : x); o.out = R(out); o.rows = rows; o.c1 = C;
       o.col = pending_cols; pending_cols = Ref();
       o.flops = 2.0 * (double)rows * ((double)8 * C * C + (double)C * 5 * C);
@@ -649,12 +654,15 @@ struct Builder {
       snprintf(o.label, sizeof(o.label), "k_ffn320");
       plan->ops.push_back(o);
       plan->flops += o.flops;
-      drop(st); drop(h3);
+      if (st.off >= 0) drop(st);
+      drop(h3);
       return;
     }
     Act ff = act(rows, 4 * C, hw, x.side);
     if (fold3) {
-      gemm_ln(h3, rows, 8 * C, C, tb + ".ff.net.0.proj.weight", f1w, l3g, l3b, f1b, R(ff), SDN_ACT_GEGLU, true);
+      // (the two-launch form of the C = 320 feed-forward is the fallback / equality partner of k_ffn320: it takes its statistics
+      //  the way that kernel does -- from the fragments when ffn_own_stats, else from the pre-pass)
+      gemm_ln(h3, rows, 8 * C, C, tb + ".ff.net.0.proj.weight", f1w, l3g, l3b, f1b, R(ff), SDN_ACT_GEGLU, !u->ffn_own_stats);
     } else {
       layernorm(h3, l3g, l3b, ln);
       gemm(rows, 8 * C, C, R(ln), f1w, f1b, R(ff), SDN_ACT_GEGLU);
@@ -1915,6 +1923,13 @@ extern "C" void sdn_debug_set_ffn_fuse(sdn_unet* u, int on) {   // one-launch GE
 extern "C" void sdn_debug_set_ff_fuse(sdn_unet* u, int on) {
   if (!u) return;
   u->ff_fuse = on != 0;
+  drop_graphs(u);
+  u->plans.clear();
+}
+
+extern "C" void sdn_debug_set_ffn_own_stats(sdn_unet* u, int on) {
+  if (!u) return;
+  u->ffn_own_stats = on != 0;
   drop_graphs(u);
   u->plans.clear();
 }

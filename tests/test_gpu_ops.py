@@ -516,6 +516,13 @@ def test_fused_geglu_feed_forward_is_bit_identical_to_the_two_launches(dt, M):
     hid = y[:, :4 * Cc] * F.gelu(y[:, 4 * Cc:])
     ref = res.float().cpu() + torch.cat([hid, x.float().cpu()], 1) @ wcat.float().cpu().T + bcat.cpu()
     assert rel_l2(got, ref) <= (6e-3 if dt == torch.bfloat16 else 8e-4)
+    # row_stats = NULL: norm3's statistics from the kernel's own operand fragments = the bits of sdn_gemm_ln_* WITHOUT a pre-pass
+    # (fragment statistics, same dot-product order), followed by the same two-source GEMM
+    ff1 = ops.gemm_ln(x, w1i, gamma.cuda(), beta.cuda(), b1i, act=2, prepass=False)
+    want1 = ops.gemm(ff1, wcat, a2=x, bias=bcat, residual=res)
+    got1 = ops.ffn_fused(x, w1i, gamma.cuda(), beta.cuda(), b1i, wcat, bcat, res, own_stats=True)
+    assert torch.equal(got1.view(torch.int16), want1.view(torch.int16)), float((got1.float() - want1.float()).abs().max())
+    assert rel_l2(got1, ref) <= (6e-3 if dt == torch.bfloat16 else 8e-4)
     # no column sums requested; other widths are refused (the caller keeps the two-launch form)
     assert torch.equal(ops.ffn_fused(x, w1i, gamma.cuda(), beta.cuda(), b1i, wcat, bcat, res).view(torch.int16), want.view(torch.int16))
     rc = sda.lib().sdn_ffn_geglu_fused(0, 128, 640, x.data_ptr(), cs_a.data_ptr(), w1i.data_ptr(), b1i.data_ptr(), b1i.data_ptr(),

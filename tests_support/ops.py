@@ -125,8 +125,9 @@ def gemm_ln(x, w, gamma, beta, bias=None, act=0, eps=1e-5, prepass=False):
     return out
 
 
-def ffn_fused(x, w1, gamma, beta, bias1, w_cat, b_cat, residual, col_stats=None, eps=1e-5):
-    """sdn_ln_fold + sdn_row_stats_* + sdn_ffn_geglu_fused (w1 [8C, C] value / gate-interleaved, w_cat [C, 5C])."""
+def ffn_fused(x, w1, gamma, beta, bias1, w_cat, b_cat, residual, col_stats=None, eps=1e-5, own_stats=False):
+    """sdn_ln_fold + sdn_row_stats_* + sdn_ffn_geglu_fused (w1 [8C, C] value / gate-interleaved, w_cat [C, 5C]).
+    own_stats: row_stats = NULL, the kernel takes norm3's statistics from its own operand fragments."""
     N, K = w1.shape
     M = x.shape[0]
     code = 1 if x.dtype == torch.float16 else 0
@@ -134,8 +135,10 @@ def ffn_fused(x, w1, gamma, beta, bias1, w_cat, b_cat, residual, col_stats=None,
     c = torch.empty(N, dtype=torch.float32, device=x.device); dv = torch.empty_like(c)
     p = lambda t: None if t is None else t.data_ptr()
     _lib.check(sda.lib().sdn_ln_fold(code, p(w1), p(gamma), p(beta), p(bias1), N, K, p(wf), p(c), p(dv), _lib.stream_ptr()), "sdn_ln_fold")
-    stats = torch.empty(M, 2, dtype=torch.float32, device=x.device)
-    _lib.check(_fn("row_stats", x)(p(x), M, K, eps, p(stats), _lib.stream_ptr()), "sdn_row_stats")
+    stats = None
+    if not own_stats:
+        stats = torch.empty(M, 2, dtype=torch.float32, device=x.device)
+        _lib.check(_fn("row_stats", x)(p(x), M, K, eps, p(stats), _lib.stream_ptr()), "sdn_row_stats")
     out = torch.empty((M, K), dtype=x.dtype, device=x.device)
     _lib.check(sda.lib().sdn_ffn_geglu_fused(code, M, K, p(x), p(stats), p(wf), p(c), p(dv), p(w_cat), p(b_cat), p(residual), p(out),
                                              p(col_stats), _lib.stream_ptr()), "sdn_ffn_geglu_fused")

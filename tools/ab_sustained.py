@@ -21,6 +21,9 @@ for rnd in range(3):
         if os.environ.get("RESPRE") == "1":                      # second arm = attention output projections with the epilogue residual (res_pre off)
             import ctypes as C
             sda.lib().sdn_debug_set_res_pre(C.c_void_p(u._h.value), 0 if v else 1)
+        elif os.environ.get("FFNSTATS") == "1":                  # second arm = norm3's row statistics by the sdn_row_stats pre-pass
+            import ctypes as C
+            sda.lib().sdn_debug_set_ffn_own_stats(C.c_void_p(u._h.value), 0 if v else 1)
         elif TEXTVER:
             u.set_text_version(5 if v else 0)
         else:
