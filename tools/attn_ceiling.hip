@@ -31,8 +31,9 @@ __device__ __forceinline__ unsigned pk(float a, float b) {
   return *reinterpret_cast<unsigned*>(&p);
 }
 
-// MODE 0 = full mix, 1 = MFMAs only, 2 = vector work only
-template <int MODE, int QS>
+// MODE 0 = full mix, 1 = MFMAs only, 2 = vector work only.  NOMAX: the optimistic pass of round 4's second session (no per-tile
+// running maximum: 16 v_max3 + the cross-half swap per query set and tile drop out of the vector side; `opt_*` rows)
+template <int MODE, int QS, bool NOMAX = false>
 __global__ void __launch_bounds__(256) k_mix(float* out, int tiles) {
   const int lane = threadIdx.x & 63;
   bf16x8 kf[2][3], qf[QS][3], vf[8];
@@ -63,6 +64,7 @@ __global__ void __launch_bounds__(256) k_mix(float* out, int tiles) {
     if (MODE != 1) {
 #pragma unroll
       for (int s = 0; s < QS; ++s) {
+        if (!NOMAX) {
         float mx = fmaxf(st[s][0][0], st[s][1][0]);
 #pragma unroll
         for (int i = 1; i < 16; ++i) mx = fmaxf(fmaxf(mx, st[s][0][i]), st[s][1][i]);
@@ -70,6 +72,7 @@ __global__ void __launch_bounds__(256) k_mix(float* out, int tiles) {
         const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
         mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
         m_hi[s] = fmaxf(m_hi[s], mx);
+        }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -210,15 +213,15 @@ static double run_alt(int blocks, int tiles, float* out) {
   return flop / (ms * 1e-3) / 1e12;
 }
 
-template <int MODE, int QS>
+template <int MODE, int QS, bool NOMAX = false>
 static double run(int blocks, int tiles, float* out) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  hipLaunchKernelGGL((k_mix<MODE, QS>), dim3(blocks), dim3(256), 0, 0, out, tiles);   // warm-up (clock ramp)
-  hipLaunchKernelGGL((k_mix<MODE, QS>), dim3(blocks), dim3(256), 0, 0, out, tiles);
+  hipLaunchKernelGGL((k_mix<MODE, QS, NOMAX>), dim3(blocks), dim3(256), 0, 0, out, tiles);   // warm-up (clock ramp)
+  hipLaunchKernelGGL((k_mix<MODE, QS, NOMAX>), dim3(blocks), dim3(256), 0, 0, out, tiles);
   hipDeviceSynchronize();
   hipEventRecord(e0, 0);
-  for (int r = 0; r < 5; ++r) hipLaunchKernelGGL((k_mix<MODE, QS>), dim3(blocks), dim3(256), 0, 0, out, tiles);
+  for (int r = 0; r < 5; ++r) hipLaunchKernelGGL((k_mix<MODE, QS, NOMAX>), dim3(blocks), dim3(256), 0, 0, out, tiles);
   hipEventRecord(e1, 0);
   hipEventSynchronize(e1);
   float ms = 0.f;
@@ -246,6 +249,13 @@ int main() {
     const int blocks = cus * per_cu;
     printf(" \"qs1_blocks_per_cu_%d\": {\"mix\": %.1f, \"mfma_only\": %.1f, \"valu_only\": %.1f},\n", per_cu,
            run<0, 1>(blocks, tiles, out), run<1, 1>(blocks, tiles, out), run<2, 1>(blocks, tiles, out));
+  }
+  for (int per_cu = 2; per_cu <= 4; per_cu *= 2) {       // the optimistic pass (no running maximum)
+    const int blocks = cus * per_cu;
+    printf(" \"opt_qs2_blocks_per_cu_%d\": {\"mix\": %.1f, \"mfma_only\": %.1f, \"valu_only\": %.1f},\n", per_cu,
+           run<0, 2, true>(blocks, tiles, out), run<1, 2, true>(blocks, tiles, out), run<2, 2, true>(blocks, tiles, out));
+    printf(" \"opt_qs1_blocks_per_cu_%d\": {\"mix\": %.1f, \"mfma_only\": %.1f, \"valu_only\": %.1f},\n", per_cu,
+           run<0, 1, true>(blocks, tiles, out), run<1, 1, true>(blocks, tiles, out), run<2, 1, true>(blocks, tiles, out));
   }
   for (int per_cu = 2; per_cu <= 4; per_cu *= 2) {
     const int blocks = cus * per_cu;
