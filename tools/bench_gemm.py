@@ -27,6 +27,11 @@ SHAPES = [  # name, M, N, K, conv(H, Cin) or None, act
     ("ff1 geglu 1280 @16", B * 256, 10240, 1280, None, 2),
     ("qkv 640 @32", B * 1024, 1920, 640, None, 0),
     ("qkv 1280 @16", B * 256, 3840, 1280, None, 0),
+    ("x3k ff2 320", B * 4096, 320, 3840, None, 0),          # the bf16x3 plan's k loops (K' = 3 K) on narrow N: A streamed once from HBM
+    ("x3k proj 320", B * 4096, 320, 960, None, 0),
+    ("x3k ff2 640", B * 1024, 640, 7680, None, 0),
+    ("x3k proj 640", B * 1024, 640, 1920, None, 0),
+    ("x3k proj 1280", B * 256, 1280, 3840, None, 0),
     ("mmdit qkv 1536", B * 1024, 4608, 1536, None, 0),
     ("mmdit ff1 1536", B * 1024, 6144, 1536, None, 3),
 ]
