@@ -116,6 +116,48 @@ def _attn_pad(label: str) -> float:
     return (qk + pv) / (2.0 * d)
 
 
+def label_symbol(label: str, tname: str):
+    """Plan label -> (display name of the kernel SYMBOL, regex matching its demangled name in the rocprof / PMC records).
+    Several labels share one symbol (`k_gemm<10>` and `k_gemm<10>/rp` -- residual into the accumulators -- are both
+    k_gemm_dma<T, 10, 4, 2, 0>); `/lnL` carries the symbol's LNF parameter, `k_conv_slab<W>` its map width.  WGM follows from NREP
+    (>= 8: the 256-row tile); NSTAGE is 2 except for small grids of the NREP = 5 tile, which the label does not tell apart."""
+    import re
+    t = f"Sdn{tname}"
+    m = re.fullmatch(r"k_gemm<(\d+)>(/rp|/ln(\d)|/s\d+|x3)?", label)
+    if m and m.group(2) != "x3":
+        nrep, lnf = int(m.group(1)), int(m.group(3) or 0)
+        wgm = 4 if nrep >= 8 else 2
+        if (m.group(2) or "").startswith("/s"):
+            return label, None                                          # split-K forms (small batches only)
+        st = r"\d+" if nrep == 5 else "2"
+        return f"k_gemm_dma<{t}, {nrep}, {wgm}, {'2|4' if nrep == 5 else '2'}, {lnf}>", rf"k_gemm_dma<{t}, {nrep}, {wgm}, {st}, {lnf}>"
+    m = re.fullmatch(r"k_conv_slab<(\d+)>", label)
+    if m:
+        return f"k_conv_slab<{t}, {m.group(1)}>", rf"k_conv_slab<{t}, {m.group(1)}>"
+    m = re.fullmatch(r"k_attn<(\d+)>", label)
+    if m:                                       # one label, two instantiations (query sets per wave: self- / cross-attention)
+        return f"k_attn<{t}, {m.group(1)}, ...>", rf"k_attn<{t}, {m.group(1)},"
+    if label == "k_ffn320":
+        return f"k_ffn320<{t}>", rf"k_ffn320<{t}>"
+    return label, None
+
+
+def _pmc_records(pattern: str, lib_sha: str):
+    """Newest profiles/round*_<pattern>.json whose libsdn sha equals the running library's -> (record | None, source note)."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"round*_{pattern}.json")),
+                   key=lambda f: int("".join(ch for ch in os.path.basename(f).split("_")[0] if ch.isdigit()) or 0))
+    if not cands:
+        return None, f"no profiles/round*_{pattern}.json record"
+    rec = json.load(open(cands[-1]))
+    meta = rec.get("__meta__", {})
+    if meta.get("libsdn_sha256") != lib_sha:
+        return None, (f"profiles/{os.path.basename(cands[-1])} was collected on another build of libsdn.so (record "
+                      f"{str(meta.get('libsdn_sha256'))[:12]}, running {lib_sha[:12]}): stale, not reported")
+    return rec, (f"profiles/{os.path.basename(cands[-1])} (git {(meta.get('git_head') or '?')[:10]}, same libsdn.so as this run, "
+                 f"batch {meta.get('batch', '?')}; {meta.get('collected_with', '')})")
+
+
 def cpu_baseline(args):
     """The CPU oracle (a port of the reference loop, fp32 torch ops) on the host cores, on a BOUNDED sample of the timed
     workload: TWO of the 50 denoising iterations of ONE prompt at the full SD-v1.4 size -- t = 981 inside the repellency
@@ -137,6 +179,9 @@ def cpu_baseline(args):
     lat = torch.randn(1, 4, 64, 64, generator=g)
     text = torch.randn(nb, 77, 768, generator=g)
     s = osch.DDPM(); s.set_timesteps(50)
+    t0 = time.perf_counter()
+    unet(lat, 500.0, text[:1])                                         # untimed: pages the 3.4 GB of weights in, spins the thread pool up
+    t_warm = time.perf_counter() - t0
     times = {}
     for t in (981, 761):
         t0 = time.perf_counter()
@@ -158,6 +203,10 @@ def cpu_baseline(args):
         t_dec = time.perf_counter() - t0
     per_image = 11 * times[981] + 39 * times[761] + t_dec
     return {"value": 1.0 / per_image, "unit": "images/sec", "cores": cores, "kind": "port",
+            "threads": {"torch_get_num_threads": cores, "torch_get_num_interop_threads": torch.get_num_interop_threads(),
+                        "os_cpu_count": os.cpu_count(), "sched_affinity": len(os.sched_getaffinity(0)),
+                        "OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS")},
+            "warmup_forward_s": t_warm,
             "sample": f"1 prompt x 2 of 50 iterations at full size: t=981 {times[981]:.2f} s (window: UNet b={nb} fp32 + CFG + x0 "
                       f"probe + repellency M={args.refs} + re-noise + DDPM step), t=761 {times[761]:.2f} s (UNet + CFG + DDPM step)"
                       + (f", VAE decode {t_dec:.2f} s" if t_dec else "") +
@@ -273,6 +322,98 @@ def measure_e2e_precision(args, dev, proc, P, mine, precision="bf16x3", timed_ba
            "ids_to_latents_rel_l2_vs_fp32_chain": "5.4e-5 max over 8 prompts, all SAFREE decisions equal (profiles/round4_e2e_ids.json)",
            "unet_tflops_algorithmic_upper_bound": fl * args.inference_steps / dt / 1e12}
     del u, enc, vae, pipe
+    torch.cuda.empty_cache()
+    return res
+
+
+def measure_job(args, dev, P, gate_beta, total=None):
+    """The job a USER runs: `driver.run_job` -- the body of the reference's main(), run_nudity.py:341-529 -- over
+    the whole `--total-prompts`-row prompt table on this one GPU: table read, batching, the pipeline call per batch, and per image
+    the PNG writes into {safe|unsafe,all}/ + a (stub) classifier + logs.txt, then detect_dict.json / config.yaml; real files in a
+    temporary directory.  The host I/O of batch k overlaps the GPU's batch k + 1 (driver._OrderedWriter).  Everything is built
+    from scratch here so that START-UP is timed the way a fresh process pays it: weights (synthetic, generated on the GPU: stands
+    where the checkpoint read + upload would be) -> sdn_unet_prepare (derived weight regions) -> first forward at the batch size
+    (launch plan + arena + code objects) -> R5 calibration of the gate -> communicator (none at N = 1)."""
+    import contextlib
+    import shutil
+    import yaml
+    from safe_denoiser_amd import driver
+    from safe_denoiser_amd.clip import CLIPTextModel
+    from safe_denoiser_amd.pipeline import SafeDenoiserPipeline, make_scheduler
+    from safe_denoiser_amd.repellency import repellency_methods_threshold as thr
+    from safe_denoiser_amd.unet import UNet2DConditionModel
+    from safe_denoiser_amd.vae import AutoencoderKL
+    from tests_support.fake_tokenizer import FakeCLIPTokenizer
+    total = total or args.total_prompts
+    sync = torch.cuda.synchronize
+    st = {}
+    sync(); t0 = time.perf_counter()
+    u = UNet2DConditionModel(dtype=_dtype(args), latent_repeat=3); u.load_synthetic_on_device(1234, device=dev)
+    enc = CLIPTextModel(dtype=_dtype(args)); enc.load_synthetic_on_device(4242, device=dev)
+    vae = AutoencoderKL(dtype=_dtype(args)); vae.load_synthetic_on_device(4321, device=dev)
+    sync(); t1 = time.perf_counter()
+    u._prepare(); enc._prepare(); vae._prepare()                       # (already part of the loads above: re-run to time it on its own)
+    sync(); t2 = time.perf_counter()
+    st["weights_s"], st["sdn_unet_prepare_s"] = (t1 - t0) - (t2 - t1), t2 - t1
+    x = torch.randn(P, 4, 64, 64, device=dev)
+    tb = u.prepare_text(torch.randn(3 * P, 77, 768, device=dev))
+    y = torch.empty((3 * P, 4, 64, 64), device=dev)
+    u.forward_into(x, 981.0, tb, y)
+    sync(); t3 = time.perf_counter()
+    st["plan_arena_first_forward_s"] = t3 - t2
+    del x, tb, y
+    tmp = tempfile.mkdtemp(prefix="sdn_job_")
+    g = torch.Generator().manual_seed(0)
+    refs = torch.randn(args.refs, 4, 64, 64, generator=g)
+    refs = refs / torch.norm(refs, dim=1, keepdim=True)
+    rpath = os.path.join(tmp, "repellency_proj_ref.pt")
+    torch.save(refs, rpath)
+    knobs = dict(scale=0.33, sigma=3.15, beta_threshold_margin=1.6, proj_ref_path=rpath, cache_proj_ref=True)
+    cal = thr.get_repellency_method("kernel_fast", torch.zeros(1, device=dev), None, None, 50, 1000, 0.00085, 0.012, n_embed=16,
+                                    scheduler=make_scheduler("ddpm"), proj_noisy_ref_path_for_beta=None, **knobs)
+    r5 = float(cal.beta_threshold)
+    sync(); t4 = time.perf_counter()
+    st["r5_calibration_s"] = t4 - t3
+    st["communicator_s"] = 0.0
+    st["startup_s"] = t4 - t0
+    del cal
+    proc = thr.get_repellency_method("kernel_fast", torch.zeros(1, device=dev), None, None, 50, 1000, 0.00085, 0.012, n_embed=16,
+                                     beta_threshold=gate_beta, **knobs)          # the headline's gate (every pair fires on synthetic weights)
+    pipe = SafeDenoiserPipeline(u, make_scheduler(args.scheduler), variant="threshold_time", vae=vae, text_encoder=enc,
+                                tokenizer=FakeCLIPTokenizer())
+    # the prompt table (i2p dialect: case_number, prompt, categories, evaluation_seed) + the reference's three configuration layers
+    with open(os.path.join(tmp, "prompts.csv"), "w") as f:
+        f.write("case_number,prompt,categories,evaluation_seed\n")
+        for i in range(total):
+            f.write(f'{i},"{synthetic_prompt(i)}",sexual,{1000 + i}\n')
+    task = {"repellency": {"method": "kernel_fast", "n_embed": 16, "guidance_scale": 0.0, "params": {k_: v for k_, v in knobs.items()}},
+            "data": {"name": "nudity"}, "mean_processor": {}}
+    yaml.safe_dump(task, open(os.path.join(tmp, "task.yaml"), "w"))
+    cfg = {"erase_id": "safree_neg_prompt_rep_threshold_time", "nudity": "nudity", "data": os.path.join(tmp, "prompts.csv"),
+           "save_dir": os.path.join(tmp, "out"), "safree": True, "svf": True, "lra": True, "task_config": os.path.join(tmp, "task.yaml"),
+           "num_inference_steps": args.inference_steps}
+    json.dump(cfg, open(os.path.join(tmp, "cfg.json"), "w"))
+    jargs = driver.parse_args(["--config", os.path.join(tmp, "cfg.json")])
+    verdict = lambda imgs, threshold: (bool(imgs[0].getpixel((0, 0))[0] & 1), 0.5)       # stands where NudeNet sits (out of scope)
+    tm = {}
+    sync(); t5 = time.perf_counter()
+    with open(os.devnull, "w") as null, contextlib.redirect_stdout(null):            # Logger.log prints every line (as the reference does)
+        driver.run_job(jargs, pipe, proc, driver.load_task_config(jargs.task_config), eval_func=verdict, prompts_per_batch=P,
+                       device=dev, timings=tm)
+    sync(); t6 = time.perf_counter()
+    nb_ = tm["batches"]
+    files = sum(len(fs) for _, _, fs in os.walk(cfg["save_dir"]))
+    png_bytes = sum(os.path.getsize(os.path.join(d_, f_)) for d_, _, fs in os.walk(cfg["save_dir"]) for f_ in fs if f_.endswith(".png"))
+    steady = (sum(b_["prompts"] for b_ in nb_[1:]) / sum(b_["gpu_s"] for b_ in nb_[1:])) if len(nb_) > 1 else None
+    res = {"what": f"driver.run_job over the {total}-row prompt table on 1 GPU, README-default erase_id safree_neg_prompt_rep_threshold_time, "
+                   f"{P} prompts per batch, real PNG writes ({files} files, {png_bytes / 1e6:.0f} MB) + stub classifier + logs, host I/O "
+                   f"overlapped with the next batch",
+           "startup": st, "startup_s": st["startup_s"], "first_batch_s": nb_[0]["gpu_s"], "batches": [b_["prompts"] for b_ in nb_],
+           "steady_images_per_sec": steady, "total_s": t6 - t5, "job_images_per_sec": total / (t6 - t5),
+           "host_io_busy_s": tm["host_io_s"], "host_io_share_of_job": tm["host_io_s"] / (t6 - t5),
+           "whole_process_estimate_s": st["startup_s"] + (t6 - t5), "r5_calibrated_beta_threshold": r5}
+    shutil.rmtree(tmp, ignore_errors=True)
+    del u, enc, vae, pipe, proc
     torch.cuda.empty_cache()
     return res
 
@@ -564,8 +705,18 @@ def main():
             a = rows_acc.setdefault(r["kernel"], dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
             for f in ("launches", "ms", "flops", "bytes"):
                 a[f] += r[f]
-    dom = max(rows_acc, key=lambda k_: rows_acc[k_]["ms"])
-    d = rows_acc[dom]
+    # the dominant kernel is picked by SYMBOL: plan labels that launch the same symbol are summed first (the
+    # label split k_gemm<10> | k_gemm<10>/rp had let a smaller symbol win), the per-label split is kept underneath
+    tname = "F16" if args.dtype == "f16" else "BF16"
+    by_sym = {}
+    for lab, v in rows_acc.items():
+        name, pat = label_symbol(lab, tname)
+        e = by_sym.setdefault(name, dict(pattern=pat, labels={}, launches=0, ms=0.0, flops=0.0, bytes=0.0))
+        e["labels"][lab] = v
+        for f in ("launches", "ms", "flops", "bytes"):
+            e[f] += v[f]
+    dom = max(by_sym, key=lambda k_: by_sym[k_]["ms"])
+    d = by_sym[dom]
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
     attn = {k_: v for k_, v in rows_acc.items() if k_.startswith("k_attn")}
     attn_tf = sum(v["flops"] for v in attn.values()) / (sum(v["ms"] for v in attn.values()) * 1e-3) / 1e12
@@ -619,69 +770,50 @@ def main():
                      "note": f"decode_latents + uint8 conversion of {P} images (inside the timed region of `value`)"}
         del zl
 
-    # HBM bytes per launch of the dominant kernel from the PMC passes (tools/pmc_traffic.py; collected in separate
-    # rocprofv3 --pmc runs, which cannot be combined with timing).  The record carries the sha256 of the libsdn.so it was
-    # collected on: a record made on another build is NOT reported (traffic = null with the reason).
-    traffic, traffic_src = None, None
-    import glob
+    # HBM bytes per launch and matrix-pipe utilisation per symbol from the PMC passes (tools/pmc_traffic.py, tools/pmc_mfma.py;
+    # collected in separate rocprofv3 --pmc runs, which cannot be combined with timing).  A record carries the sha256 of the
+    # libsdn.so it was collected on: a record made on another build is NOT reported (null with the reason).
     import hashlib
+    import re
     import safe_denoiser_amd as sda
     lib_sha = hashlib.sha256(open(sda.lib_path(), "rb").read()).hexdigest()
-    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_traffic.json")))
-    if not cands:
-        traffic_src = "no PMC record under profiles/"
-    else:
-        rec_all = json.load(open(cands[-1]))
-        meta = rec_all.get("__meta__", {})
-        if meta.get("libsdn_sha256") != lib_sha:
-            traffic_src = (f"profiles/{os.path.basename(cands[-1])} was collected on another build of libsdn.so "
-                           f"(record {str(meta.get('libsdn_sha256'))[:12]}, running {lib_sha[:12]}): stale, not reported")
-        else:
-            tname = "F16" if args.dtype == "f16" else "BF16"
-            if dom == "k_conv_slab":  # one plan label, three instantiations (map width 64 / 32 / 16): launch-weighted mean
-                want = [f"k_conv_slab<Sdn{tname}, {w_}>" for w_ in (64, 32, 16)]
-            else:                     # plan label k_gemm<NREP>[/ln] -> the symbol k_gemm_dma<T, NREP, WGM, NSTAGE, LNF> (LNF = 0 without /ln)
-                import re
-                nrep = dom[dom.index("<") + 1:dom.index(">")]
-                lnf = "[12]" if dom.endswith("/ln") else "0"
-                pat = re.compile(rf"k_gemm_dma<Sdn{tname}, {nrep}, \d+, \d+, {lnf}>")
-                want = sorted({kname for kname in rec_all if pat.search(kname)})
-            hit = [rec for kname, rec in rec_all.items() if kname != "__meta__" and any(w_ in kname for w_ in want)]
+    rec_t, traffic_src = _pmc_records("traffic", lib_sha)
+    rec_m, mfma_src = _pmc_records("mfma_util", lib_sha)
+
+    def pmc_for(pat):
+        out = dict(traffic=None, mfma_busy=None, detail=None)
+        if pat is None:
+            return out
+        rx = re.compile(pat)
+        if rec_t is not None:
+            hit = [r_ for k_, r_ in rec_t.items() if k_ != "__meta__" and rx.search(k_)]
             if hit:
-                traffic = sum(r["hbm_bytes_per_launch"] * r["launches"] for r in hit) / sum(r["launches"] for r in hit)
-                traffic_src = (f"profiles/{os.path.basename(cands[-1])} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected; "
-                               f"git {(meta.get('git_head') or '?')[:10]}, same libsdn.so as this run, batch {meta.get('batch', '?')})")
-            else:
-                traffic_src = f"profiles/{os.path.basename(cands[-1])} has no row for {dom}"
-    # matrix-pipe utilisation of the same kernel from the SQ counter passes (tools/pmc_mfma.py), under the same sha rule
-    mfma_busy, mfma_src, mfma_extra = None, None, None
-    mc = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_mfma_util.json")))
-    if not mc:
-        mfma_src = "no SQ counter record under profiles/"
-    else:
-        rec_m = json.load(open(mc[-1]))
-        meta_m = rec_m.get("__meta__", {})
-        if meta_m.get("libsdn_sha256") != lib_sha:
-            mfma_src = (f"profiles/{os.path.basename(mc[-1])} was collected on another build of libsdn.so (record "
-                        f"{str(meta_m.get('libsdn_sha256'))[:12]}, running {lib_sha[:12]}): stale, not reported")
-        else:
-            import re as _re
-            tname = "F16" if args.dtype == "f16" else "BF16"
-            if dom == "k_conv_slab":
-                pat_m = _re.compile(rf"k_conv_slab<Sdn{tname}, \d+>")
-            else:
-                nrep_m = dom[dom.index("<") + 1:dom.index(">")]
-                pat_m = _re.compile(rf"k_gemm_dma<Sdn{tname}, {nrep_m}, \d+, \d+, {'[12]' if dom.endswith('/ln') else '0'}>")
-            hit_m = [r_ for k_, r_ in rec_m.items() if k_ != "__meta__" and pat_m.search(k_)]
-            if hit_m:
-                wsum = sum(r_["time_share_ms"] for r_ in hit_m)
-                mfma_busy = sum(r_["mfma_busy"] * r_["time_share_ms"] for r_ in hit_m) / wsum
-                mfma_extra = {"clock_ghz": sum((r_["clock_ghz_sq"] or 0.0) * r_["time_share_ms"] for r_ in hit_m) / wsum,
-                              "lds_issue_stall_share_of_wave_cycles": sum((r_["lds_issue_stall_share_of_wave_cycles"] or 0.0) * r_["time_share_ms"] for r_ in hit_m) / wsum}
-                mfma_src = (f"profiles/{os.path.basename(mc[-1])} (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES over a UNet-only "
-                            f"forward at batch {meta_m.get('batch', '?')}; same libsdn.so as this run)")
-            else:
-                mfma_src = f"profiles/{os.path.basename(mc[-1])} has no row for {dom}"
+                out["traffic"] = sum(r_["hbm_bytes_per_launch"] * r_["launches"] for r_ in hit) / sum(r_["launches"] for r_ in hit)
+        if rec_m is not None:
+            hit = [r_ for k_, r_ in rec_m.items() if k_ != "__meta__" and rx.search(k_)]
+            wsum = sum(r_["time_share_ms"] for r_ in hit)
+            if hit and wsum > 0:
+                out["mfma_busy"] = sum(r_["mfma_busy"] * r_["time_share_ms"] for r_ in hit) / wsum
+                out["detail"] = {"clock_ghz": sum((r_["clock_ghz_sq"] or 0.0) * r_["time_share_ms"] for r_ in hit) / wsum,
+                                 "lds_issue_stall_share_of_wave_cycles": sum((r_["lds_issue_stall_share_of_wave_cycles"] or 0.0) * r_["time_share_ms"] for r_ in hit) / wsum,
+                                 "issue_stall_share_of_wave_cycles": sum((r_.get("issue_stall_share_of_wave_cycles") or 0.0) * r_["time_share_ms"] for r_ in hit) / wsum}
+        return out
+
+    def sym_row(name):
+        e = by_sym[name]
+        pm = pmc_for(e["pattern"])
+        tf = e["flops"] / (e["ms"] * 1e-3) / 1e12 if e["flops"] else None
+        return {"share_of_unet_time": e["ms"] / 3 / unet_ms, "launches_per_forward": e["launches"] // 3,
+                "avg_launch_us": e["ms"] / e["launches"] * 1e3, "tflops": tf, "frac": None if tf is None else tf / PEAK_BF16_TFLOPS,
+                "algorithmic_bytes_per_launch": e["bytes"] / e["launches"], "traffic": pm["traffic"], "mfma_busy": pm["mfma_busy"],
+                **({"mfma_busy_detail": pm["detail"]} if pm["detail"] else {}),
+                "labels": {lab: {"launches_per_forward": v["launches"] // 3, "ms_per_forward": v["ms"] / 3,
+                                 "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["flops"] else None}
+                           for lab, v in sorted(e["labels"].items(), key=lambda kv: -kv[1]["ms"])}}
+    top5 = sorted(by_sym, key=lambda k_: -by_sym[k_]["ms"])[:5]
+    by_symbol = {name: sym_row(name) for name in top5}
+    dom_row = by_symbol[dom]
+    traffic, mfma_busy, mfma_extra = dom_row["traffic"], dom_row["mfma_busy"], dom_row.get("mfma_busy_detail")
     n_img = world * P * args.steps
     value = n_img / dt
     by_tf = {k_: v["flops"] / (v["ms"] * 1e-3) / 1e12 for k_, v in sorted(rows_acc.items(), key=lambda kv: -kv[1]["ms"])[:5]}
@@ -715,11 +847,12 @@ def main():
                      "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                      "mfma_busy": mfma_busy, "mfma_busy_source": mfma_src, **({"mfma_busy_detail": mfma_extra} if mfma_extra else {}),
                      "algorithmic_bytes_per_launch": d["bytes"] / d["launches"], "kernel": dom,
-                     **({"kernel_instantiations": "k_conv_slab<T, 64>, <T, 32>, <T, 16> (one per map width): avg_launch_us and traffic "
-                                                  "are launch-weighted means over the three rows of the rocprof summaries"}
-                        if dom == "k_conv_slab" else {}),
+                     "kernel_selection": "plan labels summed by the kernel symbol they launch; the symbol with the largest share of the "
+                                         "HIP-event-timed forward (3 profiled forwards at the benchmark batch)",
+                     "labels": dom_row["labels"],
                      "launches_per_forward": d["launches"] // 3, "avg_launch_us": d["ms"] / d["launches"] * 1e3,
-                     "share_of_unet_time": d["ms"] / 3 / unet_ms},
+                     "share_of_unet_time": d["ms"] / 3 / unet_ms,
+                     "by_symbol": by_symbol},
         "attention_roofline": {"achieved": attn_tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": attn_tf / PEAK_BF16_TFLOPS,
                                # diagnostic only: MFMA work actually ISSUED by the flash kernel, which pads the head dim to
@@ -761,12 +894,17 @@ def main():
         line["value_at_north_star_tolerance"] = line["e2e_bf16x3"]["value"]
         line["e2e_bf16x3"]["relative_to_headline"] = line["e2e_bf16x3"]["value"] / value
         line["parity"] = measure_parity(args, dev)
+        line["job_515"] = measure_job(args, dev, P, beta)
+        line["job_515"]["steady_vs_value"] = (line["job_515"]["steady_images_per_sec"] or 0.0) / value
         # prompts per batch from the sweep in profiles/round3_sd3_batch_sweep.txt (512^2: P = 4 / 8 / 16 / 32 -> 8.6 / 9.8 / 10.6 / 10.8
         # images/sec over 20 steps; 1024^2: P = 2 / 4 / 8 -> 2.19 / 2.44 / 2.51): the knee, not the last per cent
         line["sd3_config4"] = {"512x512": measure_sd3(dev, 64, 16), "1024x1024": measure_sd3(dev, 128, 8)}
-    ppath = os.path.join(ROOT, "profiles", "round3_parity.json")
-    if os.path.exists(ppath):                       # the GPU suite's record vs the CPU oracle (tests/test_gpu_f32.py), committed
-        line.setdefault("parity", {})["suite_record_vs_cpu_oracle"] = json.load(open(ppath))["modes"]
+    import glob as _glob
+    ppaths = sorted(_glob.glob(os.path.join(ROOT, "profiles", "round*_parity.json")),
+                    key=lambda f: int("".join(ch for ch in os.path.basename(f).split("_")[0] if ch.isdigit()) or 0))
+    if ppaths:                                      # the GPU suite's NEWEST record vs the CPU oracle (tests/test_gpu_f32.py), committed
+        line.setdefault("parity", {})["suite_record_vs_cpu_oracle"] = dict(json.load(open(ppaths[-1]))["modes"],
+                                                                           source=f"profiles/{os.path.basename(ppaths[-1])}")
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             sdist.heartbeat("cpu baseline")

@@ -614,7 +614,10 @@ int sdn_masked_attention_f32(const void* q, const void* k, const void* v, void* 
  * first `beta_adjusted` steps, the plain ones afterwards: ...threshold_time.py:525-532).  Declare the CONTENTS of the text operand
  * with a non-zero version number; while consecutive sdn_unet_forward calls carry the same version, batch and weights / text /
  * workspace addresses, those projections are not recomputed (their outputs are kept in workspace slots no other tensor uses).
- * 0 (the default) = undeclared: always computed.  Bit-identical either way.  Ignored in graph mode and by profiled forwards. */
+ * 0 (the default) = undeclared: always computed, and setting 0 drops the cached K / V at once.  Version numbers must be unique per
+ * CONTENTS for the lifetime of the handle (the host side draws them from one process-wide counter): two callers that re-used a
+ * number for different text at the same addresses would be served each other's K / V.  Bit-identical either way.  Ignored in graph
+ * mode and by profiled forwards. */
 void sdn_unet_set_text_version(sdn_unet* u, uint64_t version);
 
 /* Graph mode for launch-bound (small) batches: sdn_unet_forward / sdn_mmdit_forward capture their ~850 launches into a

@@ -1055,6 +1055,12 @@ extern "C" int sdn_gemm_x3(const sdn_gemm_desc* d, const void* a, const void* a2
   return gemm_f32_storage(1, d, a, a2, w, bias, rowbias, rowgate, residual, out, stream);
 }
 
+// SDN_GN_F32_OLD=1 selects the per-group kernels (A/B switch): looked up once, not on each of the ~60 launches of a forward
+static bool gn_f32_old_form() {
+  static const bool v = getenv("SDN_GN_F32_OLD") != nullptr;
+  return v;
+}
+
 static int groupnorm_f32_impl(int triple, const void* x, const void* x2, int32_t batch, int32_t hw, int32_t c1, int32_t c2,
                               int32_t groups, float eps, int32_t silu, const float* gamma, const float* beta, void* out,
                               float* stats_ws, void* stream) {
@@ -1067,7 +1073,7 @@ static int groupnorm_f32_impl(int triple, const void* x, const void* x2, int32_t
   // row-major two-pass form (coalesced rows; chunk partials in the caller's scratch: B * 129 * groups * 2 floats cover 64 chunks)
   if (stats_ws && (c1 & 3) == 0 && (c2 & 3) == 0 && c1 + c2 <= GN_MAXC && groups <= 64 && al16(x) && (!x2 || al16(x2)) && al16(gamma) &&
       al16(beta) && (reinterpret_cast<uintptr_t>(stats_ws) & 7) == 0 && (reinterpret_cast<uintptr_t>(out) & (triple ? 7 : 15)) == 0 &&
-      !getenv("SDN_GN_F32_OLD")) {
+      !gn_f32_old_form()) {
     int rpc = 16;                                                            // rows per chunk: >= 16, at most 64 chunks per sample
     while ((hw + rpc - 1) / rpc > 64) rpc *= 2;
     const int nchunk = (hw + rpc - 1) / rpc;

@@ -365,7 +365,7 @@ struct Builder {
                 (residual.space != SP_NONE ? 4.0 * (double)o.gd.M * cout : 0.0);
       if (Ho == in.side && sdn_conv_slab_shape_ok(o.gd.M, n_pad, 3 * in.C, in.side, stride, upsample, asym_pad, SDN_OUT_BF16, n_valid) &&
           sdn_gemm_pick_tile(o.gd.M, n_pad, o.gd.K, SDN_ACT_NONE) == 10)
-        snprintf(o.label, sizeof(o.label), "k_conv_slab/x3");
+        snprintf(o.label, sizeof(o.label), "k_conv_slab<%d>/x3", in.side);
       else
         snprintf(o.label, sizeof(o.label), "k_gemm<%d>x3", sdn_gemm_pick_tile(o.gd.M, n_pad, o.gd.K, SDN_ACT_NONE));
       push_gemm(o);
@@ -385,7 +385,7 @@ struct Builder {
               (residual.space != SP_NONE ? 2.0 * (double)o.gd.M * cout : 0.0);      // + the residual map the epilogue adds
     if (Ho == in.side && sdn_conv_slab_shape_ok(o.gd.M, n_pad, in.C, in.side, stride, upsample, asym_pad, out_kind, n_valid) &&
         sdn_gemm_pick_tile(o.gd.M, n_pad, o.gd.K, SDN_ACT_NONE) == 10)
-      snprintf(o.label, sizeof(o.label), "k_conv_slab");
+      snprintf(o.label, sizeof(o.label), "k_conv_slab<%d>", in.side);
     else
       snprintf(o.label, sizeof(o.label), "k_gemm<%d>", sdn_gemm_pick_tile(o.gd.M, n_pad, o.gd.K, SDN_ACT_NONE));
     push_gemm(o);
@@ -442,7 +442,9 @@ struct Builder {
     if (prepass) o.ln_stats = R(st);
     o.flops = 2.0 * (double)rows * N * K;
     o.bytes = 2.0 * ((double)rows * K + (double)N * K + (double)rows * (act_ == SDN_ACT_GEGLU ? N / 2 : N));
-    snprintf(o.label, sizeof(o.label), "k_gemm<%d>/ln", sdn_gemm_pick_tile((int)rows, N, K, act_));
+    { int t = sdn_gemm_pick_tile((int)rows, N, K, act_);
+      if (t == 8 && N % 320 == 0) t = 10;                        // (sdn_gemm_impl: the folded forms have no 256-wide instantiation)
+      snprintf(o.label, sizeof(o.label), "k_gemm<%d>/ln%d", t, prepass ? 2 : 1); }   // /lnL: L = the symbol's LNF
     plan->ops.push_back(o);
     plan->flops += o.flops;
     if (prepass) drop(st);
@@ -1855,7 +1857,11 @@ static int run_plan(sdn_unet* u, const void* weights, const float* latents, floa
   return rc_l;
 }
 
-void sdn_unet_set_text_version(sdn_unet* u, uint64_t version) { if (u) u->text_version = version; }
+void sdn_unet_set_text_version(sdn_unet* u, uint64_t version) {
+  if (!u) return;
+  u->text_version = version;
+  if (version == 0) u->kv_version = 0;                         // undeclared: the cached K / V are dropped NOW, not at the next plain forward
+}
 
 void sdn_unet_profile_next(sdn_unet* u) { if (u) u->profile_next = true; }
 

@@ -49,7 +49,19 @@ def check_device_count(world: int, local: int, share: bool = False):
     # LOCAL_WORLD_SIZE is torchrun's; a launcher that does not export it (srun / mpirun with RANK + LOCAL_RANK set by hand) may
     # span several nodes, so WORLD_SIZE says nothing about THIS node: then only this rank's own device index can be checked
     lws = os.environ.get("LOCAL_WORLD_SIZE")
-    local_world = int(lws) if lws is not None else None
+    if lws is None:
+        # a launcher that exports no LOCAL_WORLD_SIZE: take the scheduler's per-node task count when it states one (srun, mpirun).
+        # When NOTHING indicates more than one node (RANK / WORLD_SIZE set by hand on a single machine), WORLD_SIZE is this
+        # node's rank count -- so that all ranks fail fast together instead of the low ranks waiting in the rendezvous for the
+        # ones that raised.  With several nodes and no per-node count, only this rank's own device index can be checked.
+        lws = os.environ.get("SLURM_NTASKS_PER_NODE") or os.environ.get("OMPI_COMM_WORLD_LOCAL_SIZE")
+
+        def _nodes(k):
+            v = os.environ.get(k, "")
+            return int(v) if v.isdigit() else 1
+        if lws is None and max(_nodes(k) for k in ("NNODES", "SLURM_NNODES", "SLURM_JOB_NUM_NODES")) <= 1:
+            lws = str(world)
+    local_world = int(lws) if lws is not None and str(lws).isdigit() else None
     if (local_world is not None and n < local_world) or local >= n:
         ranks = f"{local_world} ranks on this node" if local_world is not None else "this node's ranks"
         raise RuntimeError(f"{ranks} (LOCAL_RANK {local}) but only {n} GPU(s) visible: one process per "

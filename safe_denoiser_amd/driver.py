@@ -285,13 +285,73 @@ class RunArtifacts:
         self.logger.close()
 
 
+class _OrderedWriter:
+    """Everything `run_job` does on the host AFTER a batch has left the GPU -- PNG encoding (three `image.save` per image:
+    run_nudity.py:469,490,504), the classifier call (:471) and every log line -- runs on ONE worker thread fed through a FIFO, so
+    that the GPU already denoises batch k + 1 while batch k is written.  One thread + one queue = the events happen in exactly the
+    order the serial loop would produce them: logs.txt, detect_dict.json and the image tree are identical to the serial output
+    (tests/test_driver.py).  `depth` bounds the number of batches in flight (their uint8 images live in pinned host memory)."""
+
+    def __init__(self, depth: int = 2):
+        import queue
+        import threading
+        self.q = queue.Queue()
+        self.slots = threading.Semaphore(depth)
+        self.err = None
+        self.busy_s = 0.0
+        self.t = threading.Thread(target=self._run, name="sdn-writer", daemon=True)
+        self.t.start()
+
+    def _run(self):
+        import time
+        while True:
+            fn = self.q.get()
+            if fn is None:
+                return
+            if self.err is None:
+                t0 = time.perf_counter()
+                try:
+                    fn()
+                except BaseException as e:           # noqa: BLE001 -- handed to the submitting thread
+                    self.err = e
+                self.busy_s += time.perf_counter() - t0
+
+    def submit(self, fn):
+        if self.err is not None:
+            self.close()
+        self.q.put(fn)
+
+    def close(self):
+        self.q.put(None)
+        self.t.join()
+        if self.err is not None:
+            err, self.err = self.err, None
+            raise err
+
+
+class _QueuedLogger:
+    """The `.log(text)` the pipeline's SAFREE block calls (safree_dict["logger"]) -- queued behind the previous batch's lines."""
+
+    def __init__(self, writer, logger):
+        self.w, self.l = writer, logger
+
+    def log(self, text):
+        self.w.submit(lambda: self.l.log(text))
+
+
 def run_job(args, pipe, repellency_processor=None, task_config: Optional[Mapping[str, Any]] = None, eval_func: Optional[Callable] = None,
-            prompts_per_batch: int = 64, rank: int = 0, world: int = 1, device="cuda") -> RunArtifacts:
+            prompts_per_batch: int = 64, rank: int = 0, world: int = 1, device="cuda", overlap_io: Optional[bool] = None,
+            max_overfill: float = 0.25, timings: Optional[dict] = None) -> RunArtifacts:
     """The body of the reference's main() after model loading (run_nudity.py:341-529) on the batched engine: read the prompt
     table (`args.data`, `--valid_case_numbers`), shard it over the ranks, and for every batch of prompts (each with its own
     guidance scale and seed) call `pipe(prompt, ..., negative_prompt, negative_prompt_space, generator, repellency_processor, safree_dict,
     **SLD config)` once, then save / classify / log every image exactly as the reference does per prompt.
-    `pipe`: a SafeDenoiserPipeline with text_encoder, tokenizer and vae attached (images come back as PIL)."""
+    `pipe`: a SafeDenoiserPipeline with text_encoder, tokenizer and vae attached.
+    `overlap_io` (default: on when the pipeline can hand back uint8 device tensors): the images of batch k are copied to pinned
+    host memory asynchronously and written / classified / logged by a worker thread while the GPU runs batch k + 1 (the reference
+    is serial: per image two or three PNG encodes + the classifier sit between two pipeline calls, :462-504); the output files
+    are identical to the serial ones.  `max_overfill`: cases.batches' tail policy (0 = never exceed `prompts_per_batch`).
+    `timings`: a dict that receives {batches: [{prompts, gpu_s}], host_io_s, total_s} (bench.py's job leg)."""
     import time
 
     from . import cases as _cases
@@ -301,6 +361,7 @@ def run_job(args, pipe, repellency_processor=None, task_config: Optional[Mapping
     if variant is not None and getattr(pipe, "variant", variant) != variant:
         raise ValueError(f"erase_id {args.erase_id!r} maps to gating variant {variant!r} but the pipeline was built with "
                          f"variant={pipe.variant!r}")
+    t_job = time.perf_counter()
     art = RunArtifacts(args, task_config, rank=rank, world=world)
     log = art.logger
     # only the *_Rep classes run the repellency block (ERASE_IDS above); everywhere else the processor is built and ignored
@@ -315,37 +376,97 @@ def run_job(args, pipe, repellency_processor=None, task_config: Optional[Mapping
     if task_config is not None:
         log.log(f"Repellency method : {task_config['repellency']['method']}")
     table = _cases.read_cases(args.data, args.valid_case_numbers, default_guidance=args.guidance_scale, category=args.category)
-    for batch in _cases.batches(table, prompts_per_batch, rank, world):
-        for c in batch:
-            art.log_case(c)
-        t0 = time.time()
-        sf = safree_dict(args, logger=log)
-        imgs = pipe([c["prompt"] for c in batch], num_inference_steps=args.num_inference_steps, guidance_scale=[c["guidance"] for c in batch],
+    if overlap_io is None:
+        overlap_io = getattr(getattr(pipe, "vae", None), "decode_latents_uint8", None) is not None
+    writer = _OrderedWriter() if overlap_io else None
+    qlog = _QueuedLogger(writer, log) if overlap_io else log
+    stats = dict(batches=[], host_io_s=0.0)
+
+    def call(batch, output_type, logger):
+        return pipe([c["prompt"] for c in batch], num_inference_steps=args.num_inference_steps, guidance_scale=[c["guidance"] for c in batch],
                     negative_prompt=neg, negative_prompt_space=space, height=args.image_length, width=args.image_length,
                     generator=_cases.generators(batch, device=device),
                     repellency_processor=repellency_processor if use_rep else None,
-                    safree_dict=sf, return_latents=False, output_type="pil", **(call_config or {}))
-        dt = time.time() - t0
-        for c, im in zip(batch, imgs):
+                    safree_dict=safree_dict(args, logger=logger), return_latents=False, output_type=output_type, **(call_config or {}))
+
+    def write_batch(batch, images, dt):
+        for c, im in zip(batch, images):
             art.log_time(c, dt / len(batch))                       # the batch's wall clock, per image
             art.record(c, im, eval_func=eval_func)
+
+    try:
+        for batch in _cases.batches(table, prompts_per_batch, rank, world, max_overfill=max_overfill):
+            if not overlap_io:
+                for c in batch:
+                    art.log_case(c)
+                t0 = time.time()
+                imgs = call(batch, "pil", log)
+                dt = time.time() - t0
+                t1 = time.perf_counter()
+                write_batch(batch, imgs, dt)
+                stats["host_io_s"] += time.perf_counter() - t1
+                stats["batches"].append(dict(prompts=len(batch), gpu_s=dt))
+                continue
+            import torch
+            from PIL import Image
+            for c in batch:
+                writer.submit(lambda c=c: art.log_case(c))
+            writer.slots.acquire()                                  # at most `depth` batches of images in flight
+            t0 = time.time()
+            u8 = call(batch, "uint8", qlog)                         # [P, H, W, 3] uint8 on the device: what numpy_to_pil would build
+            if u8.is_cuda:
+                host = torch.empty(u8.shape, dtype=torch.uint8, pin_memory=True)
+                host.copy_(u8, non_blocking=True)
+                torch.cuda.current_stream().synchronize()           # the batch is done (decode + copy): its wall clock, as the
+            else:                                                   # reference takes it around the pipeline call (:449,462)
+                host = u8
+            dt = time.time() - t0
+
+            def finish(batch=batch, host=host, dt=dt):
+                try:
+                    write_batch(batch, [Image.fromarray(a) for a in host.numpy()], dt)
+                finally:
+                    writer.slots.release()
+            writer.submit(finish)
+            stats["batches"].append(dict(prompts=len(batch), gpu_s=dt))
+    finally:
+        if writer is not None:
+            writer.close()                                          # drains the queue; re-raises what the worker caught
+            stats["host_io_s"] = writer.busy_s
     art.finish(dataset_size=len(table))
+    stats["total_s"] = time.perf_counter() - t_job
+    if timings is not None:
+        timings.update(stats)
     return art
 
 
 def merge_rank_outputs(save_dir: str, world: int) -> dict:
     """End of a W-rank job: the union of `{save_dir}/rank{r:02d}` is the reference's single tree (case numbers are global), so
-    the merged `detect_dict.json` is rebuilt from the per-rank ones -- `unsafe` lists concatenated in rank order, the per-category
-    ratios recombined with their `toxic_size` weights (run_nudity.py:507-524 computes them from the full lists; a weighted
-    mean of per-rank means is the same number) -- and written to `{save_dir}/detect_dict.json`.  Host files only; any rank (or a
-    later process) may call it once every rank has finished."""
+    the merged `detect_dict.json` is rebuilt from the per-rank ones.  `unsafe` comes back in TABLE order -- cases are sharded
+    `r::world`, so entry i of rank r is global position r + i * world (run_nudity.py appends per case in table order) -- and the
+    per-category ratios are recombined with their `toxic_size` weights (:507-524 computes them from the full lists; a weighted
+    mean of per-rank means is the same number).  Written to `{save_dir}/detect_dict.json`.  A rank whose shard was empty is
+    skipped; a rank directory without its detect_dict.json is an error that names it.  Host files only; any rank (or a later
+    process) may call it once every rank has finished."""
     parts = []
     for r in range(world):
-        with open(os.path.join(save_dir, f"rank{r:02d}", "detect_dict.json")) as f:
+        path = os.path.join(save_dir, f"rank{r:02d}", "detect_dict.json")
+        if not os.path.isfile(path):
+            raise FileNotFoundError(f"{path}: rank {r} of {world} has not finished (or wrote elsewhere); cannot merge")
+        with open(path) as f:
             parts.append(json.load(f))
     merged: dict = {}
-    unsafe = [u for d in parts for u in d.get("unsafe", [])]
-    if unsafe:
+    lists = [d.get("unsafe", []) for d in parts]
+    total = sum(len(l_) for l_ in lists)
+    if total:
+        # r::world sharding gives rank r ceil((total - r) / world) entries: then the interleave is exact; anything else (ranks that
+        # ran different tables / a classifier that skipped cases) cannot be put back in table order and stays in rank order
+        if all(len(l_) == (total - r + world - 1) // world for r, l_ in enumerate(lists)):
+            unsafe = [None] * total
+            for r, l_ in enumerate(lists):
+                unsafe[r::world] = l_
+        else:
+            unsafe = [u for l_ in lists for u in l_]
         merged["unsafe"] = unsafe
     sizes: dict = {}
     for d in parts:

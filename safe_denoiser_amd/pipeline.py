@@ -24,6 +24,7 @@ What differs from the reference by design (results per sample are the same):
 """
 from __future__ import annotations
 
+import itertools
 from typing import Callable, Optional, Sequence
 
 import torch
@@ -43,6 +44,12 @@ VARIANTS = {
 }
 
 
+# text-contents versions handed to sdn_unet_set_text_version: ONE counter for the process, so that two pipelines over one UNet (or a
+# pipeline built after another was freed, whose text buffers the caching allocator may hand back at the same addresses) can never
+# declare the same number for different text
+_TEXT_VERSIONS = itertools.count(1)
+
+
 SLD_SAFETY_CONCEPT = ("hate, harassment, violence, suffering, humiliation, harm, suicide, sexual, nudity, bodily fluids, blood, "
                       "obscene gestures, illegal activity, drug use, theft, vandalism, weapons, child abuse, brutality, cruelty")
 
@@ -51,10 +58,23 @@ class SafeDenoiserPipeline:
     GRAPH_MAX_BATCH = 16      # UNet rows (branches x prompts) up to which a forward is launch-bound and replayed as a hipGraph
 
     def __init__(self, unet, scheduler, variant: str = "threshold_time", vae=None, use_graphs: Optional[bool] = None,
-                 text_encoder=None, tokenizer=None, split_k: bool = False, elide_dead_branch: bool = False):
+                 text_encoder=None, tokenizer=None, split_k: bool = False, elide_dead_branch: bool = False,
+                 unet_hi=None, precision_schedule=None):
         if variant not in VARIANTS:
             raise KeyError(f"unknown variant {variant}; have {sorted(VARIANTS)}")
         self.unet, self.scheduler, self.variant, self.vae = unet, scheduler, variant, vae
+        # Precision schedule (round 5): `unet_hi` is a second plan over the SAME weights in a precision mode (bf16x3 / fp32) and
+        # `precision_schedule` says which steps of the loop run on it; every other step runs on `unet` (the 16-bit plan).  The
+        # reference runs every step in fp32 (run_nudity.py:277); the schedule spends the precise plan where the final latents
+        # are sensitive to the step's rounding (tools/precision_schedule.py measures that) -- see `hi_steps()` for the forms.
+        self.unet_hi, self.precision_schedule = unet_hi, precision_schedule
+        if (unet_hi is None) != (precision_schedule is None):
+            raise _lib.SdnError("unet_hi and precision_schedule go together")
+        if unet_hi is not None:
+            a, b = unet.config, unet_hi.config
+            if (a.sample_size, a.in_channels, a.cross_attention_dim) != (b.sample_size, b.in_channels, b.cross_attention_dim) \
+                    or getattr(unet, "latent_repeat", 1) != getattr(unet_hi, "latent_repeat", 1) or unet.text_len != unet_hi.text_len:
+                raise _lib.SdnError("unet_hi must be the same architecture / latent_repeat / text_len as unet")
         self.use_graphs = use_graphs          # None = automatic: on for small batches (the reference's one-prompt calls)
         # optional front end: safe_denoiser_amd.clip.CLIPTextModel + the caller's CLIPTokenizer
         self.text_encoder, self.tokenizer = text_encoder, tokenizer
@@ -70,9 +90,9 @@ class SafeDenoiserPipeline:
         self.last_stats = {}
         self.last_safree = None
         self._bufs = {}
-        self._text_ver = 0         # contents counter of the loop's text buffers (unet.set_text_version: K / V of an unchanged text are reused)
         self._rngs = {}
         self.batched_rng = True    # False: per-prompt torch.randn calls (the draws are the same bits either way)
+        self.device_flags = True   # False: read the is_negation flags back at every window step (rounds 1-4; same bits either way)
         self.batched_safree = True  # False: the SAFREE projection prompt by prompt (safree.prepare), as the reference runs it
         self.record_den = False    # diagnostics: keep each window step's denominators (device tensors, no sync) in last_stats
         # SLDPipeline._safety_text_concept: the default of the third-party base class the reference's SLD pipelines inherit
@@ -265,7 +285,6 @@ class SafeDenoiserPipeline:
         E_safe = self._branches(rescaled_text_embeddings.to(dev), E, nb) if (sf["safree"] and rescaled_text_embeddings
                                                                              is not None) else None
         tb_plain = self.unet.prepare_text(E_plain)
-        tb_safe = self.unet.prepare_text(E_safe) if E_safe is not None else None
 
         sch = self.scheduler
         sch.set_timesteps(num_inference_steps)
@@ -305,36 +324,43 @@ class SafeDenoiserPipeline:
 
         L = _lib.lib()
         st = _lib.stream_ptr()
+        use_hi = self.hi_steps(timesteps, kind, lo, hi) if self.unet_hi is not None else [False] * len(timesteps)
+        nets = ([self.unet] if not all(use_hi) else []) + ([self.unet_hi] if any(use_hi) else [])
         # a UNet built with latent_repeat = nb repeats the latents itself (and shares the branch-independent prefix)
         rep = getattr(self.unet, "latent_repeat", 1)
         if rep not in (1, nb):
             raise _lib.SdnError(f"unet.latent_repeat = {rep} but this call runs {nb} guidance branches")
         shared_latents = rep == nb
-        if hasattr(self.unet, "set_graph_mode"):
-            small = nb * P <= self.GRAPH_MAX_BATCH if self.use_graphs is None else bool(self.use_graphs)
-            self.unet.set_graph_mode(small)
-            if hasattr(self.unet, "set_split_k"):
-                self.unet.set_split_k(bool(self.split_k) and small)
+        for u_ in nets:
+            if hasattr(u_, "set_graph_mode"):
+                small = nb * P <= self.GRAPH_MAX_BATCH if self.use_graphs is None else bool(self.use_graphs)
+                u_.set_graph_mode(small)
+                if hasattr(u_, "set_split_k"):
+                    u_.set_split_k(bool(self.split_k) and small)
         # loop buffers are kept across calls (same shapes -> same addresses -> the UNet's graph cache keeps hitting);
         # the latents handed back to the caller are therefore a copy
-        key = (P, nb, C_, s, dev, bool(shared_latents), tuple(tb_plain.shape), tb_plain.dtype)
+        key = (P, nb, C_, s, dev, bool(shared_latents), tuple(tb_plain.shape), tuple(u_.dtype for u_ in nets))
         if self._bufs.get("key") != key:
             f32 = dict(dtype=torch.float32, device=dev)
             self._bufs = dict(key=key, x_in=None if shared_latents else torch.empty((nb * P, C_, s, s), **f32),
                               model_out=torch.empty((nb * P, C_, s, s), **f32), eps=torch.empty((P, C_, s, s), **f32),
                               x0=torch.empty((P, C_, s, s), **f32), noise=torch.empty((P, C_, s, s), **f32),
                               lat=torch.empty((P, C_, s, s), **f32), nxt=torch.empty((P, C_, s, s), **f32),
-                              tb_plain=torch.empty_like(tb_plain), tb_safe=torch.empty_like(tb_plain),
-                              tb_mix=torch.empty_like(tb_plain))
+                              fired=torch.zeros(P, dtype=torch.int32, device=dev),
+                              text=[{k_: torch.empty(tuple(tb_plain.shape), dtype=u_.dtype, device=dev)
+                                     for k_ in ("plain", "safe", "mix")} for u_ in nets])
         bf = self._bufs
-        tb_plain = bf["tb_plain"].copy_(tb_plain)
-        if tb_safe is not None:
-            tb_safe = bf["tb_safe"].copy_(tb_safe)
-        # every (re)write of a text buffer gets a fresh version: the UNet recomputes the cross-attention K / V of the text only when
-        # the version it is handed changes (plain / projected / per-prompt mix: a handful of changes over the 50 steps)
-        ver_plain, ver_safe, ver_mix, mix_key = self._text_ver + 1, self._text_ver + 2, 0, None
-        self._text_ver += 2
-        has_ver = hasattr(self.unet, "set_text_version")
+        # one set of text buffers per plan in use (each in its plan's storage type).  Every (re)write of a text buffer gets a fresh
+        # version: the UNet recomputes the cross-attention K / V of the text only when the version it is handed changes (plain /
+        # projected / per-prompt mix: a handful of changes over the 50 steps)
+        texts = {}
+        for u_, tb_ in zip(nets, bf["text"]):
+            tb_["plain"].copy_(tb_plain if u_ is self.unet else u_.prepare_text(E_plain))
+            if E_safe is not None:
+                tb_["safe"].copy_(u_.prepare_text(E_safe))
+            texts[id(u_)] = dict(buf=tb_, ver_plain=next(_TEXT_VERSIONS), ver_safe=next(_TEXT_VERSIONS), ver_mix=0, mix_key=None,
+                                 has_ver=hasattr(u_, "set_text_version"))
+        has_safe = E_safe is not None
         x_in, model_out, eps, x0, noise, nxt = bf["x_in"], bf["model_out"], bf["eps"], bf["x0"], bf["noise"], bf["nxt"]
         bf["lat"].copy_(lat)
         lat = bf["lat"]
@@ -344,95 +370,156 @@ class SafeDenoiserPipeline:
         den_log = []
         self._last_den = None
         momentum = torch.zeros_like(eps) if sld else None
+        # Sync-free window steps (round 5): the number of randn draws of a prompt depends on its is_negation flag, which rounds 1-4
+        # read back once per window step.  With the generators' (seed, offset) pairs resident on the device (rng.py) the flag
+        # vector itself selects the rows that draw and advance, so nothing has to come back: the torch.Generator objects are
+        # brought up to date ONCE after the loop (BatchedNormal.sync_host), the draw count is summed on the device.
+        dev_flags = bool(self.device_flags and rng is not None and rng.ok and use_flag
+                         and hasattr(repellency_processor, "conditioning_device"))
+        fired_acc = bf["fired"].zero_() if dev_flags else None
 
-        for i, t in enumerate(timesteps):
-            if not shared_latents:
-                x_in.view(nb, P, C_, s, s).copy_(lat)                               # cat([latents] * nb)
-            # which prompts see the SAFREE-projected text at this step (...threshold_time.py:525-532); with the
-            # self-validation filter the step count is PER PROMPT, so a batch can be mixed
-            if tb_safe is None:
-                safe_p = [False] * P
-            elif sf["svf"]:
-                safe_p = [ba is not None and i <= ba for ba in beta_list]
-            else:
-                safe_p = [sf["re_attn_t"][0] <= i <= sf["re_attn_t"][1]] * P
-            if all(safe_p):
-                tb, ver = tb_safe, ver_safe
-            elif not any(safe_p):
-                tb, ver = tb_plain, ver_plain
-            else:
-                if mix_key != tuple(safe_p):                                        # the set of projected prompts changed: rebuild the mix
-                    pick = torch.tensor(safe_p * nb, device=dev)[:, None, None]
-                    bf["tb_mix"].copy_(torch.where(pick, tb_safe, tb_plain))
-                    mix_key = tuple(safe_p)
-                    self._text_ver += 1
-                    ver_mix = self._text_ver
-                tb, ver = bf["tb_mix"], ver_mix
-            if has_ver:
-                self.unet.set_text_version(ver)
-            self.unet.forward_into(lat if shared_latents else x_in, float(t), tb, model_out)
-            if sld and g_rows is not None:
-                _lib.check(L.sdn_sld_guidance_rows(model_out.data_ptr(), P, D, g_rows.data_ptr(), sld["scale"], sld["thr"],
-                                                   sld["ms"], sld["mb"], int(i >= sld["warmup"]), momentum.data_ptr(),
-                                                   eps.data_ptr(), st), "sdn_sld_guidance_rows")
-            elif sld:
-                _lib.check(L.sdn_sld_guidance(model_out.data_ptr(), P, D, float(guidance_scale), sld["scale"], sld["thr"],
-                                              sld["ms"], sld["mb"], int(i >= sld["warmup"]), momentum.data_ptr(),
-                                              eps.data_ptr(), st), "sdn_sld_guidance")
-            elif g_rows is not None:
-                _lib.check(L.sdn_cfg_combine_rows(model_out.data_ptr(), P, nb, D, g_rows.data_ptr(), eps.data_ptr(), st),
-                           "sdn_cfg_combine_rows")
-            else:
-                _lib.check(L.sdn_cfg_combine(model_out.data_ptr(), P, nb, D, float(guidance_scale), eps.data_ptr(), st),
-                           "sdn_cfg_combine")
-
-            in_window = (kind is None) or (kind == "t" and lo <= t <= hi) or (kind == "i" and lo <= i <= hi)
-            if in_window and repellency_processor is not None:
-                n_window += 1
-                sa, s1 = sch.sqrt_pair(t)
-                clip = sch.config.clip_sample_range if sch.config.clip_sample else 0.0
-                _lib.check(L.sdn_pred_x0(lat.data_ptr(), eps.data_ptr(), lat.numel(), sa, s1, clip, x0.data_ptr(), st),
-                           "sdn_pred_x0")
-                if is_ddpm and t > 0:                       # scheduler.step() draws (and the caller discards) a randn
-                    draw_discard()
-                src, isneg = self._condition(repellency_processor, x0, use_beta)
-                if self.record_den and self._last_den is not None:
-                    den_log.append(self._last_den.clone())
-                if use_flag:
-                    flags = isneg.cpu().tolist()            # the one readback: decides how many randn are drawn
+        try:
+            for i, t in enumerate(timesteps):
+                u = self.unet_hi if use_hi[i] else self.unet
+                tx = texts[id(u)]
+                tbuf = tx["buf"]
+                if not shared_latents:
+                    x_in.view(nb, P, C_, s, s).copy_(lat)                               # cat([latents] * nb)
+                # which prompts see the SAFREE-projected text at this step (...threshold_time.py:525-532); with the
+                # self-validation filter the step count is PER PROMPT, so a batch can be mixed
+                if not has_safe:
+                    safe_p = [False] * P
+                elif sf["svf"]:
+                    safe_p = [ba is not None and i <= ba for ba in beta_list]
                 else:
-                    flags = [1] * P
-                    isneg = torch.ones(P, dtype=torch.int32, device=dev)
-                if any(flags):
-                    fired = [p for p in range(P) if flags[p]]
-                    draw_into(noise, fired if len(fired) < P else None, flags_dev=isneg)
-                    n_renoise += len(fired)
-                    _lib.check(L.sdn_renoise_select(lat.data_ptr(), src.data_ptr(), noise.data_ptr(), isneg.data_ptr(),
-                                                    P, D, sa, s1, st), "sdn_renoise_select")
+                    safe_p = [sf["re_attn_t"][0] <= i <= sf["re_attn_t"][1]] * P
+                if all(safe_p):
+                    tb, ver = tbuf["safe"], tx["ver_safe"]
+                elif not any(safe_p):
+                    tb, ver = tbuf["plain"], tx["ver_plain"]
+                else:
+                    if tx["mix_key"] != tuple(safe_p):                                  # the set of projected prompts changed: rebuild the mix
+                        pick = torch.tensor(safe_p * nb, device=dev)[:, None, None]
+                        tbuf["mix"].copy_(torch.where(pick, tbuf["safe"], tbuf["plain"]))
+                        tx["mix_key"] = tuple(safe_p)
+                        tx["ver_mix"] = next(_TEXT_VERSIONS)
+                    tb, ver = tbuf["mix"], tx["ver_mix"]
+                if tx["has_ver"]:
+                    u.set_text_version(ver)
+                u.forward_into(lat if shared_latents else x_in, float(t), tb, model_out)
+                if sld and g_rows is not None:
+                    _lib.check(L.sdn_sld_guidance_rows(model_out.data_ptr(), P, D, g_rows.data_ptr(), sld["scale"], sld["thr"],
+                                                       sld["ms"], sld["mb"], int(i >= sld["warmup"]), momentum.data_ptr(),
+                                                       eps.data_ptr(), st), "sdn_sld_guidance_rows")
+                elif sld:
+                    _lib.check(L.sdn_sld_guidance(model_out.data_ptr(), P, D, float(guidance_scale), sld["scale"], sld["thr"],
+                                                  sld["ms"], sld["mb"], int(i >= sld["warmup"]), momentum.data_ptr(),
+                                                  eps.data_ptr(), st), "sdn_sld_guidance")
+                elif g_rows is not None:
+                    _lib.check(L.sdn_cfg_combine_rows(model_out.data_ptr(), P, nb, D, g_rows.data_ptr(), eps.data_ptr(), st),
+                               "sdn_cfg_combine_rows")
+                else:
+                    _lib.check(L.sdn_cfg_combine(model_out.data_ptr(), P, nb, D, float(guidance_scale), eps.data_ptr(), st),
+                               "sdn_cfg_combine")
 
-            co = sch.step_coefficients(t)
-            z = None
-            if is_ddpm and t > 0:
-                draw_into(noise)
-                z = noise
-            clip = sch.config.clip_sample_range if sch.config.clip_sample else 0.0
-            _lib.check(L.sdn_sched_step(lat.data_ptr(), eps.data_ptr(), None if z is None else z.data_ptr(),
-                                        lat.numel(), co["sqrt_ac"], co["sqrt_1mac"], co["c_x0"], co["c_x"], co["c_eps"],
-                                        co["sigma"] if z is not None else 0.0, clip, nxt.data_ptr(), st),
-                       "sdn_sched_step")
-            lat, nxt = nxt, lat
-            if callback is not None and i % callback_steps == 0:
-                callback(i, t, lat)
+                in_window = (kind is None) or (kind == "t" and lo <= t <= hi) or (kind == "i" and lo <= i <= hi)
+                if in_window and repellency_processor is not None:
+                    n_window += 1
+                    sa, s1 = sch.sqrt_pair(t)
+                    clip = sch.config.clip_sample_range if sch.config.clip_sample else 0.0
+                    _lib.check(L.sdn_pred_x0(lat.data_ptr(), eps.data_ptr(), lat.numel(), sa, s1, clip, x0.data_ptr(), st),
+                               "sdn_pred_x0")
+                    if is_ddpm and t > 0:                       # scheduler.step() draws (and the caller discards) a randn
+                        draw_discard()
+                    src, isneg = self._condition(repellency_processor, x0, use_beta)
+                    if self.record_den and self._last_den is not None:
+                        den_log.append(self._last_den.clone())
+                    if dev_flags:                               # no readback: the flag vector selects the drawing rows on the device
+                        rng.draw_flagged(gens, noise, isneg)
+                        fired_acc.add_(isneg.ne(0).to(torch.int32))
+                        _lib.check(L.sdn_renoise_select(lat.data_ptr(), src.data_ptr(), noise.data_ptr(), isneg.data_ptr(),
+                                                        P, D, sa, s1, st), "sdn_renoise_select")
+                    else:
+                        if use_flag:
+                            flags = isneg.cpu().tolist()        # a readback: decides how many randn are drawn (tapes, host generators)
+                        else:
+                            flags = [1] * P
+                            isneg = torch.ones(P, dtype=torch.int32, device=dev)
+                        if any(flags):
+                            fired = [p for p in range(P) if flags[p]]
+                            draw_into(noise, fired if len(fired) < P else None, flags_dev=isneg)
+                            n_renoise += len(fired)
+                            _lib.check(L.sdn_renoise_select(lat.data_ptr(), src.data_ptr(), noise.data_ptr(), isneg.data_ptr(),
+                                                            P, D, sa, s1, st), "sdn_renoise_select")
 
-        if has_ver:
-            self.unet.set_text_version(0)                              # undeclared again: a direct caller of the UNet gets plain forwards
+                co = sch.step_coefficients(t)
+                z = None
+                if is_ddpm and t > 0:
+                    draw_into(noise)
+                    z = noise
+                clip = sch.config.clip_sample_range if sch.config.clip_sample else 0.0
+                _lib.check(L.sdn_sched_step(lat.data_ptr(), eps.data_ptr(), None if z is None else z.data_ptr(),
+                                            lat.numel(), co["sqrt_ac"], co["sqrt_1mac"], co["c_x0"], co["c_x"], co["c_eps"],
+                                            co["sigma"] if z is not None else 0.0, clip, nxt.data_ptr(), st),
+                           "sdn_sched_step")
+                lat, nxt = nxt, lat
+                if callback is not None and i % callback_steps == 0:
+                    if dev_flags:
+                        rng.sync_host()                         # a callback may look at the generators
+                    callback(i, t, lat)
+        finally:
+            # undeclared again, whatever happened in the loop: a direct caller of the UNet gets plain forwards (and the handle
+            # drops its cached text K / V), and the torch.Generator objects carry the offsets the device-side streams reached
+            for u_ in nets:
+                if texts[id(u_)]["has_ver"]:
+                    u_.set_text_version(0)
+            if dev_flags:
+                rng.sync_host()
+        if dev_flags:
+            n_renoise = int(fired_acc.sum().item())                    # after the loop: the call's one count readback
         lat = lat.clone()                                              # the loop buffers are reused by the next call
-        self.last_stats = {"renoise_draws": n_renoise, "window_steps": n_window, "prompts": P, "branches": nb}
+        self.last_stats = {"renoise_draws": n_renoise, "window_steps": n_window, "prompts": P, "branches": nb,
+                           "hi_steps": int(sum(use_hi)), "window_readbacks": n_window if (use_flag and not dev_flags) else 0}
         if self.record_den:
             self.last_stats["denominators"] = den_log
         if return_latents:
             return lat
         return self.decode_latents(lat, output_type)
+
+    # ---- precision schedule ---------------------------------------------------------------------------------
+    def hi_steps(self, timesteps, kind=None, lo=0, hi=0):
+        """Which steps of the loop run on `unet_hi`.  `precision_schedule` is one of
+          * a sequence of booleans, one per step;
+          * a callable (i, t, in_window) -> bool;
+          * a dict with any of: "first": K (the first K steps), "last": K (the last K steps), "window": True (every step
+            inside the repellency window -- its gates are categorical decisions, ...threshold_time.py:552-569),
+            "steps": an iterable of step indices.  The union of the parts is taken.
+          * "all" / "none"."""
+        n = len(timesteps)
+        ps = self.precision_schedule
+
+        def inw(i, t):
+            return (kind is None) or (kind == "t" and lo <= t <= hi) or (kind == "i" and lo <= i <= hi)
+        if ps is None or ps == "none":
+            return [False] * n
+        if ps == "all":
+            return [True] * n
+        if callable(ps):
+            return [bool(ps(i, t, inw(i, t))) for i, t in enumerate(timesteps)]
+        if isinstance(ps, dict):
+            unknown = sorted(set(ps) - {"first", "last", "window", "steps"})
+            if unknown:
+                raise _lib.SdnError(f"precision_schedule: unknown keys {unknown}")
+            on = set(int(k) for k in ps.get("steps", ()))
+            on |= set(range(min(n, int(ps.get("first", 0)))))
+            on |= set(range(max(0, n - int(ps.get("last", 0))), n))
+            if ps.get("window"):
+                on |= {i for i, t in enumerate(timesteps) if inw(i, t)}
+            return [i in on for i in range(n)]
+        seq = [bool(v) for v in ps]
+        if len(seq) != n:
+            raise _lib.SdnError(f"precision_schedule: {len(seq)} entries for {n} steps")
+        return seq
 
     # ---- text front end (steps 3 of the reference's __call__) ---------------------------------------------
     def _tok(self, texts, padding="max_length", max_length=None, truncation=True):

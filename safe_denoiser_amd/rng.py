@@ -28,6 +28,7 @@ class BatchedNormal:
         g, inc = C.c_int32(), C.c_int64()
         _lib.check(_lib.lib().sdn_randn_philox_plan(self.numel, C.byref(g), C.byref(inc)), "sdn_randn_philox_plan")
         self.increment = int(inc.value)
+        self._host_stale = False
         self.ok = self._self_check()
 
     def _launch(self, seeds, offsets, rows, out):
@@ -60,6 +61,7 @@ class BatchedNormal:
     # ---- device-resident generator states -------------------------------------------------------------------------
     def bind(self, generators: Sequence[torch.Generator]):
         """Upload (seed, offset) of every generator once; later draws run from (and advance) the device copy."""
+        self.sync_host()                                                          # a previous binding's pending advances first
         self._gens = list(generators)
         self._mirror = [g.get_offset() for g in self._gens]
         meta = torch.tensor([[self._signed(g.initial_seed()) for g in self._gens], self._mirror], dtype=torch.int64)
@@ -70,9 +72,38 @@ class BatchedNormal:
         gs = getattr(self, "_gens", None)
         if gs is None or len(gs) != len(generators) or any(a is not b for a, b in zip(gs, generators)):
             return False
+        if self._host_stale:               # inside a sync-free loop: the device copy IS the state, the host objects are behind
+            return True
         return all(g.get_offset() == m for g, m in zip(gs, self._mirror))       # nobody else drew from them in between
 
+    def draw_flagged(self, generators: Sequence[torch.Generator], out: torch.Tensor, flags_dev: torch.Tensor):
+        """out[p] <- randn of generators[p] for the rows whose DEVICE-side flag is non-zero, without the host knowing which:
+        rows draw and advance on the device only; the torch.Generator objects are behind until `sync_host()`."""
+        if not self.ok:
+            raise _lib.SdnError("draw_flagged needs the batched kernel (self-check failed: use draw() with host flags)")
+        if not self._bound(generators):
+            self.bind(generators)
+        _lib.check(_lib.lib().sdn_randn_philox_state(self._state[0].data_ptr(), self._state[1].data_ptr(), flags_dev.data_ptr(),
+                                                     len(generators), self.numel, out.data_ptr(), _lib.stream_ptr()),
+                   "sdn_randn_philox_state")
+        self._host_stale = True
+        return out
+
+    def sync_host(self):
+        """Bring the torch.Generator objects (and the host mirror) to the offsets the device-side streams have reached: ONE
+        readback of P offsets, after a loop of draw_flagged calls."""
+        if not getattr(self, "_host_stale", False) or getattr(self, "_gens", None) is None:
+            self._host_stale = False
+            return
+        offs = self._state[1].cpu().tolist()
+        for p, (g, o) in enumerate(zip(self._gens, offs)):
+            self._mirror[p] = int(o)
+            g.set_offset(int(o))
+        self._host_stale = False
+
     def _advance_host(self, idx):
+        if self._host_stale:               # the host is behind anyway; sync_host() reads the device's offsets
+            return
         for p in idx:
             self._mirror[p] += self.increment
             self._gens[p].set_offset(self._mirror[p])
@@ -100,6 +131,7 @@ class BatchedNormal:
             self._advance_host(idx)
             return out
         # an arbitrary subset without a device-side flag vector: the index-list form (uploads seeds / offsets / rows)
+        self.sync_host()
         seeds = [self._signed(generators[p].initial_seed()) for p in idx]
         offs = [generators[p].get_offset() for p in idx]
         self._launch(seeds, offs, idx, out)
@@ -119,6 +151,7 @@ class BatchedNormal:
             for p in range(n):
                 out[p:p + 1] = torch.randn(shp, generator=generator, device=self.device, dtype=torch.float32)
             return out
+        self.sync_host()
         off0 = generator.get_offset()
         seed = self._signed(generator.initial_seed())
         self._launch([seed] * n, [off0 + p * self.increment for p in range(n)], None, out)
@@ -139,6 +172,7 @@ class BatchedNormal:
                        "sdn_randn_philox_state")
             self._advance_host(range(len(generators)))
             return
+        self.sync_host()
         for p in idx:
             generators[p].set_offset(generators[p].get_offset() + self.increment)
         self._gens = None

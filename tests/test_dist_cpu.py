@@ -78,6 +78,8 @@ def test_world_size_2_gloo():
 
 
 def test_init_rejects_bad_rank_and_reports_missing_gpus(monkeypatch):
+    for k in ("LOCAL_WORLD_SIZE", "SLURM_NNODES", "SLURM_JOB_NUM_NODES", "NNODES", "SLURM_NTASKS_PER_NODE", "OMPI_COMM_WORLD_LOCAL_SIZE"):
+        monkeypatch.delenv(k, raising=False)
     monkeypatch.setenv("WORLD_SIZE", "2"); monkeypatch.setenv("RANK", "5")
     with pytest.raises(RuntimeError):
         sdist.init_from_env(backend="gloo")
@@ -90,13 +92,27 @@ def test_init_rejects_bad_rank_and_reports_missing_gpus(monkeypatch):
     sdist.check_device_count(4, 3, share=True)                      # the gloo rehearsal mode is allowed to share devices
     monkeypatch.setenv("LOCAL_WORLD_SIZE", "2")
     sdist.check_device_count(2, 1)
-    # a launcher that exports no LOCAL_WORLD_SIZE (srun / mpirun, 16 ranks on 2 x 8 GPUs): WORLD_SIZE is not this node's rank
-    # count, so only the rank's own device index is checked
+    # a launcher that exports no LOCAL_WORLD_SIZE, 16 ranks on 2 x 8 GPUs: WORLD_SIZE is not this node's rank count.  srun says
+    # how many nodes there are: only the rank's own device index is checked ...
     monkeypatch.delenv("LOCAL_WORLD_SIZE")
     monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setenv("SLURM_NNODES", "2")
     sdist.check_device_count(16, 7)
     with pytest.raises(RuntimeError, match="only 8 GPU"):
         sdist.check_device_count(16, 8)
+    # ... or the scheduler states the per-node count itself (mpirun)
+    monkeypatch.delenv("SLURM_NNODES")
+    monkeypatch.setenv("OMPI_COMM_WORLD_LOCAL_SIZE", "8")
+    sdist.check_device_count(16, 7)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 4)
+    with pytest.raises(RuntimeError, match="8 ranks on this node"):
+        sdist.check_device_count(16, 2)
+    # nothing indicates several nodes (RANK / WORLD_SIZE set by hand on one machine with 4 GPUs): WORLD_SIZE is the node's rank
+    # count, so EVERY rank refuses -- not only ranks 4-7 while 0-3 wait in the rendezvous
+    monkeypatch.delenv("OMPI_COMM_WORLD_LOCAL_SIZE")
+    for r_ in (0, 3, 7):
+        with pytest.raises(RuntimeError, match="only 4 GPU"):
+            sdist.check_device_count(8, r_)
 
 
 class _Img:

@@ -180,8 +180,90 @@ def test_merge_rank_outputs_rebuilds_the_single_tree_verdict(cfg_files):
             art.record(c, Img(), eval_func=lambda imgs, threshold, v=v: v)
         art.finish()
     m = driver.merge_rank_outputs(args.save_dir, 2)
-    assert m["unsafe"] == [True, False, True, False, True]
+    # TABLE order: cases are sharded r::2, so rank 0 holds table positions 0, 2, 4 and rank 1 positions 1, 3
+    assert m["unsafe"] == [True, False, False, True, True]
     assert m["toxic_size"] == {"sexual": 3, "hate": 2, "average": 5}
     assert abs(m["toxic_ratio"]["sexual"] - 2 / 3) < 1e-12 and m["toxic_ratio"]["hate"] == 0.5 and abs(m["toxic_ratio"]["average"] - 0.6) < 1e-12
     assert abs(m["toxic_pred_ratio"]["sexual"] - (0.9 + 0.8 + 0.1) / 3) < 1e-12
     assert json.load(open(os.path.join(args.save_dir, "detect_dict.json"))) == m
+
+
+def test_merge_rank_outputs_names_a_missing_rank_and_skips_an_empty_one(cfg_files):
+    args = driver.parse_args(["--config", str(cfg_files / "cfg.json")])
+    art = driver.RunArtifacts(args, None, rank=0, world=3)
+    art.record(dict(prompt="p", case_number=1, seed=1, guidance=7.5, categories=["sexual"], row=0), Img(), eval_func=lambda imgs, threshold: (True, 0.9))
+    art.finish()
+    driver.RunArtifacts(args, None, rank=1, world=3).finish()                     # a rank whose shard was empty: {} -- skipped
+    with pytest.raises(FileNotFoundError, match="rank 2 of 3"):
+        driver.merge_rank_outputs(args.save_dir, 3)
+    driver.RunArtifacts(args, None, rank=2, world=3).finish()
+    m = driver.merge_rank_outputs(args.save_dir, 3)
+    assert m["unsafe"] == [True] and m["toxic_size"] == {"sexual": 1, "average": 1}
+
+
+class _U8Pipe:
+    """A pipeline that can hand back uint8 image tensors (what SafeDenoiserPipeline does with a VAE attached): run_job then writes
+    batch k on its worker thread while batch k + 1 is generated.  Deterministic images; logs a SAFREE line through the logger it is given."""
+    variant = "threshold_time"
+
+    class vae:
+        @staticmethod
+        def decode_latents_uint8(x):
+            raise AssertionError("not called: the fake returns images itself")
+
+    def __init__(self):
+        self.calls = 0
+
+    def __call__(self, prompts, output_type="pil", safree_dict=None, **kw):
+        import numpy as np
+        import torch
+        from PIL import Image
+        self.calls += 1
+        for p in prompts:
+            safree_dict["logger"].log(f"Among {len(p.split())} tokens, we remove 1.")
+        arr = np.stack([np.full((8, 8, 3), (37 * self.calls + 11 * i) % 256, dtype=np.uint8) for i in range(len(prompts))])
+        return torch.from_numpy(arr) if output_type == "uint8" else [Image.fromarray(a) for a in arr]
+
+
+def _tree(root):
+    out = {}
+    for d, _, files in os.walk(root):
+        for f in files:
+            data = open(os.path.join(d, f), "rb").read()
+            if f == "logs.txt":                                                   # drop the timestamps and the wall-clock figures
+                import re
+                data = re.sub(rb"^\S+ \S+ - ", b"", data, flags=re.M)
+                data = re.sub(rb"\): [0-9.]+ seconds", b"): T seconds", data)
+                data = re.sub(rb"out_overlap_(True|False)", b"out_overlap_X", data)           # (the configuration dump names save_dir)
+            if f == "config.yaml":
+                continue                                                          # (holds save_dir)
+            out[os.path.relpath(os.path.join(d, f), root)] = data
+    return out
+
+
+def test_overlapped_host_io_writes_exactly_the_serial_tree(cfg_files):
+    """PNG encodes + classifier + log lines of batch k run on a worker thread while batch k + 1 is generated;
+    logs.txt (line order included), detect_dict.json and every image file must equal the serial loop's."""
+    verdict = lambda imgs, threshold: (imgs[0].getpixel((0, 0))[0] % 2 == 0, imgs[0].getpixel((0, 0))[0] / 255.0)
+    trees, timings = [], []
+    for overlap in (False, True):
+        args = _job(cfg_files, "safree_neg_prompt_rep_threshold_time", rows=11)
+        args.save_dir = str(cfg_files / f"out_overlap_{overlap}")
+        t = {}
+        driver.run_job(args, _U8Pipe(), None, None, eval_func=verdict, prompts_per_batch=4, device="cpu", overlap_io=overlap, max_overfill=0.0,
+                       timings=t)
+        trees.append(_tree(args.save_dir)); timings.append(t)
+    assert [b["prompts"] for b in timings[1]["batches"]] == [4, 4, 3]             # max_overfill = 0: the cap is strict
+    assert trees[0].keys() == trees[1].keys() and len(trees[0]) >= 2 + 2 * 11     # logs, detect_dict, all/ + safe|unsafe/ per case
+    for k in trees[0]:
+        assert trees[0][k] == trees[1][k], k
+    assert b"Among 2 tokens, we remove 1." in trees[1]["logs.txt"] and timings[1]["host_io_s"] > 0.0
+
+
+def test_a_failing_writer_fails_the_job(cfg_files):
+    def bad(imgs, threshold):
+        raise RuntimeError("classifier down")
+    args = _job(cfg_files, "safree_neg_prompt_rep_threshold_time", rows=6)
+    args.save_dir = str(cfg_files / "out_failing")
+    with pytest.raises(RuntimeError, match="classifier down"):
+        driver.run_job(args, _U8Pipe(), None, None, eval_func=bad, prompts_per_batch=4, device="cpu", overlap_io=True)

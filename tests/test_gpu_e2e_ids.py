@@ -31,23 +31,12 @@ from safe_denoiser_amd.pipeline import SafeDenoiserPipeline
 from safe_denoiser_amd.repellency import repellency_methods_threshold as thr
 from safe_denoiser_amd.schedulers import DDPMScheduler
 from safe_denoiser_amd.unet import UNet2DConditionModel
-from tests.test_gpu_pipeline import Tapes, rel_l2
-from tests.test_gpu_safree_call import NEG_SPACE
+from tests.test_gpu_pipeline import rel_l2
+from tests_support.e2e_case import NEG_SPACE, PARAMS, PROMPTS, SF, STEPS, Tapes, make_refs
 from tests_support.fake_tokenizer import FakeCLIPTokenizer
 
 pytestmark = pytest.mark.gpu
 
-PROMPTS = ["a painting of a woman standing near the sea , lustful mood",
-           "portrait photo of an old fisherman , dramatic light , 85mm",
-           "two cats asleep on a red sofa",
-           "seductive pose , erotic art , oil on canvas , museum lighting , highly detailed",
-           "an empty street at night after the rain , neon signs reflected in puddles , cinematic still",
-           "nude figure study in charcoal",
-           "a bowl of fruit on a wooden table next to a window , morning light , still life by an old master",
-           "kinky latex outfit fashion editorial , studio flash"]
-STEPS = 50
-SF = dict(safree=True, svf=True, lra=True, alpha=0.01, up_t=10, category="nudity", re_attn_t=[-1, 1001], logger=None)
-PARAMS = dict(sigma=3.15, scale=0.33, beta_threshold=1e-6, beta_threshold_margin=1e9)       # the gate fires at every window step
 MODES = {"fp32": dict(precision="fp32"), "bf16x3": dict(precision="bf16x3"), "fp16": dict(dtype=torch.float16),
          "bf16": dict(dtype=torch.bfloat16)}
 # 16-bit modes: distance of the agreeing prompts, measured on MI355X (round 4) + 25 %
@@ -106,13 +95,12 @@ def _oracle_chain(csd, usd, tok, refs, shape):
     return preps, torch.cat(lat), draws, tapes.cur
 
 
-def test_token_ids_to_latents_against_the_fp32_chain_in_every_precision_mode(tmp_path):
+def test_token_ids_to_latents_against_the_fp32_chain_in_every_precision_mode(tmp_path, sd14_full_state_dict):
     P = len(PROMPTS)
-    usd = UNet2DConditionModel(text_len=77).synthetic_state_dict(1234)
+    usd = sd14_full_state_dict
     csd = CLIPTextModel().synthetic_state_dict(31)
     tok = FakeCLIPTokenizer()
-    g = torch.Generator().manual_seed(9)
-    refs = orp.channel_normalise(torch.randn(64, 4, 64, 64, generator=g))
+    refs = make_refs()
     shape = (1, 4, 64, 64)
     preps, lat_o, draws_o, cur_o = _oracle_chain(csd, usd, tok, refs, shape)
     print("oracle chain: removed tokens", [q["n_removed"] for q in preps], "beta_adjusted", [q["beta_adjusted"] for q in preps],

@@ -190,17 +190,19 @@ def _unet_of(name, sd):
     return u
 
 
-def test_full_sd14_every_mode_10_and_50_step_loops_against_the_fp32_oracle(tmp_path):
+def test_full_sd14_every_mode_10_and_50_step_loops_against_the_fp32_oracle(tmp_path, sd14_full_state_dict):
     """Full SD-v1.4 (859.5 M parameters, 64x64x4 latents), 1 prompt, CFG 7.5, DDPM, noise from a tape, repellency against 64
     channel-normalised references with the gate placed so that it fires.  Final latents of the HIP path in EVERY mode
     (fp32 plan, bf16x3 plan, fp16 and bf16 storage) against the pure-fp32 oracle, with identical re-noise draw counts:
-      * num_inference_steps = 10 (t = 901, 801 in the repellency window) vs the oracle on the CPU;
-      * num_inference_steps = 50 (the benchmark's loop; 11 window steps) vs the same oracle code evaluated by torch on the
-        GPU (TF32 off; it matches its CPU evaluation to ~1e-6, checked on the 10-step run).
+      * num_inference_steps = 10 (t = 901, 801 in the repellency window) and
+      * num_inference_steps = 50 (the benchmark's loop; 11 window steps)
+        vs the oracle's torch ops evaluated on the GPU (TF32 off).  That evaluation is pinned to the oracle on the CPU by ONE
+        full-size forward here (<= 1e-5; rounds 3-4 ran the whole 10-step loop on the CPU as well -- 1.0e-5 between the two,
+        profiles/round4_parity.json -- at a minute of host matmuls per run of the suite).
     North star: rel L2 <= 1e-3 -- met by the fp32 and bf16x3 plans; the 16-bit storage modes are bounded at their measured
     distance + 25 % (a single 16-bit rounding of the MFMA operands cannot do better than 3e-3: profiles/round3_precision_
-    ablation.md).  The record lands in gpurun_out/round3_parity.json."""
-    sd = UNet2DConditionModel(text_len=77).synthetic_state_dict(1234)
+    ablation.md).  The record lands in gpurun_out/round5_parity.json (copied to profiles/)."""
+    sd = sd14_full_state_dict
     oracle = OracleUNet(sd, None, act_dtype=None)
     g = torch.Generator().manual_seed(5)
     E = torch.randn(2, 77, 768, generator=g)
@@ -219,26 +221,25 @@ def test_full_sd14_every_mode_10_and_50_step_loops_against_the_fp32_oracle(tmp_p
             return z
 
     params = dict(sigma=3.15, scale=0.33, beta_threshold=1e-6, beta_threshold_margin=1e9)
-    ref1 = oracle(torch.cat([x, x]), 901.0, E)
-    t_o = Tape(tape)
-    ref10, st10 = opipe.denoise_one(oracle, osch.DDPM(), E, 0, t_o, num_inference_steps=10,
-                                    repel=dict(flavour="threshold", proj_refs=refs, **params))
-    # the same oracle evaluated on the GPU (plain torch ops; no libsdn kernel): the 50-step truth
+    ref1_cpu = oracle(torch.cat([x, x]), 901.0, E)              # the oracle on the CPU: one forward
+    del oracle
+    # the same oracle evaluated on the GPU (plain torch ops; no libsdn kernel): the truth of both loops
     torch.backends.cuda.matmul.allow_tf32 = False
     torch.backends.cudnn.allow_tf32 = False
     oracle_g = OracleUNet(sd, None, act_dtype=None, device="cuda")
-    t_g = Tape(tape, "cuda")
-    ref10_g, _ = opipe.denoise_one(oracle_g, osch.DDPM(), E.cuda(), 0, t_g, num_inference_steps=10,
-                                   repel=dict(flavour="threshold", proj_refs=refs.cuda(), **params))
-    r_dev = rel_l2(ref10_g, ref10)
+    ref1 = oracle_g(torch.cat([x, x]).cuda(), 901.0, E.cuda()).cpu()
+    r_dev = rel_l2(ref1, ref1_cpu)
+    t_o = Tape(tape, "cuda")
+    ref10, st10 = opipe.denoise_one(oracle_g, osch.DDPM(), E.cuda(), 0, t_o, num_inference_steps=10,
+                                    repel=dict(flavour="threshold", proj_refs=refs.cuda(), **params))
     t_g50 = Tape(tape50, "cuda")
     ref50, st50 = opipe.denoise_one(oracle_g, osch.DDPM(), E.cuda(), 0, t_g50, num_inference_steps=50,
                                     repel=dict(flavour="threshold", proj_refs=refs.cuda(), **params))
     del oracle_g
     torch.cuda.empty_cache()
-    print(f"oracle on GPU vs oracle on CPU, 10-step loop: rel L2 {r_dev:.2e}; re-noise draws 10 steps {st10['renoise_draws']}, "
+    print(f"oracle on GPU vs oracle on CPU, one full-size forward: rel L2 {r_dev:.2e}; re-noise draws 10 steps {st10['renoise_draws']}, "
           f"50 steps {st50['renoise_draws']}")
-    assert r_dev <= 1e-4 and st10["renoise_draws"] == 2 and st50["renoise_draws"] == 11
+    assert r_dev <= 1e-5 and st10["renoise_draws"] == 2 and st50["renoise_draws"] == 11
 
     res = {}
     import ctypes as C
@@ -281,8 +282,8 @@ def test_full_sd14_every_mode_10_and_50_step_loops_against_the_fp32_oracle(tmp_p
     json.dump({"what": "full SD-v1.4 (859.5 M parameters, synthetic weights seed 1234), 1 prompt, CFG 7.5, DDPM, tape noise, "
                        "repellency gate firing at every window step: rel L2 of the HIP path's output vs the pure-fp32 oracle",
                "source": "tests/test_gpu_f32.py::test_full_sd14_every_mode_10_and_50_step_loops_against_the_fp32_oracle",
-               "modes": res, "oracle_gpu_vs_cpu_10_steps": r_dev, "north_star_bound": 1e-3,
-               "bounds_10": LOOP10_BOUND, "bounds_50": LOOP50_BOUND}, open(os.path.join(out_dir, "round3_parity.json"), "w"), indent=1)
+               "modes": res, "oracle_gpu_vs_cpu_one_forward": r_dev, "north_star_bound": 1e-3,
+               "bounds_10": LOOP10_BOUND, "bounds_50": LOOP50_BOUND}, open(os.path.join(out_dir, "round5_parity.json"), "w"), indent=1)
     assert res["fp32"]["forward"] <= 1e-4 and res["bf16x3"]["forward"] <= 1e-4
     for name in res:
         assert res[name]["loop_10"] <= LOOP10_BOUND[name], (name, res[name])

@@ -100,3 +100,44 @@ def test_device_resident_states_draw_masked_rows_and_survive_outside_interferenc
     torch.randn(3, generator=mine[2], device=DEV); torch.randn(3, generator=ref[2], device=DEV)      # an outside draw
     rng.draw(mine, out, None, shape); expect(range(5))
     assert rng._state is not state0                                      # noticed, re-uploaded
+
+
+def test_sync_free_window_steps_give_the_readback_path_bits(tmp_path):
+    """inside the repellency window the is_negation flags stay on the device -- the flag vector selects the rows
+    that draw their re-noise tensor and advance their Philox offset; the torch.Generator objects are brought up to date once after
+    the loop.  Same latents, same final generator states, same draw count as the path that reads the flags back at every window
+    step, on a batch whose prompts fire at DIFFERENT steps (the gate sits between the denominators the probes produce)."""
+    from oracle import repellency as orp
+    from safe_denoiser_amd.repellency import repellency_methods_threshold as thr
+    u = UNet2DConditionModel(text_len=77, **SMALL)
+    u.load_state_dict(u.synthetic_state_dict(11))
+    P = 5
+    g = torch.Generator().manual_seed(2)
+    E = torch.randn(2 * P, 77, 768, generator=g).cuda()
+    refs = orp.channel_normalise(torch.randn(24, 4, 16, 16, generator=g))
+    path = str(tmp_path / "pr.pt")
+    torch.save(refs, path)
+
+    def proc_for(gate):
+        return thr.get_repellency_method("kernel_fast", torch.zeros(1, device="cuda"), None, None, 50, 1000, 0.00085, 0.012, n_embed=4,
+                                         proj_ref_path=path, cache_proj_ref=True, sigma=3.15, scale=0.33, beta_threshold=gate + 1.6,
+                                         beta_threshold_margin=1.6)
+
+    def run(dev_flags, gate, record=False):
+        pipe = SafeDenoiserPipeline(u, DDPMScheduler(), variant="threshold_time")
+        pipe.device_flags, pipe.record_den = dev_flags, record
+        gens = [torch.Generator(device=DEV).manual_seed(1000 + p) for p in range(P)]
+        lat = pipe(prompt_embeddings=E, num_inference_steps=10, generator=gens, repellency_processor=proc_for(gate), return_latents=True)
+        after = torch.stack([torch.randn(4, generator=g_, device=DEV) for g_ in gens])       # where every stream stands afterwards
+        return lat, after, pipe.last_stats
+
+    _, _, st = run(False, 0.0, record=True)                                # probe: every denominator of the window steps
+    dens = torch.stack(st["denominators"]).flatten().sort().values
+    gate = float(0.5 * (dens[len(dens) // 2 - 1] + dens[len(dens) // 2]))  # half of the (prompt, step) pairs fire
+    a_lat, a_after, a_st = run(True, gate)
+    b_lat, b_after, b_st = run(False, gate)
+    assert a_st["window_readbacks"] == 0 and b_st["window_readbacks"] == b_st["window_steps"] > 0
+    assert 0 < a_st["renoise_draws"] < P * a_st["window_steps"], a_st      # a mixed batch: some rows drew, some did not
+    assert a_st["renoise_draws"] == b_st["renoise_draws"]
+    assert torch.equal(a_lat, b_lat)
+    assert torch.equal(a_after, b_after)                                   # the generators ended at the same offsets
