@@ -305,7 +305,11 @@ int sdn_timestep_embed_f16(float timestep, int32_t batch, int32_t dim, void* out
  * They exist so the SAME launch plan can be compared with the reference's fp32 arithmetic (run_nudity.py:277 loads the
  * pipeline with torch_dtype=float32) to ~1e-6 per forward at full size; 16-bit storage cannot do better than 1e-3
  * (fp16) / 1e-2 (bf16) in any implementation.  The LayerNorm-folded, column-statistics and split-K forms have no f32
- * counterpart: an f32 plan uses the plain operator chain. */
+ * counterpart: an f32 plan uses the plain operator chain.
+ * sdn_groupnorm_f32's `stats_ws` is NOT optional scratch any more (round 4): a non-null, 8-byte-aligned pointer selects the
+ * row-major two-pass form, which WRITES batch * nchunk * groups * 2 DOUBLES there (nchunk <= 64): the full
+ * batch * 129 * groups * 2 floats documented for sdn_groupnorm_bf16 must be available.  Pass NULL for the per-group kernels,
+ * which need none. */
 int sdn_gemm_f32(const sdn_gemm_desc* d_host, const void* a, const void* a2, const void* w,
                  const float* bias, const float* rowbias, const float* rowgate, const void* residual, void* out,
                  void* stream);

@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--ratio", type=float, default=2.95)
     ap.add_argument("--quick", action="store_true", help="every 5th sensitivity arm only")
+    ap.add_argument("--verify", action="store_true", help="another weight seed: the two baselines and the candidate schedules only")
     ap.add_argument("--lo", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "round5_precision_schedule"))
     a = ap.parse_args()
@@ -111,6 +112,22 @@ def main():
     r_all, lat_all = arm("all bf16x3", "all")
     r_none, lat_none = arm(f"all {a.lo}", "none")
     res["arms"] += [r_all, r_none]
+
+    if a.verify:
+        for name, spec in (("window (11)", {"window": True}), ("first 10", {"first": 10}), ("first 15", {"first": 15}),
+                           ("window (11) + last 5", {"window": True, "last": 5})):
+            res["arms"].append(arm(name, spec)[0])
+        res["wall_s"] = round(time.time() - t00, 1)
+        os.makedirs(os.path.dirname(a.out), exist_ok=True)
+        json.dump(res, open(a.out + ".json", "w"), indent=1)
+        with open(a.out + ".md", "w") as f:
+            f.write(f"# Precision schedules on another weight seed ({a.seed}; 16-bit plan = {a.lo})\n\n| arm | precise steps | cost | worst rel L2 | "
+                    f"decisions / draws equal |\n|---|---|---|---|---|\n")
+            for r in res["arms"]:
+                f.write(f"| {r['name']} | {r['hi_steps']} | x{r['cost_vs_16bit']:.2f} | {r['worst']:.2e} | "
+                        f"{'yes' if r['decisions_equal'] and r['draws_equal'] else 'NO'} |\n")
+        print("wrote", a.out + ".json/.md", f"in {res['wall_s']} s")
+        return
 
     # ---- sensitivities
     ks = list(range(0, STEPS, 5 if a.quick else 1))
