@@ -195,6 +195,17 @@ k_conv_slab(const GemmArgs g) {
         }
       }
     };
+    // (experiment, see k_gemm_dma: dbg 32 / 64 = one half of the workgroup issues the next k-tile's DMA at the top of the iteration,
+    //  its SIMD partners behind their first k-step's MFMAs)
+    const bool dma_top = (g.dbg & 96) && ((wid < 4) == ((g.dbg & 32) != 0));
+    auto issue_next = [&]() {
+      if (more) issue_w(kt + 1);
+      if (tap == 0) {
+        if (c + 1 < nchunks) issue_slab_main(c + 1);
+        if (c >= 1) issue_slab_tail(c);
+      }
+    };
+    if (dma_top) issue_next();
     read_fa(0);
 #pragma unroll
     for (int j = 0; j < 2; ++j) fw[0][j] = *reinterpret_cast<const typename T::v8*>(sw + lds_off(j * 16 + fr, fq));
@@ -216,13 +227,7 @@ k_conv_slab(const GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][2 * gq + j] = T::mfma16(fw[gi & 1][j], fa[ks][i], acc[i][2 * gq + j]);
       __builtin_amdgcn_s_setprio(0);
-      if (gi == 4) {                                         // DMA behind the first k-step's MFMAs (see k_gemm_dma)
-        if (more) issue_w(kt + 1);
-        if (tap == 0) {
-          if (c + 1 < nchunks) issue_slab_main(c + 1);
-          if (c >= 1) issue_slab_tail(c);
-        }
-      }
+      if (gi == 4 && !dma_top) issue_next();                  // DMA behind the first k-step's MFMAs (see k_gemm_dma)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -268,7 +273,7 @@ int dispatch_conv_slab(int dtype, const GemmArgs& g, hipStream_t st) {
   if (g.a_mode != 1 || g.Hs != g.Ws || g.Ho != g.Hs || g.Wo != g.Ws ||
       !sdn_conv_slab_shape_ok(g.M, g.N, g.Cin, g.Ws, g.stride, g.upsample, g.conv_off, g.x3_out ? SDN_OUT_BF16 : g.out_kind, g.n_valid))
     return SDN_GEMM_NOT_SLAB;
-  if (g.kt_per_split != 0 || g.rowgate || g.act != 0 || g.stamps || g.dbg || (g.residual && !g.res_lds && !g.x3_out) ||
+  if (g.kt_per_split != 0 || g.rowgate || g.act != 0 || g.stamps || (g.dbg & ~96) || (g.residual && !g.res_lds && !g.x3_out) ||
       (g.rowbias && g.rows_per_batch != g.Hs * g.Ws))
     return SDN_GEMM_NOT_SLAB;
   return dtype == 0 ? launch_slab<SdnBF16>(g, st) : launch_slab<SdnF16>(g, st);

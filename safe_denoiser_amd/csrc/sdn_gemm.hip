@@ -314,7 +314,12 @@ k_gemm_dma(const GemmArgs g) {
     // half (+3...9 % on the K = 640...2560 shapes over the top-of-iteration placement, +2...4 % more from the split); 3x3 conv:
     // everything after the whole first k-step (+7...9 %; the split is neutral there).  Later positions lose.  The 128-row tile
     // (two workgroups per CU cover each other) loses 2-7 % with any late position.  (tools/bench_gemm.py VARIANTS=0,64,128.)
-    const int ipos = (NSTAGE == 2 && WGM == 4 && !(g.dbg & 8)) ? ((g.dbg & 4) ? 1 : (g.a_mode == 1 ? 2 : ((g.act == 2 && g.K >= 1280) ? 1 : 4))) : 0;   // dbg 8: top of the iteration, 4: unsplit (A/B)
+    int ipos = (NSTAGE == 2 && WGM == 4 && !(g.dbg & 8)) ? ((g.dbg & 4) ? 1 : (g.a_mode == 1 ? 2 : ((g.act == 2 && g.K >= 1280) ? 1 : 4))) : 0;   // dbg 8: top of the iteration, 4: unsplit (A/B)
+    // Experiment (round 5): the two waves of a SIMD (wid, wid + 4) run the same phase order, so their DMA-issue
+    // stretches (9 pieces x 100-185 cycles) coincide and the matrix pipe idles under both.  dbg 32 / 64 stagger them: one half of the
+    // workgroup issues the next k-tile's pieces at the TOP of the iteration (the matrix pipe then belongs to its SIMD partner), the
+    // other half behind its first k-step's MFMAs.
+    if (NSTAGE == 2 && WGM == 4 && (g.dbg & 96)) ipos = ((wid < 4) == ((g.dbg & 32) != 0)) ? 0 : 2;
     // (the long-K GEGLU projection of the 16 x 16 level is the one plain shape that prefers the unsplit form: 802 vs 852 us)
     const bool more = kt + NSTAGE - 1 < nk && !(g.dbg & 2);
     if (ipos == 0 && more) issue((kt + NSTAGE - 1) & (NSTAGE - 1));
