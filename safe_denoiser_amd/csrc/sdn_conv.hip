@@ -195,9 +195,9 @@ k_conv_slab(const GemmArgs g) {
         }
       }
     };
-    // (experiment, see k_gemm_dma: dbg 32 / 64 = one half of the workgroup issues the next k-tile's DMA at the top of the iteration,
-    //  its SIMD partners behind their first k-step's MFMAs)
-    const bool dma_top = (g.dbg & 96) && ((wid < 4) == ((g.dbg & 32) != 0));
+    // the younger half of the workgroup issues the next k-tile's DMA at the top of the iteration, its SIMD partners of the older
+    // half behind their first k-step's MFMAs (see k_gemm_dma; dbg 32: everyone behind the first k-step as in rounds 2-4, 64: reversed)
+    const bool dma_top = !(g.dbg & 32) && ((wid >= 4) != ((g.dbg & 64) != 0));
     auto issue_next = [&]() {
       if (more) issue_w(kt + 1);
       if (tap == 0) {

@@ -36,6 +36,8 @@ SHAPES = [  # name, M, N, K, conv(H, Cin) or None, act
     ("mmdit ff1 1536", B * 1024, 6144, 1536, None, 3),
 ]
 VARIANTS = [int(v) for v in os.environ.get("VARIANTS", "0,1").split(",")]
+if os.environ.get("SKIP"):                                   # comma-separated substrings of the shape names to drop
+    SHAPES = [s for s in SHAPES if not any(k in s[0] for k in os.environ["SKIP"].split(","))]
 if os.environ.get("ONLY"):                                   # comma-separated substrings of the shape names to keep
     SHAPES = [s for s in SHAPES if any(k in s[0] for k in os.environ["ONLY"].split(","))]
 
