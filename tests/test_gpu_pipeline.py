@@ -395,3 +395,43 @@ def test_mixed_guidance_batch_gives_each_prompt_the_bits_of_its_own_scalar_call(
         assert torch.equal(one[0], both[p]), p
     with pytest.raises(Exception):
         pipe(prompt_embeddings=E, num_inference_steps=2, guidance_scale=[7.5], return_latents=True)
+
+
+def test_precision_schedule_switches_plans_per_step(world, tmp_path):
+    """Round 5: `SafeDenoiserPipeline(unet=<16-bit plan>, unet_hi=<precise plan>, precision_schedule=...)` runs each step on the plan
+    the schedule names.  Plumbing check at the small configuration with the readme's three-branch text switching (per-prompt svf step
+    counts -> the mixed text buffer exists on BOTH plans) and a firing gate:
+      * "all"  == the precise plan alone, bit for bit;  "none" == the 16-bit plan alone, bit for bit;
+      * {"window": True} = the repellency-window steps only: its latents are NOT the all-16-bit ones, and sit closer to the precise
+        plan's than the 16-bit plan's do (at this size the window is 2 of 10 steps -- the ones that carry the error, DESIGN 10.1);
+      * draw counts and the tapes' cursors never depend on the schedule."""
+    u_bf, sd, E, refs, P = world
+    shape = (1, 4, 16, 16)
+    Es = _safe_text(E, P, 77)
+    sf = dict(safree=True, svf=True, lra=True, re_attn_t=(-1, -1))
+    params = dict(sigma=3.15, scale=0.33, beta_threshold=1e-6, beta_threshold_margin=1e9)
+    lo = UNet2DConditionModel(text_len=77, dtype=torch.float16, latent_repeat=3, **SMALL); lo.load_state_dict(sd)
+    hi = UNet2DConditionModel(text_len=77, precision="bf16x3", latent_repeat=3, **SMALL); hi.load_state_dict(sd)
+
+    def run(unet, unet_hi=None, schedule=None):
+        pipe = SafeDenoiserPipeline(unet, DDPMScheduler(), variant="threshold_time", unet_hi=unet_hi, precision_schedule=schedule)
+        t = Tapes(P, shape, 3 * STEPS + 4, seed=21)
+        lat = pipe(prompt_embeddings=E.cuda(), num_inference_steps=STEPS, repellency_processor=make_proc(thr, refs, tmp_path, **params),
+                   noise_fn=t, safree_dict=sf, rescaled_text_embeddings=Es.cuda(), beta_adjusted=[3, 0, 7][:P], return_latents=True)
+        return lat, pipe.last_stats, list(t.cur)
+
+    only_lo, st_lo, cur_lo = run(lo)
+    only_hi, st_hi, cur_hi = run(hi)
+    s_all, st_all, cur_all = run(lo, hi, "all")
+    s_none, st_none, cur_none = run(lo, hi, "none")
+    s_win, st_win, cur_win = run(lo, hi, {"window": True})
+    assert torch.equal(s_all, only_hi) and torch.equal(s_none, only_lo)
+    assert st_all["hi_steps"] == STEPS and st_none["hi_steps"] == 0 and st_win["hi_steps"] == st_win["window_steps"] == 2
+    assert cur_lo == cur_hi == cur_all == cur_none == cur_win
+    assert st_lo["renoise_draws"] == st_hi["renoise_draws"] == st_win["renoise_draws"] > 0
+    d_lo, d_win = rel_l2(only_lo, only_hi), rel_l2(s_win, only_hi)
+    print(f"small configuration, distance from the bf16x3 plan's latents: fp16 plan {d_lo:.2e}, fp16 + bf16x3 inside the window {d_win:.2e}")
+    assert not torch.equal(s_win, only_lo) and d_win < 0.6 * d_lo
+    # a later call on the 16-bit plan alone is unaffected by the second plan's text cache (versions are process-wide, ADVICE r4)
+    again, _, _ = run(lo)
+    assert torch.equal(again, only_lo)
