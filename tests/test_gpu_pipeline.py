@@ -42,11 +42,15 @@ class Tapes:
         return z.clone()
 
 
-# Where the oracle's torch ops are evaluated.  The oracle is a CPU restatement; its arithmetic is the same torch code on either
-# device (TF32 off), and ONE mode of test_loop_matches_oracle ("ddpm_threshold_time") keeps the CPU evaluation as the pin, together
-# with test_oracle_evaluates_the_same_on_both_devices.  Everything else runs it on the GPU: on a shared box the small CPU loops
-# took 30-45 s each under host contention (270 s of a 900 s suite limit).
-ODEV = "cuda"
+# Where the oracle's torch ops are evaluated: the CPU.  Round 5 tried the GPU for these loops (on a shared box the small CPU loops
+# took 30-45 s each under host contention) and found that a STORAGE-EMULATING oracle is not the same function on the two devices:
+# fp32 summation order differs in the last bit, which moves 16-bit roundings, and over a 10-step CFG loop the two evaluations of
+# the SAME bf16-emulating oracle end 3.4e-2 apart -- as far as the engine is from either (test_oracle_on_both_devices below pins
+# the pure-fp32 oracle across devices at <= 1e-4 and records the emulating one's spread).  So the 16-bit loop bounds of this file are
+# distances between two bf16-noisy trajectories (a statistic, measured + 25 %), the full-size tests against the pure-fp32 oracle
+# (tests/test_gpu_f32.py, test_gpu_e2e_ids.py) are the acceptance, and the emulating oracles stay on the device the bounds were
+# measured on.  ODEV = "cuda" would evaluate them on the GPU.
+ODEV = "cpu"
 
 
 class DevTapes:
@@ -175,7 +179,7 @@ def test_loop_matches_oracle(world, tmp_path, mode):
         repel_o, proc, variant = None, None, "threshold_time"
 
     t_o = Tapes(P, shape, 3 * STEPS + 4, seed=5)
-    ref, draws_o = run_oracle(sd, E, refs, P, t_o, sched_o, variant, repel_o, dev="cpu" if mode == "ddpm_threshold_time" else None)
+    ref, draws_o = run_oracle(sd, E, refs, P, t_o, sched_o, variant, repel_o)
     t_p = Tapes(P, shape, 3 * STEPS + 4, seed=5)
     pipe = SafeDenoiserPipeline(u, sched_p(), variant=variant)
     lat = pipe(prompt_embeddings=E.cuda(), num_inference_steps=STEPS, guidance_scale=7.5, repellency_processor=proc,
@@ -191,22 +195,27 @@ def test_loop_matches_oracle(world, tmp_path, mode):
         assert draws_o > 0                                             # the gate fired at least once
 
 
-def test_oracle_evaluates_the_same_on_both_devices(world):
-    """The oracle is a CPU restatement in plain torch ops; most loop tests here evaluate those ops on the GPU (ODEV).  Pin: the
-    whole 10-step loop of one prompt -- storage-emulating UNet, CFG, x0 probe, repellency, re-noise, DDPM steps -- lands on the
-    same latents on either device (bf16 emulation rounds at the same points; what differs is fp32 summation order)."""
+def test_oracle_on_both_devices(world):
+    """The oracle is a CPU restatement in plain torch ops; the full-size tests evaluate those ops on the GPU (TF32 off).  Pin, on the
+    whole 10-step loop of one prompt (UNet, CFG, x0 probe, repellency, re-noise, DDPM steps): the PURE-fp32 oracle lands on the same
+    latents on either device (<= 1e-4).  Recorded beside it: the bf16-EMULATING oracle does not -- last-bit differences of the fp32
+    sums move its 16-bit roundings and the loop amplifies them to the size of the bf16 noise itself (3.4e-2 measured) -- which is
+    why the emulating oracles of this file stay on the CPU, where their bounds were measured."""
     u, sd, E, refs, P = world
     shape = (1, 4, 16, 16)
     params = dict(sigma=3.15, scale=0.33, beta_threshold=1e-6, beta_threshold_margin=1e9)
-    out = {}
-    for dev in ("cpu", "cuda"):
-        t = Tapes(P, shape, 3 * STEPS + 4, seed=5)
-        out[dev], st = opipe.denoise_one(o_unet(sd, torch.bfloat16, dev), osch.DDPM(), torch.stack([E[0], E[P]]).to(dev), 0, DevTapes(t, dev),
-                                         num_inference_steps=STEPS, repel=o_repel(dict(flavour="threshold", proj_refs=refs, **params), dev))
-        assert st["renoise_draws"] == 2
-    r = rel_l2(out["cuda"], out["cpu"])
-    print(f"oracle loop, GPU evaluation vs CPU evaluation (bf16-emulating, small configuration): rel L2 {r:.2e}")
-    assert r <= 5e-3          # far below the 3e-2 ... 5e-2 the engine's bf16 storage sits from either
+    res = {}
+    for name, act in (("fp32", None), ("bf16-emulating", torch.bfloat16)):
+        out = {}
+        for dev in ("cpu", "cuda"):
+            t = Tapes(P, shape, 3 * STEPS + 4, seed=5)
+            out[dev], st = opipe.denoise_one(o_unet(sd, act, dev), osch.DDPM(), torch.stack([E[0], E[P]]).to(dev), 0, DevTapes(t, dev),
+                                             num_inference_steps=STEPS, repel=o_repel(dict(flavour="threshold", proj_refs=refs, **params), dev))
+            assert st["renoise_draws"] == 2
+        res[name] = rel_l2(out["cuda"], out["cpu"])
+    print(f"oracle loop, GPU evaluation vs CPU evaluation (small configuration): pure fp32 {res['fp32']:.2e}, bf16-emulating {res['bf16-emulating']:.2e}")
+    assert res["fp32"] <= 1e-4
+    assert res["bf16-emulating"] <= 8e-2          # a sanity bound only: see the docstring
 
 
 def test_device_generators_are_per_prompt(world):
