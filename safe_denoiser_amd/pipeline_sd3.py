@@ -10,7 +10,14 @@ Restates the hot loop of models/sdv3/safe_denoiser_pipeline.py:1105-1165 on libs
     else: lat = scheduler.step(v, t, lat)       (Euler)                                          :1165
     lat = lat.to(latents_dtype)   (the reference keeps fp16 latents between steps)               :1161,1167-1171
 Text encoders (CLIP x2 + T5) are outside the hot path: pass `prompt_embeds` [2P,333,4096] and
-`pooled_prompt_embeds` [2P,2048] ([P negative | P positive]).  `return_latents=True` (the engine-side default: the loop's own
+`pooled_prompt_embeds` [2P,2048] ([P negative | P positive]) -- or the reference's four separate tensors (`prompt_embeds`,
+`negative_prompt_embeds`, `pooled_prompt_embeds`, `negative_pooled_prompt_embeds`, each [P, ...]; concatenated as :1069,1081-1082) --
+or, round 5, PROMPT STRINGS as the reference's call takes them (:862-891, run_nudity_sdv3.py:351-360) with a caller-supplied
+`text_front_end` (constructor argument) that owns the three third-party encoders and exposes the three calls the reference makes:
+`encode_prompt(prompt=, negative_prompt=, ...)` -> (prompt_embeds, negative_prompt_embeds, pooled, negative_pooled) (:1038-1059),
+`masked_encode_prompt(prompt)` -> [n_tokens, 4096] (:773-860) and `encode_negative_prompt_space(phrases)` -> [n_phrases, 4096]
+(:722-771).  The orchestration between them is the reference's: the negative prompt is OVERWRITTEN with the 17 joined concept
+phrases (:988-996), the SAFREE projection (`mask_to_onp`, :1061-1078) runs per prompt, the projected text is fed at every step.  `return_latents=True` (the engine-side default: the loop's own
 output) gives the latents; with a `vae` and `return_latents=False` the call ends like the reference's (:1195-1214) and returns
 `StableDiffusion3PipelineOutput(images=...)` -- `.images` as run_nudity_sdv3.py:351-360 reads it (`return_dict=False`: a tuple;
 `output_type="latent"`: the latents in `.images`).
@@ -41,9 +48,16 @@ class StableDiffusion3PipelineOutput:
         self.images = images
 
 
+# the concept phrases hard-coded in the reference's __call__ (models/sdv3/safe_denoiser_pipeline.py:988-994)
+SD3_NEGATIVE_PROMPT_SPACE = ["Sexual Acts", "Content Meant to Arouse Sexual Excitement", "Nudity", "Pornography", "Erotic Art", "Lustful",
+                             "Seductive", "Orgasmic", "Libido", "Kinky", "Sexual Orientation", "Sexual Attraction", "Sexual Intercourse",
+                             "Sexual Pleasure", "Sexual Fantasy", "Carnal Desires", "Sexual Gratification"]
+
+
 class SD3SafeDenoiserPipeline:
-    def __init__(self, transformer, scheduler, vae=None):
+    def __init__(self, transformer, scheduler, vae=None, text_front_end=None):
         self.transformer, self.scheduler, self.vae = transformer, scheduler, vae
+        self.text_front_end = text_front_end   # the caller's CLIP x2 + T5 stack (see the module docstring); None = embeddings only
         self.vae_scale_factor = 8
         self.last_stats = {}
         self._bufs = {}
@@ -56,11 +70,32 @@ class SD3SafeDenoiserPipeline:
                  prompt_embeds: Optional[torch.Tensor] = None, pooled_prompt_embeds: Optional[torch.Tensor] = None,
                  repellency_processor=None, latents_dtype=torch.float16, return_latents: bool = True,
                  noise_fn: Optional[Callable] = None, rescaled_text_embeddings: Optional[torch.Tensor] = None,
-                 masked_embs=None, negspace_embs: Optional[torch.Tensor] = None, safree_alpha: float = 0.01, **kwargs):
+                 masked_embs=None, negspace_embs: Optional[torch.Tensor] = None, safree_alpha: float = 0.01,
+                 negative_prompt=None, negative_prompt_embeds: Optional[torch.Tensor] = None,
+                 negative_pooled_prompt_embeds: Optional[torch.Tensor] = None, **kwargs):
         _lib.require_gpu()
+        if prompt_embeds is None and prompt is not None and self.text_front_end is not None:
+            # the reference's steps 1-3 (:985-1078) for P prompts: its own negative prompt, the three encoder calls, and the inputs
+            # of the SAFREE projection (which runs below, per prompt, on the GPU)
+            fe = self.text_front_end
+            prompts = [prompt] if isinstance(prompt, str) else list(prompt)
+            neg = ", ".join(SD3_NEGATIVE_PROMPT_SPACE)                        # (:996: whatever the caller passed is overwritten)
+            pe, npe, pp, npp = fe.encode_prompt(prompt=prompts, negative_prompt=[neg] * len(prompts))
+            prompt_embeds, negative_prompt_embeds, pooled_prompt_embeds, negative_pooled_prompt_embeds = pe, npe, pp, npp
+            if masked_embs is None and rescaled_text_embeddings is None:
+                masked_embs = [fe.masked_encode_prompt(p_) for p_ in prompts]
+                negspace_embs = fe.encode_negative_prompt_space(SD3_NEGATIVE_PROMPT_SPACE)
+        if negative_prompt_embeds is not None:                                 # the reference's four-tensor form -> [negative | positive]
+            if negative_pooled_prompt_embeds is None or prompt_embeds is None or pooled_prompt_embeds is None:
+                raise _lib.SdnError("negative_prompt_embeds needs prompt_embeds, pooled_prompt_embeds and negative_pooled_prompt_embeds")
+            if negative_prompt_embeds.shape != prompt_embeds.shape or negative_pooled_prompt_embeds.shape != pooled_prompt_embeds.shape:
+                raise _lib.SdnError("negative / positive embeddings must have the same shapes")
+            prompt_embeds = torch.cat([negative_prompt_embeds, prompt_embeds], dim=0)                     # (:1069,1081)
+            pooled_prompt_embeds = torch.cat([negative_pooled_prompt_embeds, pooled_prompt_embeds], dim=0)   # (:1082)
         if prompt_embeds is None or pooled_prompt_embeds is None:
             raise NotImplementedError("text encoders are outside the hot path: pass prompt_embeds [2P,T,4096] and "
-                                      "pooled_prompt_embeds [2P,2048] ([P negative | P positive])")
+                                      "pooled_prompt_embeds [2P,2048] ([P negative | P positive]), or construct the pipeline with "
+                                      "text_front_end= (the caller's CLIP x2 + T5 stack) and pass `prompt` strings")
         output_type = kwargs.get("output_type", "pil")
         return_dict = kwargs.get("return_dict", True)
         if output_type == "latent":                                          # the reference's own latent tap (:1195-1196)

@@ -224,6 +224,67 @@ def test_sd3_loop_with_safree_text_projection(tmp_path):
     assert r <= 1e-2
 
 
+def test_sd3_call_with_prompt_strings_runs_the_references_front_end_orchestration():
+    """models/sdv3/safe_denoiser_pipeline.py:862-891,985-1078: `pipe(prompt=[...], negative_prompt=...)`.  The three third-party
+    encoders (CLIP x2 + T5) belong to the caller (`text_front_end`); the orchestration between their calls is the reference's: the
+    caller's negative prompt is OVERWRITTEN with the 17 joined concept phrases, the masked-prompt / concept states feed the SAFREE
+    projection, the projected text goes to the transformer at every step.  With a recording front end the call must equal the
+    embeddings-level call on what the front end returned, and the reference's four-tensor form must equal the concatenated one."""
+    from safe_denoiser_amd.pipeline_sd3 import SD3_NEGATIVE_PROMPT_SPACE, SD3SafeDenoiserPipeline
+    from safe_denoiser_amd.schedulers import FlowMatchEulerDiscreteScheduler
+    m = SD3Transformer2DModel(text_len=45, dtype=torch.float16, **SMALL)
+    m.load_state_dict(m.synthetic_state_dict(5))
+    prompts = ["a lustful portrait in oil", "two cats asleep on a red sofa in the evening sun"]
+    P = len(prompts)
+
+    class FrontEnd:                                   # deterministic stand-ins for the encoders' outputs
+        def __init__(self):
+            self.calls = []
+
+        def _g(self, text):
+            import zlib
+            return torch.Generator().manual_seed(zlib.crc32(text.encode()))
+
+        def encode_prompt(self, prompt, negative_prompt, **kw):
+            self.calls.append(("encode_prompt", list(prompt), list(negative_prompt)))
+            pe = torch.stack([torch.randn(45, 128, generator=self._g(p)) for p in prompt])
+            ne = torch.stack([torch.randn(45, 128, generator=self._g("neg" + n)) for n in negative_prompt])
+            pp = torch.stack([torch.randn(64, generator=self._g("pool" + p)) for p in prompt])
+            npp = torch.stack([torch.randn(64, generator=self._g("npool" + n)) for n in negative_prompt])
+            return pe.cuda(), ne.cuda(), pp.cuda(), npp.cuda()
+
+        def masked_encode_prompt(self, prompt):
+            self.calls.append(("masked", prompt))
+            return torch.randn(len(prompt.split()), 128, generator=self._g("m" + prompt)).cuda()
+
+        def encode_negative_prompt_space(self, phrases):
+            self.calls.append(("space", list(phrases)))
+            return torch.randn(len(phrases), 128, generator=self._g("space")).cuda()
+
+    fe = FrontEnd()
+    tape = torch.randn(P, 1, 16, 16, 16, generator=torch.Generator().manual_seed(3))
+    nf = lambda p, shape: tape[p].clone()
+    pipe = SD3SafeDenoiserPipeline(m, FlowMatchEulerDiscreteScheduler(), text_front_end=fe)
+    out = pipe(prompt=prompts, negative_prompt="something the reference ignores", num_inference_steps=5, guidance_scale=3.5, noise_fn=nf)
+    joined = ", ".join(SD3_NEGATIVE_PROMPT_SPACE)
+    assert fe.calls[0] == ("encode_prompt", prompts, [joined] * P)                     # (:996: the caller's negative prompt is overwritten)
+    assert [c[0] for c in fe.calls[1:]] == ["masked", "masked", "space"] and fe.calls[-1][1] == SD3_NEGATIVE_PROMPT_SPACE
+    # the same call from the embeddings the front end returned, in the reference's four-tensor form and in the concatenated form
+    fe2 = FrontEnd()
+    pe, ne, pp, npp = fe2.encode_prompt(prompts, [joined] * P)
+    masked = [fe2.masked_encode_prompt(p) for p in prompts]
+    space = fe2.encode_negative_prompt_space(SD3_NEGATIVE_PROMPT_SPACE)
+    plain = SD3SafeDenoiserPipeline(m, FlowMatchEulerDiscreteScheduler())
+    kw = dict(num_inference_steps=5, guidance_scale=3.5, noise_fn=nf, masked_embs=masked, negspace_embs=space)
+    four = plain(prompt_embeds=pe, negative_prompt_embeds=ne, pooled_prompt_embeds=pp, negative_pooled_prompt_embeds=npp, **kw)
+    cat = plain(prompt_embeds=torch.cat([ne, pe]), pooled_prompt_embeds=torch.cat([npp, pp]), **kw)
+    assert torch.equal(out, four) and torch.equal(four, cat)
+    with pytest.raises(NotImplementedError):
+        plain(prompt=prompts, num_inference_steps=2)                                       # no front end, no embeddings
+    with pytest.raises(Exception):
+        plain(prompt_embeds=pe, negative_prompt_embeds=ne, pooled_prompt_embeds=pp, num_inference_steps=2)
+
+
 @pytest.fixture(scope="module")
 def sd3_medium():
     """Full SD3-medium (~2 B parameters, synthetic weights seed 3) on the engine + its state_dict, shared by the two full-size tests
