@@ -102,6 +102,16 @@ k_attn(const AttnArgs a) {
   constexpr int NDB = (HD + 31) / 32;         // 32-row blocks of O^T
   constexpr bool ONES = (HD % 32) != 0;       // a free padding column exists -> row sums via MFMA
   constexpr bool OFFSET_FREE = T::kDtype == 0; // bf16 has fp32's exponent range: softmax without max subtraction (below)
+  // fp16 with a FREE padding column in the Q K^T contraction (d = 40 -> 48) and LDS-DMA tiles -- round 5.  fp16's P needs p < 2^16,
+  // so the bf16 form (no offset at all) is out; the classic form pays one FMA + 1/2 v_max3 per score that the bf16 loop does not
+  // (VALU is this kernel's bound: 31.4 vs 23.5 ms per forward at B = 192).  Here the scale is folded into Q as for bf16 and the
+  // query's exponent is CENTRED on its first tile's maximum m0 once: column HD of every K row reads 1.0 (the static block) and
+  // column HD of the Q fragment is set to -m0 after tile 0, so the MFMA itself delivers s - m0 for all later tiles -- no per-score
+  // subtraction, no running maximum.  p <= 2^15 is checked afterwards through the row sum (sum >= p); a workgroup with a query
+  // outside [2^-10, 2^15] re-runs its block with the guarded (running-maximum) loop.
+  constexpr bool CENTRED = T::kDtype == 1 && !SEG && !MASK && DMA && (KQ * 16 > HD);
+  constexpr bool QSCALED = OFFSET_FREE || CENTRED;
+  static_assert(!CENTRED || ((HD % 32) != 0 && HD - 16 * (KQ - 1) == 8), "centred form: row sums by the ones column, column HD = element 0 of the h = 1 lanes");
   constexpr int CH = HD / 8;                  // valid 16-B chunks per K / V row
   // Single-buffer inputs (DMA): K/V tiles arrive by LDS-DMA (buffer_load ... lds, 16 B per lane, one linear 1-KiB
   // piece per wave-instruction): no staging registers, no ds_write pass.  A DMA piece cannot skip bytes, so the tiles
@@ -189,7 +199,7 @@ k_attn(const AttnArgs a) {
       v = *reinterpret_cast<const u32x4*>(row_ptr<SEG>(a.q, a.q2, a.ldq, a.ldq2, a.n1, a.nq, b, q0 + 32 * qs + r) + head * HD + dc);
     // fold scale * log2(e) into Q once (re-rounded to the storage type): the MFMA then yields scores already in
     // log2 units, and the per-score FMA of the softmax disappears (VALU is this kernel's bound for d = 40)
-    if (OFFSET_FREE) {
+    if (QSCALED) {
       v.x = T::pack2(T::to_f(v.x & 0xffff) * a.c, T::to_f(v.x >> 16) * a.c);
       v.y = T::pack2(T::to_f(v.y & 0xffff) * a.c, T::to_f(v.y >> 16) * a.c);
       v.z = T::pack2(T::to_f(v.z & 0xffff) * a.c, T::to_f(v.z >> 16) * a.c);
@@ -311,6 +321,11 @@ k_attn(const AttnArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) o[qs][d][i] = 0.f;
     m_run[qs] = OFFSET_FREE ? 0.f : -1e30f; l_run[qs] = 0.f; m_hi[qs] = -1e30f;
+    if constexpr (CENTRED) {                             // column HD of Q: 0 at the start of either pass (the guarded re-run wants it 0)
+      u32x4 v = *reinterpret_cast<u32x4*>(&qf[qs][KQ - 1]);
+      if (h == 1) v.x &= 0xffff0000u;
+      qf[qs][KQ - 1] = *reinterpret_cast<typename T::v8*>(&v);
+    }
   }
 
   // tr-read lane geometry
@@ -350,7 +365,7 @@ k_attn(const AttnArgs a) {
 #pragma unroll
         for (int s = 0; s < KQ; ++s) {
           const unsigned char* kp = sK + (32 * kb + r) * KSTR + (16 * s + 8 * h) * 2;
-          if (DMA && 16 * s + 16 > HD) { if (16 * s + 8 * h >= HD) kp = smem + ZOFF + 16; }   // zero padding of d
+          if (DMA && 16 * s + 16 > HD) { if (16 * s + 8 * h >= HD) kp = smem + ZOFF + (CENTRED ? 0 : 16); }   // zero padding of d (CENTRED: [1, 0 ...])
           kfa[kb][s] = *reinterpret_cast<const typename T::v8*>(kp);
         }
       __builtin_amdgcn_sched_barrier(0);
@@ -369,7 +384,7 @@ k_attn(const AttnArgs a) {
           kf = kfa[kb][s];
         } else {
           const unsigned char* kp = sK + (32 * kb + r) * KSTR + (16 * s + 8 * h) * 2;
-          if (DMA && 16 * s + 16 > HD) { if (16 * s + 8 * h >= HD) kp = smem + ZOFF + 16; }   // zero padding of d
+          if (DMA && 16 * s + 16 > HD) { if (16 * s + 8 * h >= HD) kp = smem + ZOFF + (CENTRED ? 0 : 16); }   // zero padding of d (CENTRED: [1, 0 ...])
           kf = *reinterpret_cast<const typename T::v8*>(kp);
         }
 #pragma unroll
@@ -410,7 +425,9 @@ k_attn(const AttnArgs a) {
 #pragma unroll
     for (int qs = 0; qs < QS; ++qs) {
     [[maybe_unused]] float mx = 0.f;
-    if constexpr (safe) {
+    bool need_mx = safe;                           // (a compile-time constant except in the centred fp16 pass: its first tile only)
+    if constexpr (CENTRED && !safe) need_mx = t == 0;
+    if (need_mx) {
     mx = fmaxf(st[qs][0][0], st[qs][1][0]);
 #pragma unroll
     for (int i = 1; i < 16; ++i) mx = fmaxf(fmaxf(mx, st[qs][0][i]), st[qs][1][i]);
@@ -456,6 +473,41 @@ k_attn(const AttnArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) ps += st[qs][0][i] + st[qs][1][i];
       l_run[qs] += ps;
+    }
+    } else if constexpr (CENTRED) {
+    if constexpr (!safe) {
+      if (t == 0) {
+        // the offset is the first tile's maximum ROUNDED to the storage type: tile 0 subtracts exactly what the MFMA will
+        // subtract for the later tiles (column HD: K reads 1.0, Q holds -off)
+        const unsigned o16 = T::pack2(mx, 0.f) & 0xffffu;
+        const float off = T::to_f(o16);
+        m_run[qs] = off;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) st[qs][kb][i] -= off;
+        u32x4 v = *reinterpret_cast<u32x4*>(&qf[qs][KQ - 1]);
+        if (h == 1) v.x = (v.x & 0xffff0000u) | (o16 ^ 0x8000u);      // -off: the sign bit of the 16-bit pattern
+        qf[qs][KQ - 1] = *reinterpret_cast<typename T::v8*>(&v);
+      }
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st[qs][kb][i] = __builtin_amdgcn_exp2f(st[qs][kb][i]);
+    } else {                                        // guarded re-run: running maximum on the pre-scaled scores (column HD of Q is 0)
+      const float m_new = fmaxf(m_run[qs], mx);
+      if (__builtin_amdgcn_ballot_w64(m_new != m_run[qs]) != 0) {            // wave-uniform: rescale only when needed
+        const float alpha = __builtin_amdgcn_exp2f(m_run[qs] - m_new);
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) o[qs][d][i] *= alpha;
+        m_run[qs] = m_new;
+      }
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st[qs][kb][i] = __builtin_amdgcn_exp2f(st[qs][kb][i] - m_new);
     }
     } else {                                          // fp16: classic running-max form (fp16 P needs p <= 1)
     const float m_new = fmaxf(m_run[qs], mx);
@@ -585,12 +637,13 @@ k_attn(const AttnArgs a) {
     } else {
       l_tot[qs] = l_run[qs] + __shfl_xor(l_run[qs], 32, 64);  // both halves hold partial sums of the same query
     }
-    bad |= !(l_tot[qs] >= 0x1p-64f && l_tot[qs] <= 0x1p64f);
+    if constexpr (CENTRED) bad |= !(l_tot[qs] >= 0x1p-10f && l_tot[qs] <= 0x1p15f);   // every p <= sum <= 2^15 < fp16's maximum
+    else bad |= !(l_tot[qs] >= 0x1p-64f && l_tot[qs] <= 0x1p64f);
   }
   return bad;
   };   // run_pass
   bool rerun = true;
-  if constexpr (OFFSET_FREE) {
+  if constexpr (OFFSET_FREE || CENTRED) {
     if (a.nomax) {
       const bool bad = run_pass(std::false_type{});
       if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) *reinterpret_cast<volatile unsigned*>(smem + ZOFF + 32) = 1u;

@@ -383,6 +383,54 @@ def test_attention_optimistic_pass_gives_the_guarded_pass_bits(kind, N, Nk, d):
     assert rel_l2(out, ref) <= 8e-3, rel_l2(out, ref)
 
 
+@pytest.mark.parametrize("kind", ["plain", "spike_up_late", "spike_up_moderate", "all_far_down", "ragged_cross"])
+@pytest.mark.parametrize("d", [40, 80])
+def test_attention_fp16_centred_pass_and_its_guarded_rerun(kind, d):
+    """fp16 storage, d = 40 (round 5): the scale rides in Q, and each query's exponent is centred ONCE on its first tile's maximum m0
+    -- column 40 of every K row reads 1.0, column 40 of the Q fragment is set to -m0 after tile 0, so the MFMA delivers s - m0 for
+    the later tiles with no per-score VALU work and no running maximum; sum_k p <= 2^15 is checked afterwards and a workgroup
+    with a query outside the window re-runs its block with the guarded loop.  Inputs: ordinary; a late key 2^20 above the first
+    tile's maximum (p would overflow fp16: the re-run); one 2^9 above it (stays on the fast pass with p up to 512); every score far
+    below zero (the offset does its job); 77 keys with a ragged tile.  Against float64 softmax attention on the fp16 values, and
+    against the guarded loop alone (sdn_debug_set_attn_nomax(0)).  d = 80 has no free column: the classic form, unchanged."""
+    B, H, N = 1, 8, 512
+    Nk = 77 if kind == "ragged_cross" else 512
+    C_ = H * d
+    g = torch.Generator().manual_seed(43)
+    q = torch.randn(B, N, C_, generator=g) * 0.5
+    k = torch.randn(B, Nk, C_, generator=g) * 0.5
+    v = torch.randn(B, Nk, C_, generator=g)
+    f = (40 / d) ** 0.25
+    if kind == "spike_up_late":
+        q[0, 7, :d] = 4.0 * f; k[0, Nk - 30, :d] = 4.0 * f                    # logit 16 * 40 / sqrt(40) = 101 nats = 2^146 above the rest
+    if kind == "spike_up_moderate":
+        q[0, 7, :d] = 1.0 * f; k[0, Nk - 30, :d] = 1.0 * f                    # 6.3 nats = 2^9: inside the window
+    if kind == "all_far_down":
+        q[0, 9, d:2 * d] = 4.0 * f; k[0, :, d:2 * d] = (-2.0 + 0.05 * torch.randn(Nk, d, generator=g)) * f     # all ~ -50 nats
+    q, k, v = q.half(), k.half(), v.half()
+    sp = lambda t, n: t.double().reshape(B, n, H, d).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(sp(q, N), sp(k, Nk), sp(v, Nk)).transpose(1, 2).reshape(B, N, C_)
+    lib = sda.lib()
+    try:
+        lib.sdn_debug_set_attn_nomax(0)
+        guarded = ops.attention(q.cuda(), k.cuda(), v.cuda(), H)
+        torch.cuda.synchronize()
+    finally:
+        lib.sdn_debug_set_attn_nomax(1)
+    out = ops.attention(q.cuda(), k.cuda(), v.cuda(), H)
+    assert torch.isfinite(out).all()
+    r_out, r_g, r_between = rel_l2(out, ref), rel_l2(guarded, ref), rel_l2(out, guarded)
+    print(f"fp16 attention d={d} {kind}: vs float64 {r_out:.2e} (guarded loop alone {r_g:.2e}); between the two {r_between:.2e}")
+    assert r_out <= 1.2e-3 and r_g <= 1.2e-3                                  # P and the output are rounded to fp16: 2^-11 per element
+    for row, hd in ((7, 0), (9, 1)):                                          # the forced rows themselves
+        sl = slice(hd * d, (hd + 1) * d)
+        assert rel_l2(out[0, row, sl], ref[0, row, sl]) <= 3e-3
+    if d == 80 or kind == "spike_up_late":
+        # d = 80: one form only; the overflowing block: the re-run IS the guarded loop -> the same bits for that block's rows
+        blk = slice(0, 256) if d == 40 else slice(0, N)
+        assert torch.equal(out[0, blk, :d], guarded[0, blk, :d])
+
+
 # ------------------------------------------------------------------------------------------ conv_in / temb
 def test_conv_in_and_timestep_embedding():
     B, H = 2, 64
