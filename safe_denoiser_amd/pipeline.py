@@ -110,6 +110,9 @@ class SafeDenoiserPipeline:
         passed (DDPMScheduler.from_pretrained, :108 -- including its clip_sample) and the tokenizer is
         loaded when its vocabulary files are present.  `torch_dtype`: bf16 / fp16 storage, or float32 = the fp32 plan
         (`precision="bf16x3"` = fp32 storage with split-operand contractions); the VAE and text encoder take the 16-bit type.
+        `precision="scheduled"` (round 5) = the fp32 RESULT at 1.4 x the 16-bit cost: the fp16 plan and the bf16x3 plan over the
+        same weights, the bf16x3 one on the steps inside the repellency window (`precision_schedule=`, default {"window": True};
+        DESIGN 10.1), text encoder bf16x3.
         `variant` = the gating variant (SD_FUNCTIONS[erase_id], driver.ERASE_IDS); `latent_repeat` = guidance branches that
         share their latents (2 = CFG, 3 = lra / SLD).  `revision` and other hub arguments are accepted and ignored."""
         import os
@@ -123,9 +126,18 @@ class SafeDenoiserPipeline:
         if scheduler is None:
             scheduler = DDPMScheduler.from_pretrained(model_dir, subfolder="scheduler")
         dt16 = torch_dtype if torch_dtype in (torch.bfloat16, torch.float16) else torch.bfloat16
-        unet = UNet2DConditionModel(dtype=torch_dtype, latent_repeat=latent_repeat, precision=precision,
-                                    **ck.unet_kwargs(ck.read_config(os.path.join(model_dir, "unet"))))
-        unet.load_state_dict(ck.load_weights(os.path.join(model_dir, "unet"), weights_variant), device=device)
+        ucfg = ck.unet_kwargs(ck.read_config(os.path.join(model_dir, "unet")))
+        usd = ck.load_weights(os.path.join(model_dir, "unet"), weights_variant)
+        unet_hi = schedule = None
+        if precision == "scheduled":
+            schedule = kwargs.pop("precision_schedule", None) or {"window": True}
+            unet = UNet2DConditionModel(dtype=torch.float16, latent_repeat=latent_repeat, **ucfg)     # fp16: a bf16 step costs 8 x its error
+            unet_hi = UNet2DConditionModel(latent_repeat=latent_repeat, precision="bf16x3", **ucfg)
+            unet_hi.load_state_dict(usd, device=device)
+        else:
+            unet = UNet2DConditionModel(dtype=torch_dtype, latent_repeat=latent_repeat, precision=precision, **ucfg)
+        unet.load_state_dict(usd, device=device)
+        del usd
         vae = enc = None
         if os.path.isdir(os.path.join(model_dir, "vae")):
             vae = AutoencoderKL(dtype=dt16, **ck.vae_kwargs(ck.read_config(os.path.join(model_dir, "vae"))))
@@ -133,12 +145,13 @@ class SafeDenoiserPipeline:
         if os.path.isdir(os.path.join(model_dir, "text_encoder")):
             # the reference loads the text encoder in the pipeline's dtype (run_nudity.py:277: fp32): an fp32 / bf16x3 UNet gets the
             # text encoder in the same precision mode -- its states feed every cross-attention and the SAFREE decisions
-            enc_kw = dict(dtype=dt16) if unet.precision is None else dict(precision=unet.precision)
+            enc_kw = dict(precision="bf16x3") if unet_hi is not None else (dict(dtype=dt16) if unet.precision is None else dict(precision=unet.precision))
             enc = CLIPTextModel(**enc_kw, **ck.clip_kwargs(ck.read_config(os.path.join(model_dir, "text_encoder"))))
             enc.load_state_dict(ck.load_weights(os.path.join(model_dir, "text_encoder"), weights_variant), device=device)
         if tokenizer is None:
             tokenizer = ck.load_tokenizer(model_dir)
-        return cls(unet, scheduler, variant=variant, vae=vae, text_encoder=enc, tokenizer=tokenizer)
+        return cls(unet, scheduler, variant=variant, vae=vae, text_encoder=enc, tokenizer=tokenizer, unet_hi=unet_hi,
+                   precision_schedule=schedule)
 
     def to(self, *args, **kwargs):
         """`pipe.to(device)` of the reference's load_sd (run_nudity.py:131): the engine's weights already live on the GPU."""

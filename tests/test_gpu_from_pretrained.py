@@ -97,3 +97,35 @@ def test_from_pretrained_then_the_reference_call_site_returns_pil_images(tmp_pat
     out = pipe(target_prompt, num_inference_steps=3, callback=lambda i, t, lat: seen.append((i, int(t), tuple(lat.shape))),
                callback_steps=2, output_type="np", return_dict=False, safree_dict={"lra": True})
     assert seen == [(0, 667, (1, 4, 16, 16)), (2, 1, (1, 4, 16, 16))] and out.shape == (1, 32, 32, 3)
+
+
+def test_from_pretrained_scheduled_precision_builds_both_plans(tmp_path):
+    """`from_pretrained(dir, precision="scheduled")`: the fp16 plan + the bf16x3 plan over the same checkpoint, bf16x3 inside the
+    repellency window, text encoder bf16x3 -- the same images as the stack built by hand."""
+    root = str(tmp_path / "ckpt")
+    usd, vsd, csd = _write_checkpoint(root)
+    tok = FakeCLIPTokenizer(vocab_size=CLIP_CFG["vocab_size"])
+    pipe = SafeDenoiserPipeline.from_pretrained(root, precision="scheduled", variant="threshold_time", latent_repeat=3, tokenizer=tok)
+    assert pipe.unet.dtype == torch.float16 and pipe.unet_hi.precision == "bf16x3" and pipe.text_encoder.precision == "bf16x3"
+    assert pipe.precision_schedule == {"window": True}
+    refs = orp.channel_normalise(torch.randn(12, 4, 16, 16, generator=torch.Generator().manual_seed(4)))
+    torch.save(refs, tmp_path / "proj_ref.pt")
+    proc = thr.get_repellency_method("kernel_fast", torch.zeros(1, device="cuda"), None, None, 6, 1000, 0.00085, 0.012, n_embed=4,
+                                     scale=0.33, sigma=3.15, proj_ref_path=str(tmp_path / "proj_ref.pt"), cache_proj_ref=True,
+                                     beta_threshold=1e-6, beta_threshold_margin=1e9)
+    space = driver.NUDITY_NEGATIVE_PROMPT_SPACE
+    kw = dict(guidance_scale=7.5, num_inference_steps=10, height=128, width=128, negative_prompt=", ".join(space), negative_prompt_space=space,
+              repellency_processor=proc, safree_dict=dict(safree=True, svf=True, lra=True, alpha=0.01, up_t=10, category="nudity", logger=None,
+                                                          re_attn_t=[-1, 1001]))
+    prompts = ["a painting of a woman standing near the sea , lustful mood", "two cats asleep on a red sofa"]
+    gens = lambda: [torch.Generator(device="cuda").manual_seed(7 + i) for i in range(2)]
+    imgs = pipe(prompts, generator=gens(), **kw)
+    assert pipe.last_stats["hi_steps"] == pipe.last_stats["window_steps"] == 2 and pipe.last_stats["window_readbacks"] == 0
+    lo = UNet2DConditionModel(text_len=77, dtype=torch.float16, latent_repeat=3, **SMALL); lo.load_state_dict(usd)
+    hi = UNet2DConditionModel(text_len=77, precision="bf16x3", latent_repeat=3, **SMALL); hi.load_state_dict(usd)
+    v = AutoencoderKL(**VAE_CFG); v.load_state_dict(vsd)
+    c = CLIPTextModel(precision="bf16x3", **CLIP_CFG); c.load_state_dict(csd)
+    direct = SafeDenoiserPipeline(lo, DDPMScheduler(), variant="threshold_time", vae=v, text_encoder=c, tokenizer=tok, unet_hi=hi,
+                                  precision_schedule={"window": True})
+    for a, b in zip(direct(prompts, generator=gens(), **kw), imgs):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
