@@ -321,6 +321,13 @@ class _OrderedWriter:
             self.close()
         self.q.put(fn)
 
+    def acquire_slot(self):
+        """Blocks while `depth` batches are in flight -- but never on a worker that has failed (its queued batches are skipped,
+        so their slots would never come back): the failure is raised here instead."""
+        while not self.slots.acquire(timeout=0.2):
+            if self.err is not None:
+                self.close()
+
     def close(self):
         self.q.put(None)
         self.t.join()
@@ -411,7 +418,7 @@ def run_job(args, pipe, repellency_processor=None, task_config: Optional[Mapping
             from PIL import Image
             for c in batch:
                 writer.submit(lambda c=c: art.log_case(c))
-            writer.slots.acquire()                                  # at most `depth` batches of images in flight
+            writer.acquire_slot()                                   # at most `depth` batches of images in flight
             t0 = time.time()
             u8 = call(batch, "uint8", qlog)                         # [P, H, W, 3] uint8 on the device: what numpy_to_pil would build
             if u8.is_cuda:

@@ -263,7 +263,8 @@ def test_overlapped_host_io_writes_exactly_the_serial_tree(cfg_files):
 def test_a_failing_writer_fails_the_job(cfg_files):
     def bad(imgs, threshold):
         raise RuntimeError("classifier down")
-    args = _job(cfg_files, "safree_neg_prompt_rep_threshold_time", rows=6)
+    # more batches than the writer keeps in flight: the producer must not wait forever for slots a dead worker never returns
+    args = _job(cfg_files, "safree_neg_prompt_rep_threshold_time", rows=24)
     args.save_dir = str(cfg_files / "out_failing")
     with pytest.raises(RuntimeError, match="classifier down"):
         driver.run_job(args, _U8Pipe(), None, None, eval_func=bad, prompts_per_batch=4, device="cpu", overlap_io=True)
