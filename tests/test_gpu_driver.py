@@ -101,3 +101,50 @@ def test_run_job_with_an_sld_erase_id_builds_the_safety_concept_branch(tmp_path)
     assert pipe.last_stats["branches"] == 3 and pipe.last_stats["prompts"] == 2
     with pytest.raises(Exception):                                       # caller-supplied rows that do not match the prompt count
         pipe(["a", "b"], prompt_embeddings=E3[:4], num_inference_steps=2, return_latents=True, **driver.SLD_CONFIGS["MEDIUM"])
+
+
+@pytest.mark.parametrize("config", ["copro_1k_config3", "coco_10k_config5"])
+def test_baseline_config_3_and_5_tables_through_run_job_on_one_rank_of_two(tmp_path, config):
+    """BASELINE configs 3 (CoPro_balanced_1k.csv: `idx, unsafe_prompt, safe_prompt, concept, category`; run_copro.py:436-448, the
+    `fast` repellency module, :52) and 5 (datasets/coco_30k.csv: `case_number, source, prompt, evaluation_seed, coco_id`; run_coco30k.py:400-426) are
+    prompt-sharded 8-GPU jobs; no multi-GPU node exists for this build, so what CAN run does: the table in its own dialect through
+    `driver.run_job` as rank 1 of a 2-rank world on the engine (rows 1, 3, ... of the table, a per-rank tree, global case numbers)."""
+    from safe_denoiser_amd.repellency import repellency_methods_fast as fast
+    if config == "copro_1k_config3":
+        rows = ["idx,unsafe_prompt,safe_prompt,concept,category"] + [
+            f'{28731 + i},"An unsafe prompt number {i} about a quarrel","A safe prompt {i}",ostracism,Harrasment' for i in range(5)]
+        erase_id, mod, cat_flag, want = "safree_neg_prompt_rep_time", fast, "nudity", ["28732_n-u-d-i-t-y.png", "28734_n-u-d-i-t-y.png"]
+        params = {"scale": 0.03}
+    else:
+        # the header of the reference's own datasets/coco_30k.csv (the `prompt` + `case_number` dialect, no categories column)
+        rows = ["case_number,source,prompt,evaluation_seed,coco_id"] + [f'{i},coco-30k,"A bicycle replica with a clock as wheel {i}.",{41337 + i},{203564 + i}'
+                                                                        for i in range(5)]
+        erase_id, mod, cat_flag, want = "safree_neg_prompt_rep_threshold_time", thr, "all", ["1_n-u-d-i-t-y.png", "3_n-u-d-i-t-y.png"]
+        params = {"scale": 0.33, "sigma": 3.15, "beta_threshold": 1e-6, "beta_threshold_margin": 1e9}
+    (tmp_path / "table.csv").write_text("\n".join(rows) + "\n")
+    refs = orp.channel_normalise(torch.randn(12, 4, 16, 16, generator=torch.Generator().manual_seed(4)))
+    torch.save(refs, tmp_path / "proj_ref.pt")
+    task = {"repellency": {"method": "kernel_fast", "n_embed": 4, "guidance_scale": 0.0,
+                           "params": dict(params, proj_ref_path=str(tmp_path / "proj_ref.pt"), cache_proj_ref=True)},
+            "data": {"name": config}, "mean_processor": {}}
+    (tmp_path / "task.yaml").write_text(yaml.dump(task))
+    cfg = {"erase_id": erase_id, "safree": True, "svf": True, "lra": True, "nudity": cat_flag, "data": str(tmp_path / "table.csv"),
+           "save_dir": str(tmp_path / "out"), "num_inference_steps": 6, "image_length": 128, "task_config": str(tmp_path / "task.yaml")}
+    (tmp_path / "cfg.json").write_text(json.dumps(cfg))
+    args = driver.parse_args(["--config", str(tmp_path / "cfg.json")])
+    tc = driver.load_task_config(args.task_config)
+    u = UNet2DConditionModel(text_len=77, latent_repeat=3, **SMALL); u.load_state_dict(u.synthetic_state_dict(11))
+    enc = CLIPTextModel(dtype=torch.float16, **CLIP_CFG); enc.load_state_dict(enc.synthetic_state_dict(31))
+    vae = AutoencoderKL(block_out_channels=(64, 128), layers_per_block=1, sample_size=32); vae.load_state_dict(vae.synthetic_state_dict(5))
+    sch = DDPMScheduler()
+    pipe = SafeDenoiserPipeline(u, sch, variant=driver.ERASE_IDS[erase_id][1], vae=vae, text_encoder=enc,
+                                tokenizer=FakeCLIPTokenizer(vocab_size=CLIP_CFG["vocab_size"]))
+    kw = driver.repellency_kwargs(tc, args.num_inference_steps, sch)
+    proc = mod.get_repellency_method(kw.pop("name"), torch.zeros(1, device="cuda"), None, None, **kw)
+    t = {}
+    art = driver.run_job(args, pipe, proc, tc, eval_func=lambda imgs, threshold: (False, 0.1), prompts_per_batch=2, rank=1, world=2, timings=t)
+    assert art.save_dir.endswith("rank01") and [b["prompts"] for b in t["batches"]] == [2]          # rows 1 and 3 of five
+    assert sorted(os.listdir(os.path.join(art.save_dir, "all"))) == want
+    assert pipe.last_stats["branches"] == 3 and pipe.last_stats["window_steps"] > 0 and pipe.last_stats["window_readbacks"] == 0
+    d = json.load(open(os.path.join(art.save_dir, "detect_dict.json")))
+    assert d["unsafe"] == [False, False] and d["toxic_size"]["average"] == 2
