@@ -194,6 +194,22 @@ def cpu_baseline(args):
             lat = s.add_noise(d["x_0_hat"], torch.randn(lat.shape, generator=g), t)
         lat = s.step(eps, t, lat, generator=g).prev_sample
         times[t] = time.perf_counter() - t0
+    # SURVEY 8d's own CPU case, BASELINE config 1 (SD-v1.4 DDIM 50 steps, 2 CFG branches, repellency OFF, fp32): one iteration of one
+    # prompt at full size, extrapolated to 50 (on the resident oracle UNet)
+    cfg1 = None
+    try:
+        unet1 = unet
+        sd_ = osch.DDIM(); sd_.set_timesteps(50)
+        lat1 = torch.randn(1, 4, 64, 64, generator=g)
+        t0 = time.perf_counter()
+        out1 = unet1(torch.cat([lat1] * 2), 981.0, text[:2])
+        eps1 = out1[0:1] + 7.5 * (out1[1:2] - out1[0:1])
+        lat1 = sd_.step(eps1, 981, lat1).prev_sample
+        t_it = time.perf_counter() - t0
+        cfg1 = {"value": 1.0 / (50 * t_it), "unit": "images/sec", "sample": f"BASELINE config 1 (DDIM 50 steps, b = 2, repellency off, fp32): one full-size "
+                                                                            f"iteration of one prompt = {t_it:.2f} s, extrapolated x 50"}
+    except Exception as e:                                            # the secondary figure must never cost the line
+        cfg1 = {"error": repr(e)}
     t_dec = 0.0
     if args.workload == "e2e":
         del unet, sd
@@ -206,7 +222,7 @@ def cpu_baseline(args):
             "threads": {"torch_get_num_threads": cores, "torch_get_num_interop_threads": torch.get_num_interop_threads(),
                         "os_cpu_count": os.cpu_count(), "sched_affinity": len(os.sched_getaffinity(0)),
                         "OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS")},
-            "warmup_forward_s": t_warm,
+            "warmup_forward_s": t_warm, "config1": cfg1,
             "sample": f"1 prompt x 2 of 50 iterations at full size: t=981 {times[981]:.2f} s (window: UNet b={nb} fp32 + CFG + x0 "
                       f"probe + repellency M={args.refs} + re-noise + DDPM step), t=761 {times[761]:.2f} s (UNet + CFG + DDPM step)"
                       + (f", VAE decode {t_dec:.2f} s" if t_dec else "") +
@@ -418,7 +434,7 @@ def measure_job(args, dev, P, gate_beta, total=None):
     return res
 
 
-def measure_e2e_scheduled(args, dev, proc, P, mine, schedule, lo="f16", timed_batches=2):
+def measure_e2e_scheduled(args, dev, proc, P, mine, schedule, lo="f16", timed_batches=2, elide=False):
     """The HEADLINE call with a per-step PRECISION SCHEDULE (round 5): two launch plans over the same weights -- the 16-bit plan
     (`lo`) and the bf16x3 plan -- and `schedule` (SafeDenoiserPipeline.hi_steps forms) says which of the 50 steps run on the
     precise one.  Text encoder bf16x3 throughout (its output feeds the categorical SAFREE decisions), VAE decoder 16-bit (after
@@ -430,12 +446,13 @@ def measure_e2e_scheduled(args, dev, proc, P, mine, schedule, lo="f16", timed_ba
     from safe_denoiser_amd.vae import AutoencoderKL
     from tests_support.fake_tokenizer import FakeCLIPTokenizer
     dt_lo = torch.float16 if lo == "f16" else torch.bfloat16
-    u_lo = UNet2DConditionModel(latent_repeat=3, dtype=dt_lo); u_lo.load_synthetic_on_device(1234, device=dev)
-    u_hi = UNet2DConditionModel(latent_repeat=3, precision="bf16x3"); u_hi.load_synthetic_on_device(1234, device=dev)
+    rep = 2 if elide else 3
+    u_lo = UNet2DConditionModel(latent_repeat=rep, dtype=dt_lo); u_lo.load_synthetic_on_device(1234, device=dev)
+    u_hi = UNet2DConditionModel(latent_repeat=rep, precision="bf16x3"); u_hi.load_synthetic_on_device(1234, device=dev)
     enc = CLIPTextModel(precision="bf16x3"); enc.load_synthetic_on_device(4242, device=dev)
     vae = AutoencoderKL(dtype=_dtype(args)); vae.load_synthetic_on_device(4321, device=dev)
     pipe = SafeDenoiserPipeline(u_lo, make_scheduler(args.scheduler), variant="threshold_time", vae=vae, text_encoder=enc,
-                                tokenizer=FakeCLIPTokenizer(), unet_hi=u_hi, precision_schedule=schedule)
+                                tokenizer=FakeCLIPTokenizer(), unet_hi=u_hi, precision_schedule=schedule, elide_dead_branch=elide)
 
     def call(k, n):
         idx = [mine[(k * P + j) % len(mine)] for j in range(P)]
@@ -455,6 +472,7 @@ def measure_e2e_scheduled(args, dev, proc, P, mine, schedule, lo="f16", timed_ba
            "schedule": schedule if not callable(schedule) else "callable", "precise_steps": pipe.last_stats["hi_steps"],
            "workload": "the headline call (README-default end to end, 3 guidance branches)", "prompts_per_batch": P,
            "timed_batches": timed_batches, "ms_per_batch": dt * 1e3, "renoise_draws": renoise,
+           "guidance_branches_computed": pipe.last_stats["branches"],
            "window_readbacks_per_batch": pipe.last_stats["window_readbacks"]}
     del u_lo, u_hi, enc, vae, pipe
     torch.cuda.empty_cache()
@@ -944,6 +962,10 @@ def main():
         line["e2e_scheduled"]["ids_to_latents_rel_l2_vs_fp32_chain"] = ("1.0e-4 max over 8 prompts, all decisions / draw counts equal "
                                                                          "(profiles/round5_precision_schedule.md, round5_e2e_ids.json)")
         line["value_at_north_star_tolerance"] = line["e2e_scheduled"]["value"]
+        line["e2e_scheduled_dead_branch_elided"] = dict(
+            measure_e2e_scheduled(args, dev, proc, min(P, 64), mine, {"window": True}, timed_batches=1, elide=True),
+            note="the scheduled mode with lra's discarded third branch not computed (bit-identical latents, 2/3 of the UNet work): a labelled "
+                 "secondary, NOT value_at_north_star_tolerance")
         line["value_at_north_star_tolerance_mode"] = "e2e_scheduled (fp16 plan + bf16x3 plan inside the repellency window; text encoder bf16x3)"
         line["parity"] = measure_parity(args, dev)
         line["job_515"] = measure_job(args, dev, P, beta)
