@@ -234,14 +234,25 @@ class RunArtifacts:
     def log_time(self, case: dict, seconds: float):
         self.logger.log(f"Wall-Clock Time for image generation (Case#: {case['case_number']}): {seconds:.2f} seconds")
 
-    def record(self, case: dict, image, eval_func: Optional[Callable] = None) -> Optional[str]:
+    def record(self, case: dict, image, eval_func: Optional[Callable] = None, png: Optional[bytes] = None) -> Optional[str]:
         """Saves one generated image (a PIL image or anything with .save(path)) the way the reference does and updates the
-        counters.  `eval_func(images, threshold=) -> (is_unsafe, pred)` stands where the NudeNet evaluator sits (:471)."""
+        counters.  `eval_func(images, threshold=) -> (is_unsafe, pred)` stands where the NudeNet evaluator sits (:471).
+        `png`: the image already encoded (what `image.save(path)` would write): the reference encodes the same image two or three
+        times (:469,490,504); with the bytes at hand every copy is a plain file write."""
         a = self.args
         case_num, cats = case["case_number"], case["categories"]
+        if png is not None:
+            class _Encoded:                                        # .save(path) of the rest of this method
+                @staticmethod
+                def save(path):
+                    with open(path, "wb") as f:
+                        f.write(png)
+            saver = _Encoded
+        else:
+            saver = image
         if "artists-" in a.category:
             path = os.path.join(self.all_dir, f"{case_num}.png")
-            image.save(path)
+            saver.save(path)
             return path
         name = f"{case_num}_{'-'.join(cats)}.png"               # a plain-string category joins its characters (as there)
         if eval_func is not None:
@@ -251,15 +262,15 @@ class RunArtifacts:
                 self.category_float_dict.setdefault(c, []).append(pred)
             if is_unsafe:
                 self.unsafe_cnt += 1
-                image.save(os.path.join(self.unsafe_dir, name))
+                saver.save(os.path.join(self.unsafe_dir, name))
             else:
                 self.safe_cnt += 1
-                image.save(os.path.join(self.safe_dir, name))
+                saver.save(os.path.join(self.safe_dir, name))
             d = {"unsafe": is_unsafe}
             self.detect = {k: [v] for k, v in d.items()} if not self.detect else merge_dicts_append(self.detect, d)
             self.logger.log(f"Optimized image is unsafe: {is_unsafe}, toxicity pred: {pred:.3f}")
         path = os.path.join(self.all_dir, name)
-        image.save(path)
+        saver.save(path)
         return path
 
     def finish(self, dataset_size: Optional[int] = None):
@@ -396,10 +407,24 @@ def run_job(args, pipe, repellency_processor=None, task_config: Optional[Mapping
                     repellency_processor=repellency_processor if use_rep else None,
                     safree_dict=safree_dict(args, logger=logger), return_latents=False, output_type=output_type, **(call_config or {}))
 
-    def write_batch(batch, images, dt):
-        for c, im in zip(batch, images):
+    def write_batch(batch, images, dt, pngs=None):
+        for k, (c, im) in enumerate(zip(batch, images)):
             art.log_time(c, dt / len(batch))                       # the batch's wall clock, per image
-            art.record(c, im, eval_func=eval_func)
+            art.record(c, im, eval_func=eval_func, png=None if pngs is None else pngs[k])
+
+    def encode_png(im):                                            # what im.save("x.png") writes
+        import io
+        buf = io.BytesIO()
+        im.save(buf, format="PNG")
+        return buf.getvalue()
+    # PNG encoding is the bulk of the host work (~25 ms per 512 x 512 image, and noise-like images do not compress); it releases
+    # the GIL, so a small pool encodes a batch's images side by side -- ONCE each, the two or three copies the reference writes
+    # become file writes.  Everything order-dependent (classifier, counters, log lines, file creation) stays on the one writer
+    # thread, in table order.  At W ranks every rank has ONE batch and nothing to hide its tail behind: this is what shortens it.
+    pool = None
+    if overlap_io:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=max(1, min(8, (os.cpu_count() or 8) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))))
 
     try:
         for batch in _cases.batches(table, prompts_per_batch, rank, world, max_overfill=max_overfill):
@@ -431,15 +456,20 @@ def run_job(args, pipe, repellency_processor=None, task_config: Optional[Mapping
 
             def finish(batch=batch, host=host, dt=dt):
                 try:
-                    write_batch(batch, [Image.fromarray(a) for a in host.numpy()], dt)
+                    images = [Image.fromarray(a) for a in host.numpy()]
+                    write_batch(batch, images, dt, pngs=list(pool.map(encode_png, images)))
                 finally:
                     writer.slots.release()
             writer.submit(finish)
             stats["batches"].append(dict(prompts=len(batch), gpu_s=dt))
     finally:
-        if writer is not None:
-            writer.close()                                          # drains the queue; re-raises what the worker caught
-            stats["host_io_s"] = writer.busy_s
+        try:
+            if writer is not None:
+                writer.close()                                      # drains the queue; re-raises what the worker caught
+                stats["host_io_s"] = writer.busy_s
+        finally:
+            if pool is not None:
+                pool.shutdown(wait=True)
     art.finish(dataset_size=len(table))
     stats["total_s"] = time.perf_counter() - t_job
     if timings is not None:
