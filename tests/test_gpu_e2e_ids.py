@@ -123,8 +123,8 @@ def test_token_ids_to_latents_against_the_fp32_chain_in_every_precision_mode(tmp
         u.load_state_dict(usd)
         enc = CLIPTextModel(**kw)
         enc.load_state_dict(csd)
-        if name in ("bf16x3", "fp16"):
-            kept[name] = (u, enc)                                   # the scheduled mode below runs on these two plans
+        if name in ("fp32", "bf16x3", "fp16"):
+            kept[name] = (u, enc)                                   # the scheduled mode below runs on the last two; fp32 = its device-generator truth
         proc = thr.get_repellency_method("kernel_fast", torch.zeros(1, device="cuda"), None, None, 50, 1000, 0.00085, 0.012, n_embed=4,
                                          proj_ref_path=path, cache_proj_ref=True, **PARAMS)
         per_mode = {}
@@ -177,7 +177,22 @@ def test_token_ids_to_latents_against_the_fp32_chain_in_every_precision_mode(tmp
     print(f"ids -> latents, fp16 + bf16x3 on the {sched['precise_steps']} window steps: decisions agree on "
           f"{sum(m and b for m, b in zip(sched['mask_equal'], sched['beta_adjusted_equal']))}/{P} prompts; latents rel L2 max "
           f"{max(sched['latents_rel_l2']):.2e}; all prompts {['%.1e' % e for e in sched['latents_rel_l2']]}")
-    del pipe, kept
+    # ---- the same mode as PRODUCTION runs it: per-prompt device generators (no tapes), the sync-free window (no is_negation
+    # readback: rng.BatchedNormal.draw_flagged), against the engine's fp32 plans on the same seeds (themselves 3e-5 from the oracle
+    # chain above).  This is the configuration bench.py's `e2e_scheduled` times.
+    gens = lambda: [torch.Generator(device="cuda").manual_seed(1000 + p) for p in range(P)]
+    call = lambda pp: pp(PROMPTS, num_inference_steps=STEPS, guidance_scale=7.5, negative_prompt=", ".join(NEG_SPACE), negative_prompt_space=NEG_SPACE,
+                         repellency_processor=proc, safree_dict=SF, generator=gens(), return_latents=True)
+    p32 = SafeDenoiserPipeline(kept["fp32"][0], DDPMScheduler(), variant="threshold_time", text_encoder=kept["fp32"][1], tokenizer=tok)
+    lat32 = call(p32)
+    draws32 = p32.last_stats["renoise_draws"]
+    lat_s = call(pipe)
+    sched["device_generators"] = {"latents_rel_l2_vs_fp32_plans": [rel_l2(lat_s[p:p + 1], lat32[p:p + 1]) for p in range(P)],
+                                  "renoise_draws_equal": pipe.last_stats["renoise_draws"] == draws32,
+                                  "window_readbacks": pipe.last_stats["window_readbacks"]}
+    print(f"the same with device generators and the sync-free window: latents rel L2 vs the fp32 plans max "
+          f"{max(sched['device_generators']['latents_rel_l2_vs_fp32_plans']):.2e}, draws equal {sched['device_generators']['renoise_draws_equal']}")
+    del pipe, kept, p32
     torch.cuda.empty_cache()
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
@@ -200,3 +215,5 @@ def test_token_ids_to_latents_against_the_fp32_chain_in_every_precision_mode(tmp
     assert sched["precise_steps"] == 11
     assert all(sched["mask_equal"]) and all(sched["beta_adjusted_equal"]) and sched["renoise_draws_equal"], sched
     assert max(sched["latents_rel_l2"]) <= SCHEDULED_BOUND, sched["latents_rel_l2"]
+    dg = sched["device_generators"]
+    assert dg["window_readbacks"] == 0 and dg["renoise_draws_equal"] and max(dg["latents_rel_l2_vs_fp32_plans"]) <= SCHEDULED_BOUND, dg
