@@ -85,9 +85,13 @@ def test_from_pretrained_then_the_reference_call_site_returns_pil_images(tmp_pat
     # the same stack built by hand from the same state dicts gives the same image, bit for bit
     u = UNet2DConditionModel(text_len=77, latent_repeat=3, **SMALL); u.load_state_dict(usd)
     v = AutoencoderKL(**VAE_CFG); v.load_state_dict(vsd)
-    c = CLIPTextModel(dtype=torch.bfloat16, **CLIP_CFG); c.load_state_dict(csd)
+    assert pipe.text_encoder.precision == "bf16x3"                   # the default in every mode: its output feeds categorical decisions
+    c = CLIPTextModel(precision="bf16x3", **CLIP_CFG); c.load_state_dict(csd)
     direct = SafeDenoiserPipeline(u, DDPMScheduler(), variant="threshold_time", vae=v, text_encoder=c, tokenizer=tok)
     assert np.array_equal(np.asarray(call(direct)[0]), np.asarray(imgs[0]))
+    legacy = SafeDenoiserPipeline.from_pretrained(root, scheduler=scheduler, torch_dtype=torch.bfloat16, latent_repeat=3, tokenizer=tok,
+                                                  text_encoder_precision=None)
+    assert legacy.text_encoder.precision is None and legacy.text_encoder.dtype == torch.bfloat16
     # what the call surface rejects instead of silently dropping
     with pytest.raises(NotImplementedError):
         pipe(target_prompt, num_images_per_prompt=2, num_inference_steps=2)
