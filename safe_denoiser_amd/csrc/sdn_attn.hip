@@ -110,7 +110,12 @@ k_attn(const AttnArgs a) {
   // subtraction, no running maximum.  p <= 2^15 is checked afterwards through the row sum (sum >= p); a workgroup with a query
   // outside [2^-10, 2^15] re-runs its block with the guarded (running-maximum) loop.
   constexpr bool CENTRED = T::kDtype == 1 && !SEG && !MASK && DMA && (KQ * 16 > HD);
-  constexpr bool QSCALED = OFFSET_FREE || CENTRED;
+  // The other unmasked fp16 instances (d = 64 / 80 / 160: no free column) take the same idea with the subtraction spelled out:
+  // p = 2^(s - m0), one v_sub per score (what the classic form's FMA cost) but no running maximum (16 v_max3, a cross-half swap, two
+  // ballots and the conditional rescale per query set and tile), checked and re-run the same way.  MMDiT's joint attention
+  // (d = 64, 18-38 % of the SD-v3 forward) is bound by vector issue: 640 vs 512 cycles per 64-key tile and query set.
+  constexpr bool CENTRED_SUB = T::kDtype == 1 && !MASK && !CENTRED;
+  constexpr bool QSCALED = OFFSET_FREE || CENTRED || CENTRED_SUB;
   static_assert(!CENTRED || ((HD % 32) != 0 && HD - 16 * (KQ - 1) == 8), "centred form: row sums by the ones column, column HD = element 0 of the h = 1 lanes");
   constexpr int CH = HD / 8;                  // valid 16-B chunks per K / V row
   // Single-buffer inputs (DMA): K/V tiles arrive by LDS-DMA (buffer_load ... lds, 16 B per lane, one linear 1-KiB
@@ -426,7 +431,7 @@ k_attn(const AttnArgs a) {
     for (int qs = 0; qs < QS; ++qs) {
     [[maybe_unused]] float mx = 0.f;
     bool need_mx = safe;                           // (a compile-time constant except in the centred fp16 pass: its first tile only)
-    if constexpr (CENTRED && !safe) need_mx = t == 0;
+    if constexpr ((CENTRED || CENTRED_SUB) && !safe) need_mx = t == 0;
     if (need_mx) {
     mx = fmaxf(st[qs][0][0], st[qs][1][0]);
 #pragma unroll
@@ -474,30 +479,34 @@ k_attn(const AttnArgs a) {
       for (int i = 0; i < 16; ++i) ps += st[qs][0][i] + st[qs][1][i];
       l_run[qs] += ps;
     }
-    } else if constexpr (CENTRED) {
+    } else if constexpr (CENTRED || CENTRED_SUB) {
     if constexpr (!safe) {
       if (t == 0) {
         // the offset is the first tile's maximum ROUNDED to the storage type: tile 0 subtracts exactly what the MFMA will
-        // subtract for the later tiles (column HD: K reads 1.0, Q holds -off)
+        // subtract for the later tiles (CENTRED -- column HD: K reads 1.0, Q holds -off)
         const unsigned o16 = T::pack2(mx, 0.f) & 0xffffu;
         const float off = T::to_f(o16);
         m_run[qs] = off;
+        if constexpr (CENTRED) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+          for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-          for (int i = 0; i < 16; ++i) st[qs][kb][i] -= off;
-        u32x4 v = *reinterpret_cast<u32x4*>(&qf[qs][KQ - 1]);
-        if (h == 1) v.x = (v.x & 0xffff0000u) | (o16 ^ 0x8000u);      // -off: the sign bit of the 16-bit pattern
-        qf[qs][KQ - 1] = *reinterpret_cast<typename T::v8*>(&v);
+            for (int i = 0; i < 16; ++i) st[qs][kb][i] -= off;
+          u32x4 v = *reinterpret_cast<u32x4*>(&qf[qs][KQ - 1]);
+          if (h == 1) v.x = (v.x & 0xffff0000u) | (o16 ^ 0x8000u);      // -off: the sign bit of the 16-bit pattern
+          qf[qs][KQ - 1] = *reinterpret_cast<typename T::v8*>(&v);
+        }
       }
+      const float sub = CENTRED_SUB ? m_run[qs] : 0.f;                  // no free column: the subtraction per score, every tile
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) st[qs][kb][i] = __builtin_amdgcn_exp2f(st[qs][kb][i]);
+        for (int i = 0; i < 16; ++i) st[qs][kb][i] = __builtin_amdgcn_exp2f(CENTRED_SUB ? st[qs][kb][i] - sub : st[qs][kb][i]);
     } else {                                        // guarded re-run: running maximum on the pre-scaled scores (column HD of Q is 0)
       const float m_new = fmaxf(m_run[qs], mx);
       if (__builtin_amdgcn_ballot_w64(m_new != m_run[qs]) != 0) {            // wave-uniform: rescale only when needed
         const float alpha = __builtin_amdgcn_exp2f(m_run[qs] - m_new);
+        if (!ONES) l_run[qs] *= alpha;
 #pragma unroll
         for (int d = 0; d < NDB; ++d)
 #pragma unroll
@@ -508,6 +517,12 @@ k_attn(const AttnArgs a) {
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int i = 0; i < 16; ++i) st[qs][kb][i] = __builtin_amdgcn_exp2f(st[qs][kb][i] - m_new);
+    }
+    if (!ONES) {
+      float ps = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) ps += st[qs][0][i] + st[qs][1][i];
+      l_run[qs] += ps;
     }
     } else {                                          // fp16: classic running-max form (fp16 P needs p <= 1)
     const float m_new = fmaxf(m_run[qs], mx);
@@ -637,13 +652,13 @@ k_attn(const AttnArgs a) {
     } else {
       l_tot[qs] = l_run[qs] + __shfl_xor(l_run[qs], 32, 64);  // both halves hold partial sums of the same query
     }
-    if constexpr (CENTRED) bad |= !(l_tot[qs] >= 0x1p-10f && l_tot[qs] <= 0x1p15f);   // every p <= sum <= 2^15 < fp16's maximum
+    if constexpr (CENTRED || CENTRED_SUB) bad |= !(l_tot[qs] >= 0x1p-10f && l_tot[qs] <= 0x1p15f);   // every p <= sum <= 2^15 < fp16's maximum
     else bad |= !(l_tot[qs] >= 0x1p-64f && l_tot[qs] <= 0x1p64f);
   }
   return bad;
   };   // run_pass
   bool rerun = true;
-  if constexpr (OFFSET_FREE || CENTRED) {
+  if constexpr (OFFSET_FREE || CENTRED || CENTRED_SUB) {
     if (a.nomax) {
       const bool bad = run_pass(std::false_type{});
       if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) *reinterpret_cast<volatile unsigned*>(smem + ZOFF + 32) = 1u;
