@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 from safe_denoiser_amd.clip import CLIPTextModel  # noqa: E402
 from safe_denoiser_amd.pipeline import SafeDenoiserPipeline  # noqa: E402
 from safe_denoiser_amd.repellency import repellency_methods_threshold as thr  # noqa: E402
-from safe_denoiser_amd.schedulers import DDPMScheduler  # noqa: E402
+from safe_denoiser_amd.schedulers import DDIMScheduler, DDPMScheduler  # noqa: E402
 from safe_denoiser_amd.unet import UNet2DConditionModel  # noqa: E402
 from tests_support.fake_tokenizer import FakeCLIPTokenizer  # noqa: E402
 from tests_support.e2e_case import NEG_SPACE, PARAMS, PROMPTS, SF, STEPS, Tapes, make_refs  # noqa: E402
@@ -47,8 +47,10 @@ def main():
     ap.add_argument("--quick", action="store_true", help="every 5th sensitivity arm only")
     ap.add_argument("--verify", action="store_true", help="another weight seed: the two baselines and the candidate schedules only")
     ap.add_argument("--lo", default="f16", choices=["f16", "bf16"])
+    ap.add_argument("--scheduler", default="ddpm", choices=["ddpm", "ddim"], help="ddpm = the reference's live scheduler; ddim = the one BASELINE names")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "round5_precision_schedule"))
     a = ap.parse_args()
+    Sched = DDPMScheduler if a.scheduler == "ddpm" else DDIMScheduler
     t00 = time.time()
     P = len(PROMPTS)
     tok = FakeCLIPTokenizer()
@@ -83,7 +85,7 @@ def main():
 
     # ---- truth: the engine's fp32 plans
     u32, e32 = unet(precision="fp32"), clip(precision="fp32")
-    truth, st_truth = call(SafeDenoiserPipeline(u32, DDPMScheduler(), variant="threshold_time", text_encoder=e32, tokenizer=tok))
+    truth, st_truth = call(SafeDenoiserPipeline(u32, Sched(), variant="threshold_time", text_encoder=e32, tokenizer=tok))
     del u32, e32
     torch.cuda.empty_cache()
     print(f"[{time.time() - t00:6.0f} s] truth (fp32 plans): {st_truth}", flush=True)
@@ -91,12 +93,12 @@ def main():
     u_lo = unet(dtype=torch.float16 if a.lo == "f16" else torch.bfloat16)
     u_hi = unet(precision="bf16x3")
     e_hi = clip(precision="bf16x3")
-    sch = DDPMScheduler()
+    sch = Sched()
     sch.set_timesteps(STEPS)
     timesteps = [int(t) for t in sch.timesteps]
 
     def arm(name, spec):
-        pipe = SafeDenoiserPipeline(u_lo, DDPMScheduler(), variant="threshold_time", text_encoder=e_hi, tokenizer=tok, unet_hi=u_hi,
+        pipe = SafeDenoiserPipeline(u_lo, Sched(), variant="threshold_time", text_encoder=e_hi, tokenizer=tok, unet_hi=u_hi,
                                     precision_schedule=spec)
         lat, st = call(pipe)
         per = [rel(lat[p], truth[p]) for p in range(P)]
@@ -108,7 +110,7 @@ def main():
               f"decisions {'=' if r['decisions_equal'] else 'DIFFER'} draws {'=' if r['draws_equal'] else 'DIFFER'}  ({st['seconds']} s)", flush=True)
         return r, lat
 
-    res = dict(what=__doc__.split("\n\n")[0], seed=a.seed, lo=a.lo, ratio=a.ratio, timesteps=timesteps, truth=st_truth, arms=[])
+    res = dict(what=__doc__.split("\n\n")[0], seed=a.seed, lo=a.lo, scheduler=a.scheduler, ratio=a.ratio, timesteps=timesteps, truth=st_truth, arms=[])
     r_all, lat_all = arm("all bf16x3", "all")
     r_none, lat_none = arm(f"all {a.lo}", "none")
     res["arms"] += [r_all, r_none]
@@ -121,7 +123,7 @@ def main():
         os.makedirs(os.path.dirname(a.out), exist_ok=True)
         json.dump(res, open(a.out + ".json", "w"), indent=1)
         with open(a.out + ".md", "w") as f:
-            f.write(f"# Precision schedules on another weight seed ({a.seed}; 16-bit plan = {a.lo})\n\n| arm | precise steps | cost | worst rel L2 | "
+            f.write(f"# Precision schedules, verification arms (weight seed {a.seed}; 16-bit plan = {a.lo}; scheduler = {a.scheduler})\n\n| arm | precise steps | cost | worst rel L2 | "
                     f"decisions / draws equal |\n|---|---|---|---|---|\n")
             for r in res["arms"]:
                 f.write(f"| {r['name']} | {r['hi_steps']} | x{r['cost_vs_16bit']:.2f} | {r['worst']:.2e} | "
