@@ -24,6 +24,9 @@ for rnd in range(3):
         elif os.environ.get("FFNSTATS") == "1":                  # second arm = norm3's row statistics by the sdn_row_stats pre-pass
             import ctypes as C
             sda.lib().sdn_debug_set_ffn_own_stats(C.c_void_p(u._h.value), 0 if v else 1)
+        elif os.environ.get("LNPRE") == "1":                     # second arm = every folded LayerNorm's row statistics from the pre-pass (LNF = 2 kernels)
+            import ctypes as C
+            sda.lib().sdn_debug_set_ln_prepass_all(C.c_void_p(u._h.value), 1 if v else 0)
         elif TEXTVER:
             u.set_text_version(5 if v else 0)
         else:
