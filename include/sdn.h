@@ -214,7 +214,14 @@ typedef struct sdn_gemm_desc {
   int32_t x3_out;           /* sdn_gemm_bf16 inside the bf16x3 plan (see "bf16x3 by operand expansion" below): 0 = off;
                                1 = out is F32 [M, ldc]; 2 = GEGLU, out is a bf16 triple [M, 3 ldc]; 3 = out is a bf16 triple;
                                4 = out is a bf16 hi | lo PAIR [M, 2 ldc] (the operand form of sdn_attention_x3_pairs).
-                               With any of them `residual` is F32 [M, ldc] and out_kind is ignored                        */
+                               With any of them `residual` is F32 [M, ldc] and out_kind is ignored.
+                               5 = EXPERIMENTAL (round 5, sdn_gemm_f16 only, plain A, no activation): the "h8" operand form -- rows of
+                               4 bytes per element, A' = [fp16(a) | e4m3(2^11 (a - fp16(a))) | e4m3(a)], W' = [fp16(w) | e4m3(w) |
+                               e4m3(2^11 (w - fp16(w)))] (OCP e4m3), K = 2 x the logical K (the row length in 16-bit units; logical
+                               K % 128 == 0), out = F32 [M, ldc]: an fp16 main term plus two correction products on the scaled fp8
+                               matrix instruction, f32 accumulation throughout (1.2e-5 ... 2.2e-5 from float64 per
+                               GEMM against fp16's 2.9e-4 and bf16x3's 4.5e-6).  256-row tiles only (N % 256 == 0 or N % 320 == 0
+                               with >= 192 tiles); not used by any plan yet                                                   */
 } sdn_gemm_desc;
 
 /* out = act((A.W^T + bias[n] + rowbias[b(m), n]) * rowgate[b(m), n] + residual[m, n])   (rowgate NULL = 1).

@@ -46,9 +46,10 @@ namespace sdn_gemm_detail {
 // LNF = 1: row statistics from the fragments (right for narrow N: every n-tile repeats that VALU work -- at N = 8C it
 // costs more than the LayerNorm kernel it replaces); LNF = 2: statistics read from g.ln_stats [M][2] = (mean, rstd),
 // written by a read-only pre-pass (sdn_row_stats_*), for wide N.
-template <typename T, int NREP, int WGM, int NSTAGE, int LNF = 0>
-__global__ void __launch_bounds__(128 * WGM, NSTAGE > 2 ? 1 : 2)
-k_gemm_dma(const GemmArgs g) {
+// (H8 = the experimental operand form of DESIGN 10.12; it lives in its OWN kernel symbol, k_gemm_h8, so that the production
+//  instances keep their code and registers -- sharing one body cost the fp16 instances 600 spilled registers)
+template <typename T, int NREP, int WGM, int NSTAGE, int LNF, bool H8>
+__device__ __forceinline__ void gemm_dma_body(const GemmArgs& g) {
 #if defined(__HIP_DEVICE_COMPILE__)
   SDN_STAMP(0)
   constexpr int BM = 64 * WGM, THREADS = 128 * WGM, NWAVES = 2 * WGM;
@@ -305,7 +306,7 @@ k_gemm_dma(const GemmArgs g) {
       ln_mu[i] = st2.x; ln_rs[i] = st2.y;
     }
   }
-  for (int kt = 0; kt < nk; ++kt) {
+  auto k_iter = [&](const int kt, auto f8_c) __attribute__((always_inline)) {
     const int buf = kt & (NSTAGE - 1);
     // WHERE the next k-tile's DMA is issued.  At the top of the iteration both waves of a SIMD come out of the barrier and spend
     // their first ~1 k cycles issuing 9 DMA pieces each (100-185 cycles apiece next to fragment reads; the conv form adds a
@@ -335,7 +336,51 @@ k_gemm_dma(const GemmArgs g) {
 #else
     constexpr bool kFragPipe = WGM == 4 && (NREP == 10 || NREP == 8) && LNF != 1;
 #endif
+    // Experimental h8 operand form: k-tiles past g.h8_t16 hold e4m3 bytes -- 128 per row, the byte geometry of a
+    // 16-bit k-tile, so DMA, LDS image and fragment reads are the 16-bit ones -- and one scaled fp8 MFMA (K = 128) per fragment
+    // pair replaces the two 16-bit MFMAs: the fragment of k-step 0 and of k-step 1 of a row are the lane's 32 operand bytes
+    // (any split of K over the lanes is a valid contraction as long as both operands agree).  Segment 1 = 2^11 lo(a) x q(w): the
+    // activation operand carries the block scale 2^-11; segment 2 = q(a) x 2^11 lo(w): the weight operand does.
+    constexpr bool f8_tile = decltype(f8_c)::value;          // (H8 only; the two kinds of k-tile run in two loops: see below)
+    if constexpr (H8 && f8_tile) {
+      {
+        typedef __attribute__((ext_vector_type(8))) int i32x8;
+        union F8 { typename T::v8 h[2]; i32x8 v; };
+        const bool seg1 = kt < g.h8_t16 + (nk - g.h8_t16) / 2;
+        const int s_act = seg1 ? 0x74747474 : 0x7f7f7f7f, s_w = seg1 ? 0x7f7f7f7f : 0x74747474;     // e8m0: 0x74 = 2^-11, 0x7f = 1
+        // fragment reads two W fragments ahead of the MFMAs that use them; the scheduler is fenced (left alone it requested six W
+        // fragments at once and spilled accumulators and the DMA address registers: a scratch reload + vmcnt(0) before every piece)
+        F8 av[4], wv[3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          av[i].h[0] = *reinterpret_cast<const typename T::v8*>(sa + lds_off(i * 16 + fr, fq));
+          av[i].h[1] = *reinterpret_cast<const typename T::v8*>(sa + lds_off(i * 16 + fr, 4 + fq));
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          wv[j].h[0] = *reinterpret_cast<const typename T::v8*>(sw + lds_off(j * 16 + fr, fq));
+          wv[j].h[1] = *reinterpret_cast<const typename T::v8*>(sw + lds_off(j * 16 + fr, 4 + fq));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) {
+          if (j + 2 < NREP) {
+            wv[(j + 2) % 3].h[0] = *reinterpret_cast<const typename T::v8*>(sw + lds_off((j + 2) * 16 + fr, fq));
+            wv[(j + 2) % 3].h[1] = *reinterpret_cast<const typename T::v8*>(sw + lds_off((j + 2) * 16 + fr, 4 + fq));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wv[j % 3].v, av[i].v, acc[i][j], 0, 0, 0, s_w, 0, s_act);
+          __builtin_amdgcn_s_setprio(0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (j == NREP / 2 - 1 && more && ipos != 0) issue((kt + 1) & 1);
+        }
+      }
+    }
     if constexpr (kFragPipe) {
+      if constexpr (!f8_tile) {
       // 256 x 320 tile: the W fragments of a k-step are consumed in 5 groups of 2 (8 MFMAs = 128 matrix-pipe cycles each),
       // and group g+1's two ds_reads are ISSUED BEFORE group g's MFMAs (two alternating 2-fragment buffers; the second
       // k-step's A fragments ride along early), so no MFMA group starts behind a fresh LDS round trip.  Left to the
@@ -367,6 +412,7 @@ k_gemm_dma(const GemmArgs g) {
         __builtin_amdgcn_s_setprio(0);
         if (gi == 2 && more) { if (ipos == 1) issue((kt + 1) & 1); else if (ipos == 4) issue_aw((kt + 1) & 1, false); }
         if (gi == G - 1 && more) { if (ipos == 2) issue((kt + 1) & 1); else if (ipos == 4) issue_w_only((kt + 1) & 1); }
+      }
       }
     } else {
 #pragma unroll
@@ -414,6 +460,13 @@ k_gemm_dma(const GemmArgs g) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this tile's fragment reads are done before its buffer is refilled
       __builtin_amdgcn_s_barrier();
     }
+    };
+  if constexpr (H8) {
+    // two loops over one skeleton: each kind of k-tile gets its own register allocation (one loop with a run-time switch spilled 517)
+    for (int kt = 0; kt < g.h8_t16; ++kt) k_iter(kt, std::false_type{});
+    for (int kt = g.h8_t16; kt < nk; ++kt) k_iter(kt, std::true_type{});
+  } else {
+    for (int kt = 0; kt < nk; ++kt) k_iter(kt, std::false_type{});
   }
 
   SDN_STAMP(2)
@@ -461,6 +514,14 @@ k_gemm_dma(const GemmArgs g) {
   SDN_STAMP(3)
 #endif  // __HIP_DEVICE_COMPILE__
 }
+
+template <typename T, int NREP, int WGM, int NSTAGE, int LNF = 0>
+__global__ void __launch_bounds__(128 * WGM, NSTAGE > 2 ? 1 : 2)
+k_gemm_dma(const GemmArgs g) { gemm_dma_body<T, NREP, WGM, NSTAGE, LNF, false>(g); }
+
+template <typename T, int NREP>
+__global__ void __launch_bounds__(512, 2)
+k_gemm_h8(const GemmArgs g) { gemm_dma_body<T, NREP, 4, 2, 0, true>(g); }
 
 
 // ---- split-K (small M, long K: the 8x8 / 16x16-level convs of a one-prompt batch have 8-20 tiles for 256 CUs and a
@@ -524,6 +585,17 @@ int launch_dma(const GemmArgs& ga, hipStream_t st) {
 
 template <typename T>
 int dispatch_dma(int nrep, const GemmArgs& g, hipStream_t st) {
+  if (g.h8_t16 > 0) {                                         // experimental h8 operand form: its own symbol, 256-row tiles only
+    if constexpr (T::kDtype == 1) {
+      const int grid = g.tiles_m * g.tiles_n;
+      if (nrep == 10) hipLaunchKernelGGL((k_gemm_h8<T, 10>), dim3(grid), dim3(512), 0, st, g);
+      else if (nrep == 8) hipLaunchKernelGGL((k_gemm_h8<T, 8>), dim3(grid), dim3(512), 0, st, g);
+      else return SDN_E_INVALID;
+      return sdn_launch_status();
+    } else {
+      return SDN_E_INVALID;
+    }
+  }
   if (g.ln_c && g.ln_stats) {                                // LayerNorm-folded form, row statistics from the pre-pass
     switch (nrep) {
       case 10: return launch_dma<T, 10, 4, 2, 2>(g, st);
@@ -626,7 +698,10 @@ static int sdn_gemm_impl(int dtype, const sdn_gemm_desc* d, const void* a, const
   if (n_valid > d->N) return SDN_E_INVALID;
   if (sdn_gemm_pick_nrep(d->N, d->act) == 0) return SDN_E_INVALID;
   const int x3 = d->x3_out;
-  if (x3 < 0 || x3 > 4 || (x3 && (dtype != 0 || rowgate || d->split_k > 1 || partials || ln_c || col_stats || n_valid != d->N)))
+  const bool h8 = x3 == 5;                                  // experimental: fp16 + e4m3 corrections by operand expansion
+  if (x3 < 0 || x3 > 5 || (x3 && ((dtype != 0) != h8 || rowgate || d->split_k > 1 || partials || ln_c || col_stats || n_valid != d->N)))
+    return SDN_E_INVALID;
+  if (h8 && (d->a_mode != SDN_A_PLAIN || d->act != SDN_ACT_NONE || (d->K % 256) != 0 || d->res_pre || (d->K1 > 0 && d->K1 < d->K)))
     return SDN_E_INVALID;
   if (x3 && ((x3 == 2) != (d->act == SDN_ACT_GEGLU) || (x3 != 2 && d->act != SDN_ACT_NONE) || (residual && !al16(residual)) || !al16(out)))
     return SDN_E_INVALID;
@@ -637,6 +712,10 @@ static int sdn_gemm_impl(int dtype, const sdn_gemm_desc* d, const void* a, const
                        d->out_kind == SDN_OUT_BF16 && n_valid == d->N && d->act == SDN_ACT_NONE;
   int nrep = sdn_gemm_pick_tile(d->M, d->N, d->K, d->act, ((residual && !x3 && !res_pre) || rowgate) ? 1 : 0);
   if ((ln_c || ln_d) && nrep == 8 && d->N % 320 == 0) nrep = 10;          // (the LayerNorm-folded forms have no 256-wide instantiation)
+  if (h8) {                                                                // the fp8 k-tiles exist on the 256-row tiles only; the 256-wide
+    if (d->N % 256 == 0) nrep = 8;                                         // one holds its fp8 body in registers (the 320-wide one spills
+    else if (nrep < 8) return SDN_E_INVALID;                               // ~100 of them: measured, slower), so it is taken where it divides N
+  }
   if (!al16(a) || !al16(w) || (a2 && !al16(a2)) || (residual && (reinterpret_cast<uintptr_t>(residual) & 7)) ||
       (reinterpret_cast<uintptr_t>(out) & 7) || (bias && !al16(bias)) || (rowbias && !al16(rowbias)))
     return SDN_E_INVALID;
@@ -667,7 +746,8 @@ static int sdn_gemm_impl(int dtype, const sdn_gemm_desc* d, const void* a, const
     return SDN_E_INVALID;
   if ((rowbias || rowgate || d->residual_bcast || d->out_kind == SDN_OUT_F32_NCHW) && d->rows_per_batch <= 0) return SDN_E_INVALID;
   if (rowgate && !al16(rowgate)) return SDN_E_INVALID;
-  g.x3_out = x3;
+  g.x3_out = h8 ? 1 : x3;                                    // (h8: f32 rows straight from the accumulators, as x3_out = 1)
+  g.h8_t16 = h8 ? d->K / 128 : 0;                            // d->K counts 16-bit units of the 4-byte-per-element row: half of it is fp16
   g.act = d->act; g.out_kind = x3 ? SDN_OUT_F32 : d->out_kind; g.rows_per_batch = d->rows_per_batch; g.ld_rowbias = d->ld_rowbias;
   g.ld_rowgate = d->ld_rowgate; g.residual_bcast = d->residual_bcast;
   g.n_valid = n_valid;

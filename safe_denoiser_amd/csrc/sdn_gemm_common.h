@@ -32,6 +32,8 @@ struct GemmArgs {
   int x3_out;                // bf16x3 plan (operands = bf16 hi|lo|hi triples, K = 3 x the logical K; sdn_gemm_x3t): the residual is F32
                              // [M, ldc], added into the accumulators before the k loop, and the output goes straight from the
                              // registers to global memory: 1 = f32 [M, ldc]; 2 = GEGLU, triple [M, 3 ldc]; 3 = triple [M, 3 ldc]
+  int h8_t16;                // experimental "h8" operand form (sdn_gemm_desc.x3_out = 5, fp16 instance): the first h8_t16 k-tiles are fp16,
+                             // the rest are e4m3 bytes in two equal segments (corrections); 0 = off
   unsigned long long* stamps; // diagnostics: 8 s_memtime stamp slots per workgroup (tools/gemm_stamps.py); nullptr in production
   int dbg;                   // timing-only ablations (tools/bench_gemm.py): 1 = no global stores, 2 = DMA only for k-tile 0
 };

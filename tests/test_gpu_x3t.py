@@ -201,3 +201,39 @@ def test_cross_attention_on_presplit_pairs_against_float64(B, Nq, Nk, d):
     out = ops.cross_attention_x3_pairs(qp, kvp, H)
     assert torch.isfinite(out).all()
     assert rel_l2(out, ref) <= TOL, rel_l2(out, ref)
+
+
+@pytest.mark.parametrize("M,N,K", [(49152, 1280, 1280), (24576, 2560, 640), (61440, 640, 512)])
+def test_experimental_h8_operand_form_against_float64(M, N, K):
+    """sdn_gemm_desc.x3_out = 5 (EXPERIMENTAL): rows [fp16(a) | e4m3(2^11 lo(a)) | e4m3(a)] against
+    [fp16(w) | e4m3(w) | e4m3(2^11 lo(w))] -- an fp16 main term plus two correction products on v_mfma_scale_f32_16x16x128_f8f6f4 with
+    the 2^-11 in the instruction's block scale, f32 accumulation into one set of accumulators.  Against float64 on activations with
+    outlier channels: <= 4e-5 (measured 1.2e-5 ... 2.2e-5; the fp16 GEMM alone: 2.9e-4), i.e. the corrections really land, with the
+    right scale, in both tile widths (N % 256 == 0 -> 256-wide, else 320-wide); what the form does not cover is refused."""
+    import ctypes as C
+    import safe_denoiser_amd as sda
+    from safe_denoiser_amd import _lib
+    g = torch.Generator(device="cuda").manual_seed(3)
+    a = torch.randn(M, K, device="cuda", generator=g)
+    a[:, ::64] *= 12.0
+    w = torch.randn(N, K, device="cuda", generator=g) * K ** -0.5
+    ah, wh = a.half(), w.half()
+    q = lambda x: x.to(torch.float8_e4m3fn).view(torch.uint8)
+    a8 = torch.cat([ah.view(torch.uint8), q((a - ah.float()) * 2048.0), q(ah.float())], dim=1).contiguous()
+    w8 = torch.cat([wh.view(torch.uint8), q(wh.float()), q((w - wh.float()) * 2048.0)], dim=1).contiguous()
+    out = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    d = _lib.GemmDesc()
+    d.M, d.N, d.K, d.out_kind, d.x3_out, d.ldc = M, N, 2 * K, 1, 5, N
+    call = lambda fn, dd: fn(C.byref(dd), a8.data_ptr(), None, w8.data_ptr(), None, None, None, None, out.data_ptr(), _lib.stream_ptr())
+    assert call(sda.lib().sdn_gemm_f16, d) == 0
+    rows = torch.arange(0, M, M // 1024, device="cuda")[:1024]
+    ref = a[rows].double() @ w.double().T
+    r8 = float((out[rows].double() - ref).norm() / ref.norm())
+    r16 = float(((ah[rows].float() @ wh.float().T).double() - ref).norm() / ref.norm())
+    print(f"h8 GEMM {M} x {N} x {K}: rel L2 vs float64 {r8:.2e} (fp16 operands alone {r16:.2e})")
+    assert r8 <= 4e-5 and r16 > 5 * r8
+    assert call(sda.lib().sdn_gemm_bf16, d) != 0                          # the fp16 instance only
+    d.act = 1
+    assert call(sda.lib().sdn_gemm_f16, d) != 0                           # no activation
+    d.act, d.K = 0, 2 * K + 64
+    assert call(sda.lib().sdn_gemm_f16, d) != 0                           # logical K % 128 == 0
