@@ -657,6 +657,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary legs (latent-level b = 2 figure, bf16x3 precision mode, live parity, SD-v3 config 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latent-repeat", action="store_true", help="feed cat([latents] * 2) to a plain UNet plan")
+    ap.add_argument("--no-tail-split", action="store_true",
+                    help="a batch a few prompts over a multiple of 64 samples (e.g. --prompts-per-batch 65) as ONE forward per step (A/B of pipeline.tail_split)")
     args = ap.parse_args()
 
     # N > 1 without a launcher: become the launcher BEFORE anything touches the GPU (no re-exec of a GPU process)
@@ -683,6 +685,7 @@ def main():
     torch.cuda.set_device(dev)
 
     unet, pipe, proc, beta, bcast_ms, comm_ms = build_engine(args, rank, world, dev)
+    pipe.tail_split = not args.no_tail_split
     P = args.prompts_per_batch
     e2e = args.workload == "e2e"
     nb = 3 if e2e else 2
@@ -752,6 +755,7 @@ def main():
             safree_steps += sum(b_ or 0 for b_ in (pipe.last_safree["beta_adjusted"] or []))
     torch.cuda.synchronize()
     dt_mine = time.perf_counter() - t0                                  # this rank's own clock, before the closing barrier
+    tail_split_used = pipe.last_stats.get("tail_split")
     sdist.heartbeat(f"timed region done: {P * args.steps} images in {dt_mine:.1f} s")
     sdist.barrier()
     agg = sdist.throughput_over_ranks(P * args.steps, dt_mine, time.perf_counter() - t0, dev)
@@ -901,7 +905,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": workload, "guidance_branches": nb, "text_encoder_precision": args.text_precision,
-                   "prompts_per_batch": P, "latent_repeat": unet.latent_repeat, "images_timed": n_img, "beta_threshold": beta,
+                   "prompts_per_batch": P, "latent_repeat": unet.latent_repeat, "tail_split": tail_split_used, "images_timed": n_img, "beta_threshold": beta,
                    "renoise_draws_rank0": renoise,
                    "gate": {"r5_calibrated_beta_threshold": r5_beta, "margin": float(proc.beta_threshold_margin),
                             "placement": placement,

@@ -12,6 +12,7 @@ the contractions run on the f32-input matrix cores -- 1/16 of the 16-bit rate, ~
 from __future__ import annotations
 
 import ctypes as C
+import math
 from types import SimpleNamespace
 
 import torch
@@ -81,6 +82,7 @@ class UNet2DConditionModel:
         self._h = h
         self._weights = None
         self._ws = {}
+        self.tail_split = False            # set_tail_split(): see _tail_split_of
         self._read_manifest()
 
     def _read_manifest(self):
@@ -228,6 +230,7 @@ class UNet2DConditionModel:
         """Declare the contents of the text operand of the next forwards (sdn_unet_set_text_version): while the version, the
         batch and the buffers stay the same, the cross-attention K / V projections of the text are not recomputed.  0 = undeclared."""
         _lib.lib().sdn_unet_set_text_version(self._h, int(version))
+        self._text_version = int(version)
         return self
 
     def set_split_k(self, on: bool = True):
@@ -263,12 +266,83 @@ class UNet2DConditionModel:
             raise _lib.SdnError(f"encoder_hidden_states must be [B,{self.text_len},{self.config.cross_attention_dim}]")
         return e.to(self.dtype).contiguous()
 
+    # ---- a few latents over whole waves of tiles: the tail runs beside the main forward ------------------------------------
+    # Every level of the SD-v1.4 plan is a whole number of 256-CU waves of 256-row tiles when the batch is a multiple of 64
+    # samples (64^2 level: 64 x 4096 / 256 = 1024 tiles = 4 waves; 16^2: 64 x 4 = 256 tiles = 1 wave).  A batch a few latents over
+    # such a multiple (8 ranks x 515 prompts: 65 prompts x 3 branches = 195 samples on three of the ranks) starts one more wave in
+    # every GEMM / conv launch for a handful of tiles: 162.6 ms against 152.7 ms for 192 samples, where the work grew 1.6 %
+    # (tools/ab_tail_split.py).  With `tail_split` on, such a forward runs as the aligned part on the caller's stream and the
+    # remaining latents as their own small forward (a second handle over the SAME packed weights) on a side stream, joined before
+    # the outputs are put back in branch-major order: 156.8 ms, bit-identical outputs on the 16-bit plans (rows are independent;
+    # bf16x3: 2e-6, its row chunks differ).  DESIGN 10.13.
+    TAIL_MAX_SAMPLES = 12            # measured: 3 samples -3.6 %, 24 samples -1.4 % of the unsplit forward; above this it stays one batch
+
+    def set_tail_split(self, on: bool = True):
+        self.tail_split = bool(on)
+        return self
+
+    def _tail_split_of(self, b: int):
+        """(latents in the aligned main forward, latents in the tail), or None when the batch runs as one forward."""
+        rep = self.latent_repeat
+        if not getattr(self, "tail_split", False) or rep <= 1 or type(self) is not UNet2DConditionModel:
+            return None
+        p = b // rep
+        q = 64 // math.gcd(64, rep)                                  # latents per 64-sample quantum
+        pm = p // q * q
+        r = p - pm
+        if pm == 0 or r == 0 or r * rep > self.TAIL_MAX_SAMPLES:
+            return None
+        return pm, r
+
+    def _forward_split(self, sample, timestep, text, out, pm, r):
+        rep, dev = self.latent_repeat, sample.device
+        p = pm + r
+        st = getattr(self, "_split", None)
+        if st is None or st["key"] != (p, pm, dev):
+            tail = UNet2DConditionModel(text_len=self.text_len, dtype=self.dtype, latent_repeat=rep,
+                                        precision=self.precision if self.precision in ("fp32", "bf16x3") else None, **vars(self.config))
+            tshape = tuple(text.shape[1:])
+            st = self._split = dict(key=(p, pm, dev), tail=tail, side=torch.cuda.Stream(device=dev), text_key=None,
+                                    tm=torch.empty((rep * pm,) + tshape, dtype=self.dtype, device=dev),
+                                    tt=torch.empty((rep * r,) + tshape, dtype=self.dtype, device=dev),
+                                    ym=torch.empty((rep * pm,) + tuple(out.shape[1:]), dtype=torch.float32, device=dev),
+                                    yt=torch.empty((rep * r,) + tuple(out.shape[1:]), dtype=torch.float32, device=dev))
+        tail = st["tail"]
+        tail._weights = self._weights                                # the derived regions live in the buffer: nothing to prepare again
+        ver = int(getattr(self, "_text_version", 0))
+        tkey = (ver, text.data_ptr())
+        if ver == 0 or st["text_key"] != tkey:                       # branch-major text rows [rep][p] -> [rep][pm] and [rep][r]
+            tv = text.view(rep, p, *text.shape[1:])
+            st["tm"].view(rep, pm, *text.shape[1:]).copy_(tv[:, :pm])
+            st["tt"].view(rep, r, *text.shape[1:]).copy_(tv[:, pm:])
+            st["text_key"] = tkey
+        tail.set_text_version(ver)
+        cur = torch.cuda.current_stream(dev)
+        side = st["side"]
+        side.wait_stream(cur)                                        # latents and text are ready where the caller's stream stands
+        with torch.cuda.stream(side):
+            tail._forward_one(sample[pm:], timestep, st["tt"], st["yt"])
+        self._forward_one(sample[:pm], timestep, st["tm"], st["ym"])
+        cur.wait_stream(side)
+        ov = out.view(rep, p, -1)
+        ov[:, :pm].copy_(st["ym"].view(rep, pm, -1))
+        ov[:, pm:].copy_(st["yt"].view(rep, r, -1))
+        return out
+
     def forward_into(self, sample, timestep, text_bf16, out):
         """No-allocation form used by the engine loop (text already bf16, `out` preallocated fp32).  With latent_repeat = r
         the sample has B / r rows, text and out have B."""
         b = text_bf16.shape[0]
         if sample.shape[0] * self.latent_repeat != b or out.shape[0] != b:
             raise _lib.SdnError(f"batch mismatch: {sample.shape[0]} latents x latent_repeat {self.latent_repeat} vs {b} text rows")
+        split = self._tail_split_of(b)
+        if split is not None:
+            _lib.dptr(sample, torch.float32), _lib.dptr(text_bf16, self.dtype), _lib.dptr(out, torch.float32)     # the loud checks
+            return self._forward_split(sample, timestep, text_bf16, out, *split)
+        return self._forward_one(sample, timestep, text_bf16, out)
+
+    def _forward_one(self, sample, timestep, text_bf16, out):
+        b = text_bf16.shape[0]
         ws = self._workspace(b, sample.device)
         _lib.check(_lib.lib().sdn_unet_forward(self._h, _lib.dptr(self._weights), _lib.dptr(sample, torch.float32),
                                                float(timestep), _lib.dptr(text_bf16, self.dtype),

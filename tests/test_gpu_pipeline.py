@@ -444,3 +444,35 @@ def test_precision_schedule_switches_plans_per_step(world, tmp_path):
     # a later call on the 16-bit plan alone is unaffected by the second plan's text cache (versions are process-wide)
     again, _, _ = run(lo)
     assert torch.equal(again, only_lo)
+
+
+def test_a_batch_a_few_prompts_over_whole_waves_runs_split_and_gives_the_same_latents(world, tmp_path):
+    """65 prompts x 3 branches (what three of the eight ranks of the 515-prompt job run): `pipe.tail_split` (default on) sends the
+    64 aligned prompts and the 65th through the UNet as two concurrent forwards per step (unet._tail_split_of).  Same latents, bit
+    for bit, as the one-forward-per-step loop -- with the readme's three-branch text switching (per-prompt svf step counts: plain,
+    projected and MIXED text buffers all pass through the split path's regather), a firing gate and the sync-free window."""
+    _, sd, _, refs, _ = world
+    P, steps = 65, 6
+    g = torch.Generator().manual_seed(65)
+    E = torch.randn(2 * P, 77, 768, generator=g)
+    Es = _safe_text(E, P, 78)
+    sf = dict(safree=True, svf=True, lra=True, re_attn_t=(-1, -1))
+    params = dict(sigma=3.15, scale=0.33, beta_threshold=1e-6, beta_threshold_margin=1e9)
+    u = UNet2DConditionModel(text_len=77, latent_repeat=3, **SMALL); u.load_state_dict(sd)
+    beta = [(3 * p) % 5 for p in range(P)]                                          # svf step counts 0 .. 4: mixed batches at steps 1 .. 4
+
+    def run(split):
+        pipe = SafeDenoiserPipeline(u, DDPMScheduler(), variant="threshold_time")
+        pipe.tail_split = split
+        gens = [torch.Generator(device="cuda").manual_seed(1000 + p) for p in range(P)]
+        lat = pipe(prompt_embeddings=E.cuda(), num_inference_steps=steps, repellency_processor=make_proc(thr, refs, tmp_path, **params),
+                   generator=gens, safree_dict=sf, rescaled_text_embeddings=Es.cuda(), beta_adjusted=beta, return_latents=True)
+        return lat, pipe.last_stats, [int(g_.get_offset()) for g_ in gens]
+
+    a, st_a, off_a = run(False)
+    b, st_b, off_b = run(True)
+    assert st_a["tail_split"] is None and st_b["tail_split"] == (64, 1)
+    assert st_a["renoise_draws"] == st_b["renoise_draws"] > 0 and off_a == off_b
+    assert torch.equal(a, b)
+    c, _, _ = run(False)                                                             # and back: the plan's own text cache is not confused
+    assert torch.equal(a, c)

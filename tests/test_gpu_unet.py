@@ -250,3 +250,54 @@ def test_text_kv_reuse_is_bit_identical_and_really_skips(kw):
     y = outs(); u.forward_into(x, 961.0, tb, y)                                   # undeclared again: plain forward
     y2 = outs(); u.set_text_version(9); u.forward_into(x, 961.0, tb, y2)
     assert torch.equal(y, y2)
+
+
+@pytest.mark.parametrize("kw,p", [(dict(dtype=torch.bfloat16), 65), (dict(dtype=torch.float16), 67), (dict(precision="bf16x3"), 65)])
+def test_tail_split_forward_is_the_single_forward(kw, p):
+    """unet.UNet2DConditionModel.set_tail_split: a batch a few latents over a multiple of 64 samples runs its aligned part on the
+    caller's stream and its tail as a second forward (second handle, the same packed weights) on a side stream.  Rows do not interact
+    inside the UNet: the 16-bit plans give the SAME BITS as the single forward, the bf16x3 plan (row chunks of different lengths ->
+    another summation order in the last fp32 bit) agrees to 1e-5.  Covers the text handling of the split path: the branch-major
+    text rows are regathered when the declared version changes (and at every undeclared forward), not otherwise."""
+    rep = 3
+    one = UNet2DConditionModel(text_len=77, latent_repeat=rep, **kw, **SMALL)
+    one.load_state_dict(one.synthetic_state_dict(11))
+    two = UNet2DConditionModel(text_len=77, latent_repeat=rep, **kw, **SMALL).set_tail_split(True)
+    two._weights = one._weights
+    assert two._tail_split_of(rep * p) == (64, p - 64) and one._tail_split_of(rep * p) is None
+    assert two._tail_split_of(rep * 64) is None and two._tail_split_of(rep * 69) is None and two._tail_split_of(rep * 5) is None
+    g = torch.Generator().manual_seed(p)
+    x = torch.randn(p, 4, 16, 16, generator=g).cuda()
+    ta = one.prepare_text(torch.randn(rep * p, 77, 768, generator=g).cuda())
+    tb = one.prepare_text(torch.randn(rep * p, 77, 768, generator=g).cuda())
+    outs = lambda: torch.empty(rep * p, 4, 16, 16, device="cuda")
+    exact = "precision" not in kw
+
+    def same(y, ref, what):
+        if exact:
+            assert torch.equal(y, ref), what
+        else:
+            assert rel_l2(y, ref) <= 1e-5, (what, rel_l2(y, ref))
+
+    ref_a, ref_b = {}, outs()
+    for t in (981.0, 401.0):
+        ref_a[t] = outs(); one.forward_into(x, t, ta, ref_a[t])
+    one.forward_into(x, 981.0, tb, ref_b)
+    assert not torch.equal(ref_b, ref_a[981.0])
+    for t in (981.0, 401.0):                                                      # undeclared text: gathered at every forward
+        y = outs(); two.forward_into(x, t, ta, y); same(y, ref_a[t], ("undeclared", t))
+    two.set_text_version(41)
+    for t in (981.0, 401.0):
+        y = outs(); two.forward_into(x, t, ta, y); same(y, ref_a[t], ("declared", t))
+    ta.copy_(tb)                                                                  # new contents, version not bumped: the old text stands
+    y = outs(); two.forward_into(x, 981.0, ta, y); same(y, ref_a[981.0], "stale by contract")
+    two.set_text_version(42)
+    y = outs(); two.forward_into(x, 981.0, ta, y); same(y, ref_b, "new version")
+    two.set_text_version(0)
+    y = outs(); two.forward_into(x, 981.0, ta, y); same(y, ref_b, "undeclared again")
+    # an aligned batch on the same object takes the single-forward path (and its own text cache) afterwards
+    y64, r64 = torch.empty(rep * 64, 4, 16, 16, device="cuda"), torch.empty(rep * 64, 4, 16, 16, device="cuda")
+    t64 = ta.view(rep, p, 77, 768)[:, :64].reshape(rep * 64, 77, 768).contiguous()
+    two.forward_into(x[:64], 981.0, t64, y64); one.forward_into(x[:64], 981.0, t64, r64)
+    same(y64, r64, "aligned batch")
+    same(y64.view(rep, 64, -1), ref_b.view(rep, p, -1)[:, :64], "rows are independent")
