@@ -1600,6 +1600,22 @@ static int launch_x3t_gemm(const Op& o, const char* a, const char* w, const floa
   long per = g_x3_chunk_limit / a_bytes_unit;                                 // units per launch
   if (per < 1) return SDN_E_INVALID;
   if (per > units) per = units;
+  if (per < units) {
+    // More than one launch: EQUAL chunks that are whole waves of tiles where the operand allows it.  "As many units as fit, then the
+    // rest" gave 192 samples of a 960-channel 64^2 conv as 91 + 91 + 10 (6 + 6 + 1 waves of 256-row tiles on 256 CUs against 12 for
+    // the rows themselves) and the 3072 row blocks of FF2 at 64^2 as 1092 + 1092 + 888 (5 + 5 + 4); 64 + 64 + 64 and 3 x 1024 are 12.
+    const long n = (units + per - 1) / per;
+    long even = (units + n - 1) / n;
+    const int nrep = sdn_gemm_pick_tile((int)(even * rows_out_unit < d.M ? even * rows_out_unit : d.M), d.N, d.K, d.act, 0);
+    const long tile_rows = nrep >= 8 ? 256 : 128, tile_cols = 32L * (nrep > 0 ? nrep : 2);
+    const long tiles_per_unit = ((rows_out_unit + tile_rows - 1) / tile_rows) * ((d.N + tile_cols - 1) / tile_cols);
+    long a_ = 256, b_ = tiles_per_unit % 256;                                 // q = units per whole wave of 256 tiles = 256 / gcd(256, tiles_per_unit)
+    while (b_) { const long t_ = a_ % b_; a_ = b_; b_ = t_; }
+    const long q = 256 / a_;
+    const long aligned = (even + q - 1) / q * q;
+    if (aligned <= per) even = aligned;
+    per = even;
+  }
   const int n_cols = d.x3_out == 2 ? d.N / 2 : d.N;                           // logical output width
   const long out_row_bytes = d.x3_out == 0 ? 0 : ((d.x3_out == 1 || d.x3_out == 4) ? 4L * n_cols : 6L * n_cols);
   if (d.x3_out == 0 && per < units) return SDN_E_INVALID;                     // (the NCHW output of conv_out is not chunked: 4 channels)
