@@ -978,6 +978,14 @@ def main():
             measure_e2e_scheduled(args, dev, proc, min(P, 64), mine, {"window": True}, timed_batches=1, elide=True),
             note="the scheduled mode with lra's discarded third branch not computed (bit-identical latents, 2/3 of the UNet work): a labelled "
                  "secondary, NOT value_at_north_star_tolerance")
+        # the rest of the headroom, as a labelled frontier point (NOT value_at_north_star_tolerance, which keeps the 10 x margin): the
+        # precise plan on the first 9 steps only = 4.1-4.3e-4 from the fp32 chain on three weight seeds, every decision / draw count equal
+        # (profiles/round5_precision_schedule_first_n_seed*.md; asserted <= 1e-3 in tests/test_gpu_e2e_ids.py)
+        line["e2e_scheduled_first_9"] = dict(
+            measure_e2e_scheduled(args, dev, proc, min(P, 64), mine, {"first": 9}, timed_batches=1),
+            ids_to_latents_rel_l2_vs_fp32_plans="4.1e-4 ... 4.3e-4 max over 8 prompts on 3 weight seeds (north star: 1e-3), all decisions / draw "
+                                                "counts equal",
+            note="frontier point: 2.3 x inside the bound where e2e_scheduled (the window schedule) is 10 x inside it")
         line["value_at_north_star_tolerance_mode"] = "e2e_scheduled (fp16 plan + bf16x3 plan inside the repellency window; text encoder bf16x3)"
         line["parity"] = measure_parity(args, dev)
         line["job_515"] = measure_job(args, dev, P, beta)

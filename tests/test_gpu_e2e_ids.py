@@ -195,6 +195,17 @@ def test_token_ids_to_latents_against_the_fp32_chain_in_every_precision_mode(tmp
                                   "window_readbacks": pipe.last_stats["window_readbacks"]}
     print(f"the same with device generators and the sync-free window: latents rel L2 vs the fp32 plans max "
           f"{max(sched['device_generators']['latents_rel_l2_vs_fp32_plans']):.2e}, draws equal {sched['device_generators']['renoise_draws_equal']}")
+    # ---- what the rest of the headroom buys (recorded, not the default): the precise plan on the FIRST 9 steps only.  Measured 4.1-4.3e-4
+    # on three weight seeds (profiles/round5_precision_schedule_first_n_seed*.md), 2.3 x inside the north star's bound at 1.35 x the
+    # 16-bit cost (the window schedule: 1.43 x); asserted against the bound itself
+    pipe.precision_schedule = {"first": 9}
+    lat_9 = call(pipe)
+    sched["first_9_device_generators"] = {"latents_rel_l2_vs_fp32_plans": [rel_l2(lat_9[p:p + 1], lat32[p:p + 1]) for p in range(P)],
+                                          "precise_steps": pipe.last_stats["hi_steps"],
+                                          "renoise_draws_equal": pipe.last_stats["renoise_draws"] == draws32}
+    pipe.precision_schedule = SCHEDULE
+    print(f"precise plan on the first 9 steps only: latents rel L2 vs the fp32 plans max "
+          f"{max(sched['first_9_device_generators']['latents_rel_l2_vs_fp32_plans']):.2e}")
     del pipe, kept, p32
     torch.cuda.empty_cache()
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
@@ -219,5 +230,7 @@ def test_token_ids_to_latents_against_the_fp32_chain_in_every_precision_mode(tmp
     assert sched["precise_steps"] == 11
     assert all(sched["mask_equal"]) and all(sched["beta_adjusted_equal"]) and sched["renoise_draws_equal"], sched
     assert max(sched["latents_rel_l2"]) <= SCHEDULED_BOUND, sched["latents_rel_l2"]
+    f9 = sched["first_9_device_generators"]
+    assert f9["precise_steps"] == 9 and f9["renoise_draws_equal"] and max(f9["latents_rel_l2_vs_fp32_plans"]) <= 1e-3, f9
     dg = sched["device_generators"]
     assert dg["window_readbacks"] == 0 and dg["renoise_draws_equal"] and max(dg["latents_rel_l2_vs_fp32_plans"]) <= SCHEDULED_BOUND, dg

@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--ratio", type=float, default=2.95)
     ap.add_argument("--quick", action="store_true", help="every 5th sensitivity arm only")
     ap.add_argument("--verify", action="store_true", help="another weight seed: the two baselines and the candidate schedules only")
+    ap.add_argument("--arms", default="", help='with --verify: extra "first N" arms, e.g. --arms 7,8,9')
     ap.add_argument("--lo", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--scheduler", default="ddpm", choices=["ddpm", "ddim"], help="ddpm = the reference's live scheduler; ddim = the one BASELINE names")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "round5_precision_schedule"))
@@ -117,7 +118,8 @@ def main():
 
     if a.verify:
         for name, spec in (("window (11)", {"window": True}), ("first 10", {"first": 10}), ("first 15", {"first": 15}),
-                           ("window (11) + last 5", {"window": True, "last": 5})):
+                           ("window (11) + last 5", {"window": True, "last": 5})) + tuple(
+                               (f"first {int(k)}", {"first": int(k)}) for k in a.arms.split(",") if k.strip()):
             res["arms"].append(arm(name, spec)[0])
         res["wall_s"] = round(time.time() - t00, 1)
         os.makedirs(os.path.dirname(a.out), exist_ok=True)
