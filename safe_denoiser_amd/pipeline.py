@@ -507,7 +507,9 @@ class SafeDenoiserPipeline:
         lat = lat.clone()                                              # the loop buffers are reused by the next call
         self.last_stats = {"renoise_draws": n_renoise, "window_steps": n_window, "prompts": P, "branches": nb,
                            "hi_steps": int(sum(use_hi)), "window_readbacks": n_window if (use_flag and not dev_flags) else 0,
-                           "tail_split": next((u_._tail_split_of(nb * P) for u_ in nets if hasattr(u_, "_tail_split_of")), None)}
+                           "tail_split": next((u_._tail_split_of(nb * P) for u_ in nets if hasattr(u_, "_tail_split_of")), None),
+                           # how each UNet forward of this call ran: None = one launch plan, else [(first prompt, prompts, side stream)]
+                           "forward_chunks": next((u_._chunks_of(nb * P) for u_ in nets if hasattr(u_, "_chunks_of")), None)}
         if self.record_den:
             self.last_stats["denominators"] = den_log
         if return_latents:

@@ -294,39 +294,86 @@ class UNet2DConditionModel:
             return None
         return pm, r
 
-    def _forward_split(self, sample, timestep, text, out, pm, r):
+    def max_samples(self) -> int:
+        """Largest batch ONE launch plan addresses: the LDS-DMA tiles carry 31-bit byte offsets per operand, and the widest 16-bit
+        operand of a forward is an up-path resnet's input (skip connection concatenated: 64^2 x 960 channels = 7.9 MB per sample
+        for SD-v1.4 -> 273 samples).  Larger batches run as several forwards (`_chunks_of`)."""
+        c = self.config
+        boc = list(c.block_out_channels)
+        n = len(boc)
+        worst = max((c.sample_size >> i) ** 2 * (boc[min(i + 1, n - 1)] + boc[i]) * 2 for i in range(n))
+        return ((1 << 31) - 1) // worst
+
+    def _chunks_of(self, b: int):
+        """How a forward of b samples runs: None = one launch plan; else [(first latent, latents, on the side stream)].  Two reasons to
+        cut: the tail rule above, and a batch above `max_samples()` (it used to fail with SDN_E_INVALID): whole-wave chunks (multiples of
+        64 samples) one after the other on the caller's stream, each on its own handle (its own workspace and text K / V cache), a
+        small remainder beside them."""
+        if type(self) is not UNet2DConditionModel:
+            return None
+        rep = self.latent_repeat
+        p = b // rep
+        cap = self.max_samples() // rep                                # latents one plan takes
+        if p <= cap:
+            ts = self._tail_split_of(b)
+            return None if ts is None else [(0, ts[0], False), (ts[0], ts[1], True)]
+        q = 64 // math.gcd(64, rep)
+        per = cap // q * q if cap >= q else cap                        # whole waves of tiles where the cap allows it
+        chunks = [(lo, min(per, p - lo), False) for lo in range(0, p, per)]
+        lo, n, _ = chunks[-1]
+        if n * rep <= self.TAIL_MAX_SAMPLES and getattr(self, "tail_split", False) and rep > 1:
+            chunks[-1] = (lo, n, True)
+        return chunks
+
+    def _forward_chunks(self, sample, timestep, text, out, chunks):
         rep, dev = self.latent_repeat, sample.device
-        p = pm + r
+        p = sample.shape[0]
         st = getattr(self, "_split", None)
-        if st is None or st["key"] != (p, pm, dev):
-            tail = UNet2DConditionModel(text_len=self.text_len, dtype=self.dtype, latent_repeat=rep,
-                                        precision=self.precision if self.precision in ("fp32", "bf16x3") else None, **vars(self.config))
-            tshape = tuple(text.shape[1:])
-            st = self._split = dict(key=(p, pm, dev), tail=tail, side=torch.cuda.Stream(device=dev), text_key=None,
-                                    tm=torch.empty((rep * pm,) + tshape, dtype=self.dtype, device=dev),
-                                    tt=torch.empty((rep * r,) + tshape, dtype=self.dtype, device=dev),
-                                    ym=torch.empty((rep * pm,) + tuple(out.shape[1:]), dtype=torch.float32, device=dev),
-                                    yt=torch.empty((rep * r,) + tuple(out.shape[1:]), dtype=torch.float32, device=dev))
-        tail = st["tail"]
-        tail._weights = self._weights                                # the derived regions live in the buffer: nothing to prepare again
+        if st is None or st["key"] != (p, tuple(chunks), dev):
+            kw = dict(text_len=self.text_len, dtype=self.dtype, latent_repeat=rep,
+                      precision=self.precision if self.precision in ("fp32", "bf16x3") else None, **vars(self.config))
+            tshape, oshape = tuple(text.shape[1:]), tuple(out.shape[1:])
+            parts = [dict(lo=lo, n=n, side=side, net=self if i == 0 else UNet2DConditionModel(**kw),
+                          # rep = 1: a chunk's text / output rows are contiguous views of the caller's tensors, nothing is staged
+                          text=None if rep == 1 else torch.empty((rep * n,) + tshape, dtype=self.dtype, device=dev),
+                          out=None if rep == 1 else torch.empty((rep * n,) + oshape, dtype=torch.float32, device=dev))
+                     for i, (lo, n, side) in enumerate(chunks)]
+            st = self._split = dict(key=(p, tuple(chunks), dev), parts=parts, text_key=None,
+                                    side=torch.cuda.Stream(device=dev) if any(c[2] for c in chunks) else None)
         ver = int(getattr(self, "_text_version", 0))
         tkey = (ver, text.data_ptr())
-        if ver == 0 or st["text_key"] != tkey:                       # branch-major text rows [rep][p] -> [rep][pm] and [rep][r]
+        if rep > 1 and (ver == 0 or st["text_key"] != tkey):         # branch-major text rows [rep][p] -> [rep][n] per chunk
             tv = text.view(rep, p, *text.shape[1:])
-            st["tm"].view(rep, pm, *text.shape[1:]).copy_(tv[:, :pm])
-            st["tt"].view(rep, r, *text.shape[1:]).copy_(tv[:, pm:])
+            for c in st["parts"]:
+                c["text"].view(rep, c["n"], *text.shape[1:]).copy_(tv[:, c["lo"]:c["lo"] + c["n"]])
             st["text_key"] = tkey
-        tail.set_text_version(ver)
         cur = torch.cuda.current_stream(dev)
-        side = st["side"]
-        side.wait_stream(cur)                                        # latents and text are ready where the caller's stream stands
-        with torch.cuda.stream(side):
-            tail._forward_one(sample[pm:], timestep, st["tt"], st["yt"])
-        self._forward_one(sample[:pm], timestep, st["tm"], st["ym"])
-        cur.wait_stream(side)
-        ov = out.view(rep, p, -1)
-        ov[:, :pm].copy_(st["ym"].view(rep, pm, -1))
-        ov[:, pm:].copy_(st["yt"].view(rep, r, -1))
+        if st["side"] is not None:
+            st["side"].wait_stream(cur)                              # latents and text are ready where the caller's stream stands
+
+        def run(c):
+            net, lo, n = c["net"], c["lo"], c["n"]
+            if net is not self:
+                net._weights = self._weights                         # the derived regions live in the buffer: nothing to prepare again
+                net.set_text_version(ver)
+            if rep == 1:
+                net._forward_one(sample[lo:lo + n], timestep, text[lo:lo + n], out[lo:lo + n])
+            else:
+                net._forward_one(sample[lo:lo + n], timestep, c["text"], c["out"])
+
+        for c in st["parts"]:
+            if c["side"]:
+                with torch.cuda.stream(st["side"]):
+                    run(c)
+        for c in st["parts"]:
+            if not c["side"]:
+                run(c)
+        if st["side"] is not None:
+            cur.wait_stream(st["side"])
+        if rep > 1:
+            ov = out.view(rep, p, -1)
+            for c in st["parts"]:
+                ov[:, c["lo"]:c["lo"] + c["n"]].copy_(c["out"].view(rep, c["n"], -1))
         return out
 
     def forward_into(self, sample, timestep, text_bf16, out):
@@ -335,14 +382,16 @@ class UNet2DConditionModel:
         b = text_bf16.shape[0]
         if sample.shape[0] * self.latent_repeat != b or out.shape[0] != b:
             raise _lib.SdnError(f"batch mismatch: {sample.shape[0]} latents x latent_repeat {self.latent_repeat} vs {b} text rows")
-        split = self._tail_split_of(b)
-        if split is not None:
+        chunks = self._chunks_of(b)
+        if chunks is not None:
             _lib.dptr(sample, torch.float32), _lib.dptr(text_bf16, self.dtype), _lib.dptr(out, torch.float32)     # the loud checks
-            return self._forward_split(sample, timestep, text_bf16, out, *split)
+            return self._forward_chunks(sample, timestep, text_bf16, out, chunks)
         return self._forward_one(sample, timestep, text_bf16, out)
 
     def _forward_one(self, sample, timestep, text_bf16, out):
         b = text_bf16.shape[0]
+        if type(self) is UNet2DConditionModel and b > self.max_samples():
+            raise _lib.SdnError(f"{b} samples exceed what one launch plan addresses ({self.max_samples()}): forward_into cuts such batches")
         ws = self._workspace(b, sample.device)
         _lib.check(_lib.lib().sdn_unet_forward(self._h, _lib.dptr(self._weights), _lib.dptr(sample, torch.float32),
                                                float(timestep), _lib.dptr(text_bf16, self.dtype),

@@ -301,3 +301,59 @@ def test_tail_split_forward_is_the_single_forward(kw, p):
     two.forward_into(x[:64], 981.0, t64, y64); one.forward_into(x[:64], 981.0, t64, r64)
     same(y64, r64, "aligned batch")
     same(y64.view(rep, 64, -1), ref_b.view(rep, p, -1)[:, :64], "rows are independent")
+
+
+@pytest.mark.parametrize("rep", [3, 1])
+def test_chunked_forward_gives_the_single_forward(rep):
+    """unet._chunks_of / _forward_chunks with the plan limit lowered to 100 samples (max_samples is a method: the instance gets its
+    own): 67 latents x 3 branches run as 33 + 33 + 1 (the last one beside the others when the tail rule is on), 201 plain rows as
+    64 + 64 + 64 + 9 contiguous row blocks (whole waves below the cap) with nothing staged.  Same bits as the one forward; declared text versions keep working
+    (one text K / V cache per chunk handle)."""
+    one = UNet2DConditionModel(text_len=77, latent_repeat=rep, **SMALL)
+    one.load_state_dict(one.synthetic_state_dict(11))
+    two = UNet2DConditionModel(text_len=77, latent_repeat=rep, **SMALL).set_tail_split(True)
+    two._weights = one._weights
+    two.max_samples = lambda: 100
+    p = 67 if rep == 3 else 201
+    want = [(0, 33, False), (33, 33, False), (66, 1, True)] if rep == 3 else [(0, 64, False), (64, 64, False), (128, 64, False), (192, 9, False)]
+    assert two._chunks_of(rep * p) == want and one._chunks_of(rep * p) is None
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(p, 4, 16, 16, generator=g).cuda()
+    ta = one.prepare_text(torch.randn(rep * p, 77, 768, generator=g).cuda())
+    tb = one.prepare_text(torch.randn(rep * p, 77, 768, generator=g).cuda())
+    outs = lambda: torch.empty(rep * p, 4, 16, 16, device="cuda")
+    ref_a, ref_a2, ref_b = outs(), outs(), outs()
+    one.forward_into(x, 981.0, ta, ref_a); one.forward_into(x, 401.0, ta, ref_a2); one.forward_into(x, 981.0, tb, ref_b)
+    y = outs(); two.forward_into(x, 981.0, ta, y); assert torch.equal(y, ref_a)
+    two.set_text_version(5)
+    for t, ref in ((981.0, ref_a), (401.0, ref_a2)):
+        y = outs(); two.forward_into(x, t, ta, y); assert torch.equal(y, ref), t
+    two.set_text_version(6)
+    y = outs(); two.forward_into(x, 981.0, tb, y); assert torch.equal(y, ref_b)
+    two.set_text_version(0)
+
+
+def test_full_size_batch_above_the_plan_limit_runs_in_chunks():
+    """Full SD-v1.4: 92 prompts x 3 branches = 276 samples is 3 over what one launch plan addresses (`max_samples()` = 273: the
+    960-channel 64^2 operand of the up path reaches 2 GiB, where `sdn_gemm` answers SDN_E_INVALID).  `forward_into` runs it as 64 + 28
+    prompts; rows equal the rows of the 64-prompt and 28-prompt forwards."""
+    from safe_denoiser_amd import _lib
+    u = UNet2DConditionModel(text_len=77, latent_repeat=3)
+    u.load_synthetic_on_device(77)
+    assert u.max_samples() == 273 and u._chunks_of(276) == [(0, 64, False), (64, 28, False)]
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randn(92, 4, 64, 64, generator=g, device="cuda")
+    tb = u.prepare_text(torch.randn(276, 77, 768, generator=g, device="cuda"))
+    y = torch.empty(276, 4, 64, 64, device="cuda")
+    with pytest.raises(_lib.SdnError, match="exceed what one launch plan addresses"):
+        u._forward_one(x, 981.0, tb, y)                      # (refused on the host: nothing is launched)
+    u.forward_into(x, 981.0, tb, y)
+    assert bool(torch.isfinite(y).all())
+    t64 = tb.view(3, 92, 77, 768)[:, :64].reshape(192, 77, 768).contiguous()
+    y64 = torch.empty(192, 4, 64, 64, device="cuda")
+    UNet2DConditionModel.forward_into(u, x[:64], 981.0, t64, y64)
+    assert torch.equal(y.view(3, 92, -1)[:, :64], y64.view(3, 64, -1))
+    t28 = tb.view(3, 92, 77, 768)[:, 64:].reshape(84, 77, 768).contiguous()
+    y28 = torch.empty(84, 4, 64, 64, device="cuda")
+    u.forward_into(x[64:], 981.0, t28, y28)
+    assert torch.equal(y.view(3, 92, -1)[:, 64:], y28.view(3, 28, -1))

@@ -42,3 +42,28 @@ def test_default_is_off_on_the_model_and_on_in_the_pipeline():
     assert u.tail_split is False and u._tail_split_of(195) is None
     assert u.set_tail_split(True)._tail_split_of(195) == (64, 1)
     assert SafeDenoiserPipeline(u, DDPMScheduler()).tail_split is True
+
+
+def test_batches_above_the_plan_limit_are_cut_into_whole_wave_chunks():
+    """unet.max_samples / _chunks_of: one launch plan addresses its operands with 31-bit offsets -> 273 samples for SD-v1.4; above that
+    the forward used to fail (SDN_E_INVALID), now it runs as chunks of 64 x k samples, a small remainder beside them."""
+    u = UNet2DConditionModel(text_len=77, latent_repeat=3)
+    assert u.max_samples() == 273
+    assert u._chunks_of(3 * 64) is None and u._chunks_of(3 * 91) is None                      # fits: one plan (no tail rule: split off)
+    assert u._chunks_of(3 * 92) == [(0, 64, False), (64, 28, False)]
+    assert u._chunks_of(3 * 128) == [(0, 64, False), (64, 64, False)]
+    assert u._chunks_of(3 * 130) == [(0, 64, False), (64, 64, False), (128, 2, False)]
+    u.set_tail_split(True)
+    assert u._chunks_of(3 * 65) == [(0, 64, False), (64, 1, True)]                            # the tail rule, in the same form
+    assert u._chunks_of(3 * 130) == [(0, 64, False), (64, 64, False), (128, 2, True)]
+    assert u._chunks_of(3 * 133) == [(0, 64, False), (64, 64, False), (128, 5, False)]        # 15 samples: a chunk of its own, in line
+    for p in range(1, 700):
+        ch = u._chunks_of(3 * p)
+        if ch is not None:
+            assert [c[0] for c in ch] == [sum(c[1] for c in ch[:i]) for i in range(len(ch))] and sum(c[1] for c in ch) == p
+            assert all(3 * c[1] <= 273 for c in ch) and all(c[1] % 64 == 0 for c in ch[:-1])
+    plain = UNet2DConditionModel(text_len=77)                                                  # latent_repeat 1: rows are cut directly
+    assert plain._chunks_of(273) is None and plain._chunks_of(384) == [(0, 256, False), (256, 128, False)]
+    two = UNet2DConditionModel(text_len=77, latent_repeat=2)
+    assert two._chunks_of(2 * 136) is None and two._chunks_of(2 * 137) == [(0, 128, False), (128, 9, False)]
+    assert _net(3, cls=SD3Transformer2DModel)._chunks_of(3000) is None                         # other plans keep their own rules
