@@ -103,8 +103,25 @@ class SD3Transformer2DModel(UNet2DConditionModel):
             raise _lib.SdnError(f"encoder_hidden_states must be [B,{self.text_len},{self.config.joint_attention_dim}]")
         return e.to(self.dtype).contiguous()
 
+    def max_samples(self) -> int:
+        """Largest batch ONE launch plan addresses (31-bit LDS-DMA offsets per operand): the widest 16-bit operand is the feed-forward
+        hidden state, tokens x 4 x width x 2 B per sample -- 170 samples at 512^2, 42 at 1024^2 for SD3-medium.  `forward_into` runs
+        larger batches as consecutive row blocks (samples do not interact; one handle: this plan keeps no per-text cache)."""
+        c = self.config
+        tokens = (c.sample_size // c.patch_size) ** 2
+        return ((1 << 31) - 1) // (tokens * 4 * c.num_attention_heads * c.attention_head_dim * 2)
+
     def forward_into(self, sample, timestep, text16, pooled16, out):
         b = sample.shape[0]
+        cap = self.max_samples()
+        if b > cap:
+            if text16.shape[0] != b or pooled16.shape[0] != b or out.shape[0] != b:
+                raise _lib.SdnError("batch mismatch between sample, text, pooled projections and out")
+            per = max(cap // 2 * 2, 1)                          # (even: a classifier-free-guidance pair's halves stay whole blocks apart)
+            for lo in range(0, b, per):
+                hi = min(b, lo + per)
+                self.forward_into(sample[lo:hi], timestep, text16[lo:hi], pooled16[lo:hi], out[lo:hi])
+            return out
         ws = self._workspace(b, sample.device)
         _lib.check(_lib.lib().sdn_mmdit_forward(self._h, _lib.dptr(self._weights), _lib.dptr(sample, torch.float32),
                                                 float(timestep), _lib.dptr(text16, self.dtype),

@@ -302,7 +302,12 @@ class UNet2DConditionModel:
         boc = list(c.block_out_channels)
         n = len(boc)
         worst = max((c.sample_size >> i) ** 2 * (boc[min(i + 1, n - 1)] + boc[i]) * 2 for i in range(n))
-        return ((1 << 31) - 1) // worst
+        cap = ((1 << 31) - 1) // worst
+        if self.precision in ("fp32", "bf16x3"):
+            # fp32-storage plans: their GEMMs cut launches themselves (6-byte triples), the other kernels index 4-byte tensors of twice
+            # the size; exercised up to 195 samples at full size (tests, tools/ab_tail_split.py) -- stay where that evidence is
+            cap = min(cap, 3 * (cap // 4))
+        return cap
 
     def _chunks_of(self, b: int):
         """How a forward of b samples runs: None = one launch plan; else [(first latent, latents, on the side stream)].  Two reasons to

@@ -106,6 +106,23 @@ def test_small_mmdit_matches_oracle(dtype, tol):
     assert r_em <= tol and r_32 <= tol
 
 
+def test_mmdit_batch_above_the_plan_limit_runs_as_row_blocks():
+    """SD3Transformer2DModel.max_samples: 170 samples at 512^2 / 42 at 1024^2 is what one plan addresses (31-bit operand offsets on the
+    feed-forward hidden state); above it `forward_into` runs consecutive row blocks.  Small configuration with the limit lowered to
+    3: 7 samples run as 2 + 2 + 2 + 1 and give the single forward's bits."""
+    assert SD3Transformer2DModel(sample_size=64).max_samples() == 170 and SD3Transformer2DModel(sample_size=128).max_samples() == 42
+    m = SD3Transformer2DModel(text_len=45, dtype=torch.float16, **SMALL)
+    m.load_state_dict(m.synthetic_state_dict(5))
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(7, 16, 16, 16, generator=g).cuda(); e = m.prepare_text(torch.randn(7, 45, 128, generator=g).cuda())
+    pl = torch.randn(7, 64, generator=g).cuda().half()
+    ref, y = torch.empty(7, 16, 16, 16, device="cuda"), torch.empty(7, 16, 16, 16, device="cuda")
+    m.forward_into(x, 812.0, e, pl, ref)
+    m.max_samples = lambda: 3
+    m.forward_into(x, 812.0, e, pl, y)
+    assert torch.equal(y, ref)
+
+
 @pytest.mark.parametrize("side", [64, 128])
 def test_full_sd3_medium_plan_runs(side):
     """The 2 B-parameter SD3-medium plan at the reference driver's default 512x512 (latent 64) and at BASELINE config 4's

@@ -333,27 +333,26 @@ def test_chunked_forward_gives_the_single_forward(rep):
     two.set_text_version(0)
 
 
-def test_full_size_batch_above_the_plan_limit_runs_in_chunks():
+@pytest.mark.parametrize("kw,p,cap", [(dict(), 92, 273), (dict(precision="bf16x3"), 70, 204)])
+def test_full_size_batch_above_the_plan_limit_runs_in_chunks(kw, p, cap):
     """Full SD-v1.4: 92 prompts x 3 branches = 276 samples is 3 over what one launch plan addresses (`max_samples()` = 273: the
-    960-channel 64^2 operand of the up path reaches 2 GiB, where `sdn_gemm` answers SDN_E_INVALID).  `forward_into` runs it as 64 + 28
-    prompts; rows equal the rows of the 64-prompt and 28-prompt forwards."""
+    960-channel 64^2 operand of the up path reaches 2 GiB, where `sdn_gemm` answers SDN_E_INVALID; the fp32-storage plans stop at 204).
+    `forward_into` runs it as 64 + 28 prompts (bf16x3: 70 prompts as 64 + 6); rows equal the rows of the two forwards run by hand."""
     from safe_denoiser_amd import _lib
-    u = UNet2DConditionModel(text_len=77, latent_repeat=3)
+    u = UNet2DConditionModel(text_len=77, latent_repeat=3, **kw)
     u.load_synthetic_on_device(77)
-    assert u.max_samples() == 273 and u._chunks_of(276) == [(0, 64, False), (64, 28, False)]
+    r = p - 64
+    assert u.max_samples() == cap and u._chunks_of(3 * p) == [(0, 64, False), (64, r, False)]
     g = torch.Generator(device="cuda").manual_seed(1)
-    x = torch.randn(92, 4, 64, 64, generator=g, device="cuda")
-    tb = u.prepare_text(torch.randn(276, 77, 768, generator=g, device="cuda"))
-    y = torch.empty(276, 4, 64, 64, device="cuda")
+    x = torch.randn(p, 4, 64, 64, generator=g, device="cuda")
+    tb = u.prepare_text(torch.randn(3 * p, 77, 768, generator=g, device="cuda"))
+    y = torch.empty(3 * p, 4, 64, 64, device="cuda")
     with pytest.raises(_lib.SdnError, match="exceed what one launch plan addresses"):
         u._forward_one(x, 981.0, tb, y)                      # (refused on the host: nothing is launched)
     u.forward_into(x, 981.0, tb, y)
     assert bool(torch.isfinite(y).all())
-    t64 = tb.view(3, 92, 77, 768)[:, :64].reshape(192, 77, 768).contiguous()
-    y64 = torch.empty(192, 4, 64, 64, device="cuda")
-    UNet2DConditionModel.forward_into(u, x[:64], 981.0, t64, y64)
-    assert torch.equal(y.view(3, 92, -1)[:, :64], y64.view(3, 64, -1))
-    t28 = tb.view(3, 92, 77, 768)[:, 64:].reshape(84, 77, 768).contiguous()
-    y28 = torch.empty(84, 4, 64, 64, device="cuda")
-    u.forward_into(x[64:], 981.0, t28, y28)
-    assert torch.equal(y.view(3, 92, -1)[:, 64:], y28.view(3, 28, -1))
+    for lo, n in ((0, 64), (64, r)):
+        t_ = tb.view(3, p, 77, 768)[:, lo:lo + n].reshape(3 * n, 77, 768).contiguous()
+        y_ = torch.empty(3 * n, 4, 64, 64, device="cuda")
+        u.forward_into(x[lo:lo + n], 981.0, t_, y_)
+        assert torch.equal(y.view(3, p, -1)[:, lo:lo + n], y_.view(3, n, -1)), (lo, n)

@@ -67,3 +67,6 @@ def test_batches_above_the_plan_limit_are_cut_into_whole_wave_chunks():
     two = UNet2DConditionModel(text_len=77, latent_repeat=2)
     assert two._chunks_of(2 * 136) is None and two._chunks_of(2 * 137) == [(0, 128, False), (128, 9, False)]
     assert _net(3, cls=SD3Transformer2DModel)._chunks_of(3000) is None                         # other plans keep their own rules
+    x3 = UNet2DConditionModel(text_len=77, latent_repeat=3, precision="bf16x3")               # fp32 storage: 3/4 of the 16-bit limit
+    assert x3.max_samples() == 204 and x3._chunks_of(3 * 68) is None and x3._chunks_of(3 * 70) == [(0, 64, False), (64, 6, False)]
+    assert SD3Transformer2DModel(sample_size=64).max_samples() == 170 and SD3Transformer2DModel(sample_size=128).max_samples() == 42
