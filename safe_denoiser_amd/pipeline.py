@@ -96,6 +96,12 @@ class SafeDenoiserPipeline:
         # its aligned part and its tail as two concurrent forwards (unet.UNet2DConditionModel._tail_split_of): same bits on the
         # 16-bit plans, -3.6 % per step at 65 prompts.  False: always one forward per step.
         self.tail_split = True
+        # Precision per (step, BRANCH) (round 5): with `lra` the third guidance branch is computed and discarded (...threshold_time.py:542-544),
+        # so its precision cannot reach the latents.  At the steps the schedule sends to `unet_hi`, the two LIVE branches run on the
+        # precise plan and the discarded one on the 16-bit plan -- the reference's work, branch for branch, with the precise arithmetic
+        # only where a result is read.  False: all three branches on `unet_hi` at those steps.
+        self.dead_branch_lo = True
+        self._sib = {}
         self.device_flags = True   # False: read the is_negation flags back at every window step (rounds 1-4; same bits either way)
         self.batched_safree = True  # False: the SAFREE projection prompt by prompt (safree.prepare), as the reference runs it
         self.record_den = False    # diagnostics: keep each window step's denominators (device tensors, no sync) in last_stats
@@ -404,12 +410,24 @@ class SafeDenoiserPipeline:
         dev_flags = bool(self.device_flags and rng is not None and rng.ok and use_flag
                          and hasattr(repellency_processor, "conditioning_device"))
         fired_acc = bf["fired"].zero_() if dev_flags else None
+        # per-branch precision at the precise steps (see __init__): needs a discarded branch (lra, not SLD: its third branch is live), both
+        # plans in this call, shared latents, and the engine's own UNet class on both sides
+        from .unet import UNet2DConditionModel
+        dead_lo = bool(self.dead_branch_lo and self.unet_hi is not None and nb == 3 and sf["lra"] and not sld and shared_latents
+                       and any(use_hi) and not all(use_hi) and type(self.unet) is UNet2DConditionModel
+                       and type(self.unet_hi) is UNet2DConditionModel)
+        hi2 = lo1 = None
+        n_dead_lo = 0
+        if dead_lo:
+            hi2, lo1 = self._sibling(self.unet_hi, 2), self._sibling(self.unet, 1)
+            for sib in (hi2, lo1):
+                sib.set_tail_split(bool(self.tail_split))
+                sib.set_graph_mode(nb * P <= self.GRAPH_MAX_BATCH if self.use_graphs is None else bool(self.use_graphs))
 
         try:
             for i, t in enumerate(timesteps):
                 u = self.unet_hi if use_hi[i] else self.unet
                 tx = texts[id(u)]
-                tbuf = tx["buf"]
                 if not shared_latents:
                     x_in.view(nb, P, C_, s, s).copy_(lat)                               # cat([latents] * nb)
                 # which prompts see the SAFREE-projected text at this step (...threshold_time.py:525-532); with the
@@ -420,20 +438,34 @@ class SafeDenoiserPipeline:
                     safe_p = [ba is not None and i <= ba for ba in beta_list]
                 else:
                     safe_p = [sf["re_attn_t"][0] <= i <= sf["re_attn_t"][1]] * P
-                if all(safe_p):
-                    tb, ver = tbuf["safe"], tx["ver_safe"]
-                elif not any(safe_p):
-                    tb, ver = tbuf["plain"], tx["ver_plain"]
-                else:
+
+                def pick_text(tx):                                                      # this step's text operand of one plan: (buffer, version)
+                    tbuf = tx["buf"]
+                    if all(safe_p):
+                        return tbuf["safe"], tx["ver_safe"]
+                    if not any(safe_p):
+                        return tbuf["plain"], tx["ver_plain"]
                     if tx["mix_key"] != tuple(safe_p):                                  # the set of projected prompts changed: rebuild the mix
                         pick = torch.tensor(safe_p * nb, device=dev)[:, None, None]
                         tbuf["mix"].copy_(torch.where(pick, tbuf["safe"], tbuf["plain"]))
                         tx["mix_key"] = tuple(safe_p)
                         tx["ver_mix"] = next(_TEXT_VERSIONS)
-                    tb, ver = tbuf["mix"], tx["ver_mix"]
-                if tx["has_ver"]:
-                    u.set_text_version(ver)
-                u.forward_into(lat if shared_latents else x_in, float(t), tb, model_out)
+                    return tbuf["mix"], tx["ver_mix"]
+
+                tb, ver = pick_text(tx)
+                if dead_lo and use_hi[i]:
+                    # live branches [uncond | text'] on the precise plan, the discarded third on the 16-bit plan; rows are branch-major,
+                    # so both operands and both outputs are contiguous row ranges of the plans' own text buffers / of model_out
+                    tb_lo, ver_lo = pick_text(texts[id(self.unet)])
+                    hi2.set_text_version(ver)
+                    hi2.forward_into(lat, float(t), tb[:2 * P], model_out[:2 * P])
+                    lo1.set_text_version(ver_lo)
+                    lo1.forward_into(lat, float(t), tb_lo[2 * P:], model_out[2 * P:])
+                    n_dead_lo += 1
+                else:
+                    if tx["has_ver"]:
+                        u.set_text_version(ver)
+                    u.forward_into(lat if shared_latents else x_in, float(t), tb, model_out)
                 if sld and g_rows is not None:
                     _lib.check(L.sdn_sld_guidance_rows(model_out.data_ptr(), P, D, g_rows.data_ptr(), sld["scale"], sld["thr"],
                                                        sld["ms"], sld["mb"], int(i >= sld["warmup"]), momentum.data_ptr(),
@@ -500,13 +532,16 @@ class SafeDenoiserPipeline:
             for u_ in nets:
                 if texts[id(u_)]["has_ver"]:
                     u_.set_text_version(0)
+            for sib in (hi2, lo1):
+                if sib is not None:
+                    sib.set_text_version(0)
             if dev_flags:
                 rng.sync_host()
         if dev_flags:
             n_renoise = int(fired_acc.sum().item())                    # after the loop: the call's one count readback
         lat = lat.clone()                                              # the loop buffers are reused by the next call
         self.last_stats = {"renoise_draws": n_renoise, "window_steps": n_window, "prompts": P, "branches": nb,
-                           "hi_steps": int(sum(use_hi)), "window_readbacks": n_window if (use_flag and not dev_flags) else 0,
+                           "hi_steps": int(sum(use_hi)), "dead_branch_lo_steps": n_dead_lo, "window_readbacks": n_window if (use_flag and not dev_flags) else 0,
                            "tail_split": next((u_._tail_split_of(nb * P) for u_ in nets if hasattr(u_, "_tail_split_of")), None),
                            # how each UNet forward of this call ran: None = one launch plan, else [(first prompt, prompts, side stream)]
                            "forward_chunks": next((u_._chunks_of(nb * P) for u_ in nets if hasattr(u_, "_chunks_of")), None)}
@@ -515,6 +550,18 @@ class SafeDenoiserPipeline:
         if return_latents:
             return lat
         return self.decode_latents(lat, output_type)
+
+    def _sibling(self, net, rep: int):
+        """A second launch plan over `net`'s packed weights with another latent_repeat (kept for the pipeline's lifetime)."""
+        from .unet import UNet2DConditionModel
+        key = (id(net), rep)
+        sib = self._sib.get(key)
+        if sib is None:
+            sib = self._sib[key] = UNet2DConditionModel(text_len=net.text_len, dtype=net.dtype, latent_repeat=rep,
+                                                        precision=net.precision if net.precision in ("fp32", "bf16x3") else None,
+                                                        **vars(net.config))
+        sib._weights = net._weights                                   # the derived regions live in the buffer: nothing to prepare again
+        return sib
 
     # ---- precision schedule ---------------------------------------------------------------------------------
     def hi_steps(self, timesteps, kind=None, lo=0, hi=0):

@@ -476,3 +476,39 @@ def test_a_batch_a_few_prompts_over_whole_waves_runs_split_and_gives_the_same_la
     assert torch.equal(a, b)
     c, _, _ = run(False)                                                             # and back: the plan's own text cache is not confused
     assert torch.equal(a, c)
+
+
+def test_discarded_lra_branch_runs_on_the_16_bit_plan_at_precise_steps(world, tmp_path):
+    """`pipe.dead_branch_lo` (default on): at the steps a precision schedule sends to `unet_hi`, the two live guidance branches run on the
+    precise plan and `lra`'s discarded third branch on the 16-bit plan (the reference computes it and drops it, ...threshold_time.py:
+    542-544: its precision cannot reach the latents).  Same latents as running all three branches on the precise plan -- to the last
+    fp32 bits of a differently shaped launch (<= 1e-5; the bound a split forward of the bf16x3 plan gets everywhere) --, same draw
+    counts and tape cursors; without `lra` (two branches, both live) nothing changes."""
+    _, sd, E, refs, P = world
+    shape = (1, 4, 16, 16)
+    Es = _safe_text(E, P, 77)
+    params = dict(sigma=3.15, scale=0.33, beta_threshold=1e-6, beta_threshold_margin=1e9)
+    lo = UNet2DConditionModel(text_len=77, dtype=torch.float16, latent_repeat=3, **SMALL); lo.load_state_dict(sd)
+    hi = UNet2DConditionModel(text_len=77, precision="bf16x3", latent_repeat=3, **SMALL); hi.load_state_dict(sd)
+
+    def run(split, u_lo=lo, u_hi=hi, lra=True):
+        sf = dict(safree=True, svf=True, lra=lra, re_attn_t=(-1, -1))
+        pipe = SafeDenoiserPipeline(u_lo, DDPMScheduler(), variant="threshold_time", unet_hi=u_hi, precision_schedule={"window": True})
+        pipe.dead_branch_lo = split
+        t = Tapes(P, shape, 3 * STEPS + 4, seed=21)
+        lat = pipe(prompt_embeddings=E.cuda(), num_inference_steps=STEPS, repellency_processor=make_proc(thr, refs, tmp_path, **params),
+                   noise_fn=t, safree_dict=sf, rescaled_text_embeddings=Es.cuda(), beta_adjusted=[3, 0, 7][:P], return_latents=True)
+        return lat, pipe.last_stats, list(t.cur)
+
+    a, st_a, cur_a = run(False)
+    b, st_b, cur_b = run(True)
+    assert st_a["dead_branch_lo_steps"] == 0 and st_b["dead_branch_lo_steps"] == st_b["hi_steps"] == st_b["window_steps"] == 2
+    assert cur_a == cur_b and st_a["renoise_draws"] == st_b["renoise_draws"] > 0
+    d = rel_l2(b, a)
+    print(f"discarded branch on the 16-bit plan at the precise steps: latents vs all three on the precise plan {d:.2e}")
+    assert d <= 1e-5
+    lo2 = UNet2DConditionModel(text_len=77, dtype=torch.float16, latent_repeat=2, **SMALL); lo2._weights = lo._weights
+    hi2 = UNet2DConditionModel(text_len=77, precision="bf16x3", latent_repeat=2, **SMALL); hi2._weights = hi._weights
+    c, st_c, _ = run(True, lo2, hi2, lra=False)
+    e, st_e, _ = run(False, lo2, hi2, lra=False)
+    assert st_c["dead_branch_lo_steps"] == 0 and st_c["branches"] == 2 and torch.equal(c, e)
