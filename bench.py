@@ -482,7 +482,9 @@ def measure_e2e_scheduled(args, dev, proc, P, mine, schedule, lo="f16", timed_ba
            "workload": "the headline call (README-default end to end, 3 guidance branches)", "prompts_per_batch": P,
            "timed_batches": timed_batches, "ms_per_batch": dt * 1e3, "renoise_draws": renoise,
            "guidance_branches_computed": pipe.last_stats["branches"],
-           "window_readbacks_per_batch": pipe.last_stats["window_readbacks"]}
+           "window_readbacks_per_batch": pipe.last_stats["window_readbacks"],
+           # precise steps at which lra's DISCARDED third branch ran on the 16-bit plan (the two live branches on the precise one)
+           "precise_steps_with_discarded_branch_16bit": pipe.last_stats.get("dead_branch_lo_steps", 0)}
     del u_lo, u_hi, enc, vae, pipe
     torch.cuda.empty_cache()
     return res
@@ -989,7 +991,8 @@ def main():
             ids_to_latents_rel_l2_vs_fp32_plans="4.1e-4 ... 4.3e-4 max over 8 prompts on 3 weight seeds (north star: 1e-3), all decisions / draw "
                                                 "counts equal",
             note="frontier point: 2.3 x inside the bound where e2e_scheduled (the window schedule) is 10 x inside it")
-        line["value_at_north_star_tolerance_mode"] = "e2e_scheduled (fp16 plan + bf16x3 plan inside the repellency window; text encoder bf16x3)"
+        line["value_at_north_star_tolerance_mode"] = ("e2e_scheduled (fp16 plan + bf16x3 plan inside the repellency window, there on the two live "
+                                                      "guidance branches -- lra's discarded third branch stays on the fp16 plan; text encoder bf16x3)")
         line["parity"] = measure_parity(args, dev)
         line["job_515"] = measure_job(args, dev, P, beta)
         line["job_515"]["steady_vs_value"] = (line["job_515"]["steady_images_per_sec"] or 0.0) / value
