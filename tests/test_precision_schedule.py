@@ -56,3 +56,26 @@ def test_schedule_errors():
         latent_repeat = 2
     with pytest.raises(SdnError):
         SafeDenoiserPipeline(_U(), DDPMScheduler(), unet_hi=Other(), precision_schedule="all")
+
+
+def test_pipeline_keeps_one_sibling_plan_per_net_and_branch_count():
+    """`_sibling` (the handles the per-branch precision of the precise steps runs on: the precise plan with two branches, the 16-bit plan
+    with one): same architecture / storage type / precision as the net, another latent_repeat, the SAME weights object, created once."""
+    import torch
+    from safe_denoiser_amd.pipeline import SafeDenoiserPipeline
+    from safe_denoiser_amd.schedulers import DDPMScheduler
+    from safe_denoiser_amd.unet import UNet2DConditionModel
+    small = dict(block_out_channels=(320, 640), down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"), layers_per_block=1,
+                 attention_head_dim=8, cross_attention_dim=768, sample_size=16)
+    lo = UNet2DConditionModel(text_len=77, dtype=torch.float16, latent_repeat=3, **small)
+    hi = UNet2DConditionModel(text_len=77, precision="bf16x3", latent_repeat=3, **small)
+    lo._weights, hi._weights = object(), object()                    # (stand-ins: no GPU here)
+    pipe = SafeDenoiserPipeline(lo, DDPMScheduler(), unet_hi=hi, precision_schedule={"window": True})
+    assert pipe.dead_branch_lo is True
+    h2, l1 = pipe._sibling(hi, 2), pipe._sibling(lo, 1)
+    assert (h2.latent_repeat, h2.precision, h2.dtype, h2._weights is hi._weights) == (2, "bf16x3", torch.float32, True)
+    assert (l1.latent_repeat, l1.precision, l1.dtype, l1._weights is lo._weights) == (1, None, torch.float16, True)
+    assert vars(h2.config) == vars(hi.config) and h2.weight_bytes == hi.weight_bytes and l1.weight_bytes == lo.weight_bytes
+    assert pipe._sibling(hi, 2) is h2 and pipe._sibling(lo, 1) is l1
+    new_w = object(); lo._weights = new_w                            # reloaded weights are picked up at the next use
+    assert pipe._sibling(lo, 1)._weights is new_w
